@@ -1,0 +1,720 @@
+// ce.hip -- a11-a13: EntropyOptim (src/embedder.rs:936-1345) on device.
+//
+//   ce_sgd_hogwild_kernel    gradient_iteration_threaded (:1311-1315): one thread per SGD sample,
+//                            lock-free in-place updates of the coordinate array (the reference's
+//                            rayon loop is Hogwild too, :1197).
+//   ce_plan_kernel + ce_sgd_planned_kernel
+//                            AE_CE_SEQUENTIAL: the node set of every sample depends only on the
+//                            graph and the RNG stream, so it is drawn first (plan), the host derives
+//                            a conflict-free level schedule that is equivalent to executing samples
+//                            0,1,2,... one after the other (gradient_iteration, :1305-1309), and each
+//                            level is one launch.  All arithmetic stays on the GPU.
+//   ce_value_kernel          ce_compute_threaded (:1127-1163).
+//
+// Per-sample arithmetic follows ce_optim_edge_shannon (:1167-1302) operation by operation:
+// coordinates f32, scalars f64, no FMA contraction, so that with b = 1 the sequential mode is
+// bit-exact against the CPU oracle.
+#include <algorithm>
+
+#include "internal.h"
+#include "philox.h"
+
+using namespace ae;
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct CeDev {
+    uint64_t n, nnz;
+    uint32_t dim, uniform_k;
+    const uint64_t* indptr;
+    const uint32_t* nbr;
+    const float* proba;
+    const float* emb_scale;
+    float* y;
+    double b;
+    uint64_t seed;
+    uint32_t sampler;
+    uint64_t node_lo, node_hi, edge_lo, shard_edges;
+    const float* edge_odds;
+    const uint32_t* edge_alias;
+    const uint32_t* edge_src;
+    const float* hub_odds;
+    const uint32_t* hub_alias;
+};
+
+struct Plan {
+    uint32_t i, j, k[5];
+    float w;
+};
+
+__device__ __forceinline__ void row_bounds(const CeDev& c, uint32_t i, uint64_t& b, uint32_t& len) {
+    if (c.uniform_k) {
+        b = (uint64_t)i * c.uniform_k;
+        len = c.uniform_k;
+    } else {
+        b = c.indptr[i];
+        len = (uint32_t)(c.indptr[i + 1] - b);
+    }
+}
+
+// draws the positive edge and the 5 accepted negatives of sample s (embedder.rs:1182-1184, 1241-1253)
+__device__ __forceinline__ bool make_plan(const CeDev& c, uint64_t s, uint32_t iter, Plan& p) {
+    PhiloxStream st(c.seed, s, iter);
+    uint64_t e;
+    uint64_t ib;
+    uint32_t ilen;
+    if (c.sampler == AE_SAMPLER_ROWCDF) {
+        uint32_t i = (uint32_t)(c.node_lo + st.index(c.node_hi - c.node_lo));
+        float u = st.f32();
+        row_bounds(c, i, ib, ilen);
+        uint32_t m = ilen - 1;
+        float acc = 0.f;
+        for (uint32_t t = 0; t < ilen; t++) {
+            acc += c.proba[ib + t];
+            if (u < acc) { m = t; break; }
+        }
+        e = ib + m;
+        p.i = i;
+    } else {
+        uint64_t x = st.index(c.shard_edges);
+        float u = st.f32();
+        if (!(u < c.edge_odds[x])) x = c.edge_alias[x];
+        e = c.edge_lo + x;
+        p.i = c.edge_src[x];
+        row_bounds(c, p.i, ib, ilen);
+    }
+    p.j = c.nbr[e];
+    p.w = c.proba[e];
+    int got = 0;
+    uint32_t attempts = 0;
+    while (got < 5) {
+        uint32_t k;
+        if (c.hub_odds) {  // NodeSampler::sample, :927-930
+            uint64_t x = st.index(c.n);
+            float u = st.f32();
+            k = (u < c.hub_odds[x]) ? (uint32_t)x : c.hub_alias[x];
+        } else {
+            k = (uint32_t)st.index(c.n);  // :1121
+        }
+        if (++attempts > (1u << 20)) return false;
+        bool reject = (k == p.i) || (k == p.j);
+        if (!reject)
+            for (uint32_t t = 0; t < ilen; t++)  // NodeParam::get_edge linear scan, nodeparam.rs:83-85
+                if (c.nbr[ib + t] == k) { reject = true; break; }
+        if (reject) continue;  // :1246-1253
+        p.k[got++] = k;
+    }
+    return true;
+}
+
+template <int DIM>
+struct Row {
+    float v[DIM];
+};
+
+template <int DIM>
+__device__ __forceinline__ void load_row(const float* __restrict__ y, uint32_t node, float* out) {
+    const float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        out[0] = t.x; out[1] = t.y;
+    } else if constexpr (DIM % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 4; q++) {
+            float4 t = reinterpret_cast<const float4*>(p)[q];
+            out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) out[t] = p[t];
+    }
+}
+template <int DIM>
+__device__ __forceinline__ void store_row(float* __restrict__ y, uint32_t node, const float* in) {
+    float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(in[0], in[1]);
+    } else if constexpr (DIM % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 4; q++)
+            reinterpret_cast<float4*>(p)[q] = make_float4(in[4 * q], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) p[t] = in[t];
+    }
+}
+
+// common part of the gradient coefficient, embedder.rs:1216-1222 / :1275-1281
+__device__ __forceinline__ double grad_coeff(double d_scaled, double scale, double b) {
+    if (b != 1.) {
+        double cw = 1. / (1. + pow(d_scaled, b));
+        return 2. * b * cw * pow(d_scaled, b - 1.) / (scale * scale);
+    }
+    double cw = 1. / (1. + d_scaled);
+    return 2. * b * cw / (scale * scale);
+}
+
+// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample
+template <int DIM>
+__device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, double grad_step) {
+    float yi[DIM], yj[DIM], grad[DIM];
+    load_row<DIM>(c.y, p.i, yi);  // :1185
+    load_row<DIM>(c.y, p.j, yj);  // :1186
+#pragma unroll
+    for (int t = 0; t < DIM; t++) grad[t] = 0.f;  // :1199
+    const double weight = (double)p.w;              // :1202
+    const double scale = (double)c.emb_scale[p.i];  // :1204
+    const double b = c.b;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) {  // :1207-1211
+        float df = yi[t] - yj[t];
+        acc += df * df;
+    }
+    const double d_ij_scaled = (double)acc / (scale * scale);  // :1214
+    const double coeff = grad_coeff(d_ij_scaled, scale, b);
+    if (d_ij_scaled > 0.) {  // :1223-1236
+        const double alfa = (double)(1.0f / kProbaMin);
+        const double coeff_repulsion = 1. / fmax(d_ij_scaled * d_ij_scaled, alfa);
+        const double coeff_ij = fmax(grad_step * coeff * (-weight + (1. - weight) * coeff_repulsion), -0.49);
+        const float cf = (float)coeff_ij;
+#pragma unroll
+        for (int t = 0; t < DIM; t++) grad[t] = (yj[t] - yi[t]) * cf;
+    }
+#pragma unroll
+    for (int t = 0; t < DIM; t++) {  // :1237-1238
+        yi[t] -= grad[t];
+        yj[t] += grad[t];
+    }
+    store_row<DIM>(c.y, p.j, yj);  // :1239
+#pragma unroll
+    for (int g = 0; g < 5; g++) {  // :1244-1299
+        float yk[DIM];
+        load_row<DIM>(c.y, p.k[g], yk);
+        float ak = 0.f;
+#pragma unroll
+        for (int t = 0; t < DIM; t++) {  // :1267-1271
+            float df = yi[t] - yk[t];
+            ak += df * df;
+        }
+        const double d_ik = (double)ak;
+        const double d_ik_scaled = d_ik / (scale * scale);  // :1274
+        const double cf2 = grad_coeff(d_ik_scaled, scale, b);
+        if (d_ik > 0.) {  // :1286-1295
+            const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
+            const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
+            const float cf = (float)coeff_ik;
+#pragma unroll
+            for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
+        }  // else: `gradient` keeps its previous value, as in the reference
+#pragma unroll
+        for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
+    }
+    store_row<DIM>(c.y, p.i, yi);  // :1301
+}
+
+// runtime-dimension fallback (dim <= 64), same arithmetic
+__device__ void apply_sample_dyn(const CeDev& c, const Plan& p, double grad_step) {
+    constexpr int MAXD = 64;
+    const uint32_t dim = c.dim;
+    float yi[MAXD], yj[MAXD], grad[MAXD];
+    float* Yi = c.y + (uint64_t)p.i * dim;
+    float* Yj = c.y + (uint64_t)p.j * dim;
+    for (uint32_t t = 0; t < dim; t++) { yi[t] = Yi[t]; yj[t] = Yj[t]; grad[t] = 0.f; }
+    const double weight = (double)p.w;
+    const double scale = (double)c.emb_scale[p.i];
+    const double b = c.b;
+    float acc = 0.f;
+    for (uint32_t t = 0; t < dim; t++) { float df = yi[t] - yj[t]; acc += df * df; }
+    const double d_ij_scaled = (double)acc / (scale * scale);
+    const double coeff = grad_coeff(d_ij_scaled, scale, b);
+    if (d_ij_scaled > 0.) {
+        const double alfa = (double)(1.0f / kProbaMin);
+        const double coeff_repulsion = 1. / fmax(d_ij_scaled * d_ij_scaled, alfa);
+        const double coeff_ij = fmax(grad_step * coeff * (-weight + (1. - weight) * coeff_repulsion), -0.49);
+        const float cf = (float)coeff_ij;
+        for (uint32_t t = 0; t < dim; t++) grad[t] = (yj[t] - yi[t]) * cf;
+    }
+    for (uint32_t t = 0; t < dim; t++) { yi[t] -= grad[t]; yj[t] += grad[t]; }
+    for (uint32_t t = 0; t < dim; t++) Yj[t] = yj[t];
+    for (int g = 0; g < 5; g++) {
+        const float* Yk = c.y + (uint64_t)p.k[g] * dim;
+        float ak = 0.f;
+        for (uint32_t t = 0; t < dim; t++) { float df = yi[t] - Yk[t]; ak += df * df; }
+        const double d_ik = (double)ak;
+        const double d_ik_scaled = d_ik / (scale * scale);
+        const double cf2 = grad_coeff(d_ik_scaled, scale, b);
+        if (d_ik > 0.) {
+            const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
+            const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
+            const float cf = (float)coeff_ik;
+            for (uint32_t t = 0; t < dim; t++) grad[t] = (Yk[t] - yi[t]) * cf;
+        }
+        for (uint32_t t = 0; t < dim; t++) yi[t] -= grad[t];
+    }
+    for (uint32_t t = 0; t < dim; t++) Yi[t] = yi[t];
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) ce_sgd_hogwild_kernel(CeDev c, uint64_t s_begin, uint64_t nb_sample, double grad_step,
+                                                             uint32_t iter, unsigned int* err) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nb_sample; s += stride) {
+        Plan p;
+        if (!make_plan(c, s_begin + s, iter, p)) { atomicOr(err, 1u); continue; }
+        if constexpr (DIM == 0) apply_sample_dyn(c, p, grad_step);
+        else apply_sample<DIM>(c, p, grad_step);
+    }
+}
+
+__global__ void __launch_bounds__(256) ce_plan_kernel(CeDev c, uint64_t s_begin, uint64_t nb_sample, uint32_t iter,
+                                                      uint32_t* __restrict__ plan_nodes, float* __restrict__ plan_w,
+                                                      unsigned int* err) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nb_sample; s += stride) {
+        Plan p;
+        if (!make_plan(c, s_begin + s, iter, p)) { atomicOr(err, 1u); p.i = p.j = 0; for (int g = 0; g < 5; g++) p.k[g] = 0; p.w = 0.f; }
+        uint32_t* o = plan_nodes + s * 7;
+        o[0] = p.i; o[1] = p.j;
+        for (int g = 0; g < 5; g++) o[2 + g] = p.k[g];
+        plan_w[s] = p.w;
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) ce_sgd_planned_kernel(CeDev c, const uint32_t* __restrict__ order, uint64_t count,
+                                                             const uint32_t* __restrict__ plan_nodes,
+                                                             const float* __restrict__ plan_w, double grad_step) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t s = order[t];
+    Plan p;
+    const uint32_t* o = plan_nodes + s * 7;
+    p.i = o[0]; p.j = o[1];
+    for (int g = 0; g < 5; g++) p.k[g] = o[2 + g];
+    p.w = plan_w[s];
+    if constexpr (DIM == 0) apply_sample_dyn(c, p, grad_step);
+    else apply_sample<DIM>(c, p, grad_step);
+}
+
+// cauchy_edge_weight (:1322-1345) + ce_compute_threaded (:1127-1163): per-block partial sums in f64
+__global__ void __launch_bounds__(256) ce_value_kernel(CeDev c, double* __restrict__ partial) {
+    __shared__ double red[256];
+    double local = 0.;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = c.node_lo + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < c.node_hi; i += stride) {
+        const double scale = (double)c.emb_scale[i];
+        uint64_t b;
+        uint32_t len;
+        row_bounds(c, (uint32_t)i, b, len);
+        for (uint32_t m = 0; m < len; m++) {
+            const float* a = c.y + i * c.dim;
+            const float* o = c.y + (uint64_t)c.nbr[b + m] * c.dim;
+            float acc = 0.f;
+            for (uint32_t t = 0; t < c.dim; t++) { float df = a[t] - o[t]; acc += df * df; }  // :1326-1330
+            double d = (double)acc / (scale * scale);  // :1331
+            d = pow(d, c.b);                           // :1333
+            const double weight = 1. / (1. + d);       // :1336
+            float wf = (float)weight;                  // :1337
+            if (!(wf < 1.0f)) wf = 1.0f - 1.1920929e-07f;  // :1338-1341
+            const double we = (double)wf;
+            const double wij = (double)c.proba[b + m];
+            double term = 0.;
+            if (we > 0.) term += -wij * log(we);              // :1150-1152
+            if (we < 1.) term += -(1. - wij) * log(1. - we);  // :1153-1155
+            local += term;
+        }
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// estimate_embedded_scales_from_initial_scales, embedder.rs:1356-1373 (mean computed by the host
+// driver with the reference's sequential f32 sum)
+__global__ void embedded_scales_kernel(uint64_t n, const float* __restrict__ scale, float mean_scale, float* __restrict__ out) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = 0.2f * fmaxf(fminf(scale[i] / mean_scale, 4.0f), 0.25f);
+}
+
+__global__ void edge_src_kernel(uint64_t node_lo, uint64_t node_hi, const uint64_t* __restrict__ indptr, uint64_t edge_lo,
+                                uint32_t* __restrict__ src) {
+    uint64_t i = node_lo + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= node_hi) return;
+    for (uint64_t e = indptr[i]; e < indptr[i + 1]; e++) src[e - edge_lo] = (uint32_t)i;
+}
+
+}  // namespace
+
+namespace ae {
+
+// Walker/Vose alias table (host, setup only): stands in for rand_distr::WeightedAliasIndex::new
+// (src/embedder.rs:919,987).  LIFO small/large stacks filled in index order.
+void alias_build_host(const float* w, uint64_t n, std::vector<float>& odds, std::vector<uint32_t>& alias) {
+    odds.assign(n, 1.0f);
+    alias.resize(n);
+    double sum = 0.;
+    for (uint64_t i = 0; i < n; i++) sum += (double)w[i];
+    std::vector<double> q(n);
+    std::vector<uint32_t> small, large;
+    small.reserve(n);
+    large.reserve(n);
+    for (uint64_t i = 0; i < n; i++) {
+        q[i] = (double)w[i] * (double)n / sum;
+        if (q[i] < 1.0) small.push_back((uint32_t)i);
+        else large.push_back((uint32_t)i);
+    }
+    while (!small.empty() && !large.empty()) {
+        uint32_t s = small.back(); small.pop_back();
+        uint32_t l = large.back(); large.pop_back();
+        odds[s] = (float)q[s];
+        alias[s] = l;
+        q[l] = (q[l] + q[s]) - 1.0;
+        if (q[l] < 1.0) small.push_back(l);
+        else large.push_back(l);
+    }
+    for (uint32_t l : large) { odds[l] = 1.0f; alias[l] = l; }
+    for (uint32_t s : small) { odds[s] = 1.0f; alias[s] = s; }
+}
+
+}  // namespace ae
+
+struct ae_entropy_optim {
+    const ae_kgraph* g = nullptr;
+    const ae_node_params* np = nullptr;
+    ae_embedder_params params;
+    CeDev dev;
+    DevBuf<float> y, emb_scale;
+    DevBuf<float> edge_odds, hub_odds;
+    DevBuf<uint32_t> edge_alias, edge_src, hub_alias;
+    DevBuf<double> partial;
+    DevBuf<unsigned int> err;
+    // sequential-mode scratch
+    DevBuf<uint32_t> plan_nodes, order;
+    DevBuf<float> plan_w;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    uint64_t sample_offset = 0;
+    ~ae_entropy_optim() {
+        for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+};
+
+template <int DIM>
+static void launch_hogwild(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
+    unsigned grid = grid_cap(nb_sample, 256, 256 * 32);
+    hipLaunchKernelGGL((ce_sgd_hogwild_kernel<DIM>), dim3(grid), dim3(256), 0, stream(), o->dev, o->sample_offset, nb_sample, step,
+                       iter, o->err.p);
+}
+template <int DIM>
+static void launch_planned(ae_entropy_optim* o, const uint32_t* order, uint64_t count, double step) {
+    hipLaunchKernelGGL((ce_sgd_planned_kernel<DIM>), dim3(blocks_for(count, 256)), dim3(256), 0, stream(), o->dev, order, count,
+                       o->plan_nodes.p, o->plan_w.p, step);
+}
+
+#define AE_DISPATCH_DIM(dim, FN, ...)          \
+    switch (dim) {                             \
+        case 2: FN<2>(__VA_ARGS__); break;     \
+        case 3: FN<3>(__VA_ARGS__); break;     \
+        case 4: FN<4>(__VA_ARGS__); break;     \
+        case 8: FN<8>(__VA_ARGS__); break;     \
+        case 16: FN<16>(__VA_ARGS__); break;   \
+        default: FN<0>(__VA_ARGS__); break;    \
+    }
+
+static void check_err_flag(ae_entropy_optim* o) {
+    unsigned int h = 0;
+    o->err.download(&h, 1);
+    if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
+}
+
+static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
+    if (nb_sample >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^32 samples per batch");
+    if (o->plan_nodes.n < nb_sample * 7) o->plan_nodes.alloc(nb_sample * 7);
+    if (o->plan_w.n < nb_sample) o->plan_w.alloc(nb_sample);
+    if (o->order.n < nb_sample) o->order.alloc(nb_sample);
+    hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(nb_sample, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset, nb_sample,
+                       iter, o->plan_nodes.p, o->plan_w.p, o->err.p);
+    check_launch("ce_plan");
+    std::vector<uint32_t> nodes(nb_sample * 7);
+    o->plan_nodes.download(nodes.data(), nb_sample * 7);
+    check_err_flag(o);
+    // level schedule: sample s runs after every earlier sample that wrote a node it touches and after
+    // every earlier sample that read a node it writes  =>  identical to sequential execution.
+    const uint64_t n = o->dev.n;
+    std::vector<uint32_t> last_w(n, 0), last_r(n, 0), level(nb_sample);
+    uint32_t max_level = 0;
+    for (uint64_t s = 0; s < nb_sample; s++) {
+        const uint32_t* p = &nodes[s * 7];
+        uint32_t l = std::max(std::max(last_w[p[0]], last_r[p[0]]), std::max(last_w[p[1]], last_r[p[1]]));
+        for (int g = 0; g < 5; g++) l = std::max(l, last_w[p[2 + g]]);
+        l += 1;
+        level[s] = l;
+        last_w[p[0]] = l;
+        last_w[p[1]] = l;
+        for (int g = 0; g < 5; g++) last_r[p[2 + g]] = std::max(last_r[p[2 + g]], l);
+        max_level = std::max(max_level, l);
+    }
+    std::vector<uint64_t> off(max_level + 2, 0);
+    for (uint64_t s = 0; s < nb_sample; s++) off[level[s] + 1]++;
+    for (uint32_t l = 0; l <= max_level; l++) off[l + 1] += off[l];
+    std::vector<uint32_t> order(nb_sample);
+    {
+        std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+        for (uint64_t s = 0; s < nb_sample; s++) order[cur[level[s]]++] = (uint32_t)s;
+    }
+    o->order.upload(order.data(), nb_sample);
+    for (uint32_t l = 1; l <= max_level; l++) {
+        uint64_t cnt = off[l + 1] - off[l];
+        if (!cnt) continue;
+        AE_DISPATCH_DIM(o->dev.dim, launch_planned, o, o->order.p + off[l], cnt, step);
+    }
+    check_launch("ce_sgd_planned");
+    sync();
+}
+
+
+
+ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params* params,
+                                                const float* y0, bool y0_on_device, const uint32_t* hub_counts, uint64_t node_lo,
+                                                uint64_t node_hi) {
+    {
+        require_device();
+        if (!g || !np || !params || !y0) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (np->g != g) fail(AE_ERR_INVALID_ARG, "node params were not computed from this graph");
+        if (params->asked_dim == 0 || params->asked_dim > 64) fail(AE_ERR_INVALID_ARG, "asked_dim must be in [1,64]");
+        if (node_lo >= node_hi || node_hi > g->n) fail(AE_ERR_INVALID_ARG, "bad node range");
+        if (g->n < (uint64_t)g->max_nbng + 8) fail(AE_ERR_INVALID_ARG, "graph too small for negative sampling");
+        std::unique_ptr<ae_entropy_optim> o(new ae_entropy_optim);
+        o->g = g;
+        o->np = np;
+        o->params = *params;
+        const uint64_t n = g->n, dim = params->asked_dim;
+        o->y.alloc(n * dim);
+        if (y0_on_device) AE_HIP(hipMemcpyAsync(o->y.p, y0, sizeof(float) * n * dim, hipMemcpyDeviceToDevice, stream()));
+        else o->y.upload(y0, n * dim);
+        // embedded scales: mean of the initial scales as the reference's sequential f32 sum (:1358)
+        std::vector<float> hscale = np->scale.to_host();
+        float ssum = 0.f;
+        for (uint64_t i = 0; i < n; i++) ssum += hscale[i];
+        const float mean_scale = ssum / (float)n;
+        o->emb_scale.alloc(n);
+        hipLaunchKernelGGL(embedded_scales_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, np->scale.p, mean_scale,
+                           o->emb_scale.p);
+        check_launch("embedded_scales");
+        o->err.alloc(1);
+        o->err.zero();
+        o->partial.alloc(1024);
+        std::vector<uint64_t> hindptr;  // only needed for shard edge bounds
+        uint64_t edge_lo, edge_hi;
+        if (g->uniform_k) {
+            edge_lo = node_lo * g->uniform_k;
+            edge_hi = node_hi * g->uniform_k;
+        } else {
+            uint64_t two[2];
+            AE_HIP(hipMemcpy(&two[0], g->indptr.p + node_lo, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            AE_HIP(hipMemcpy(&two[1], g->indptr.p + node_hi, sizeof(uint64_t), hipMemcpyDeviceToHost));
+            edge_lo = two[0];
+            edge_hi = two[1];
+        }
+        CeDev& d = o->dev;
+        memset(&d, 0, sizeof(d));
+        d.n = n; d.nnz = g->nnz; d.dim = (uint32_t)dim; d.uniform_k = g->uniform_k;
+        d.indptr = g->indptr.p; d.nbr = g->nbr.p; d.proba = np->proba.p; d.emb_scale = o->emb_scale.p; d.y = o->y.p;
+        d.b = params->b; d.seed = params->seed; d.sampler = params->ce_sampler;
+        d.node_lo = node_lo; d.node_hi = node_hi; d.edge_lo = edge_lo; d.shard_edges = edge_hi - edge_lo;
+        o->sample_offset = node_lo << 24;
+        if (params->ce_sampler == AE_SAMPLER_ALIAS) {
+            // WeightedAliasIndex over the edge probabilities (embedder.rs:987); host build, setup only
+            std::vector<float> hp(d.shard_edges);
+            AE_HIP(hipMemcpy(hp.data(), np->proba.p + edge_lo, sizeof(float) * d.shard_edges, hipMemcpyDeviceToHost));
+            std::vector<float> odds;
+            std::vector<uint32_t> alias;
+            alias_build_host(hp.data(), d.shard_edges, odds, alias);
+            o->edge_odds.alloc(d.shard_edges); o->edge_odds.upload(odds.data(), d.shard_edges);
+            o->edge_alias.alloc(d.shard_edges); o->edge_alias.upload(alias.data(), d.shard_edges);
+            o->edge_src.alloc(d.shard_edges);
+            hipLaunchKernelGGL(edge_src_kernel, dim3(blocks_for(node_hi - node_lo, 256)), dim3(256), 0, stream(), node_lo, node_hi,
+                               g->indptr.p, edge_lo, o->edge_src.p);
+            check_launch("edge_src");
+            sync();
+            d.edge_odds = o->edge_odds.p; d.edge_alias = o->edge_alias.p; d.edge_src = o->edge_src.p;
+        } else if (params->ce_sampler != AE_SAMPLER_ROWCDF) {
+            fail(AE_ERR_INVALID_ARG, "unknown ce_sampler %u", params->ce_sampler);
+        }
+        if (params->hubness_weighting) {
+            if (!hub_counts) fail(AE_ERR_INVALID_ARG, "hubness_weighting needs hub_counts");
+            // NodeSampler::new, embedder.rs:826-833, 915-919
+            std::vector<float> w(n);
+            const float upper = (float)n;
+            float s = 0.f;
+            for (uint64_t i = 0; i < n; i++) {
+                w[i] = std::min(std::max((float)hub_counts[i], 1.f), upper);
+                s += w[i];
+            }
+            const float mean = s / (float)n;
+            for (uint64_t i = 0; i < n; i++) w[i] = w[i] / mean;
+            std::vector<float> odds;
+            std::vector<uint32_t> alias;
+            alias_build_host(w.data(), n, odds, alias);
+            o->hub_odds.alloc(n); o->hub_odds.upload(odds.data(), n);
+            o->hub_alias.alloc(n); o->hub_alias.upload(alias.data(), n);
+            sync();
+            d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
+        }
+        sync();
+        return o.release();
+    }
+}
+
+extern "C" {
+
+int32_t ae_entropy_optim_create(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params* params, const float* y0,
+                                const uint32_t* hub_counts, uint64_t node_lo, uint64_t node_hi, ae_entropy_optim** out) {
+    return guard([&] {
+        if (!out) fail(AE_ERR_INVALID_ARG, "null argument");
+        *out = ae::entropy_optim_create_impl(g, np, params, y0, false, hub_counts, node_lo, node_hi);
+    });
+}
+
+int32_t ae_entropy_optim_destroy(ae_entropy_optim* o) {
+    return guard([&] { delete o; });
+}
+int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim* o, uint64_t* nnz) {
+    return guard([&] {
+        if (!o || !nnz) fail(AE_ERR_INVALID_ARG, "null argument");
+        *nnz = o->dev.shard_edges;
+    });
+}
+
+int32_t ae_entropy_optim_ce(ae_entropy_optim* o, double* ce) {
+    return guard([&] {
+        require_device();
+        if (!o || !ce) fail(AE_ERR_INVALID_ARG, "null argument");
+        const unsigned grid = std::min<unsigned>(1024, blocks_for(o->dev.node_hi - o->dev.node_lo, 256));
+        hipLaunchKernelGGL(ce_value_kernel, dim3(grid), dim3(256), 0, stream(), o->dev, o->partial.p);
+        check_launch("ce_value");
+        std::vector<double> h(grid);
+        o->partial.download(h.data(), grid);
+        double s = 0.;
+        for (unsigned i = 0; i < grid; i++) s += h[i];
+        *ce = s;
+    });
+}
+
+int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint64_t iter) {
+    return guard([&] {
+        require_device();
+        if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (nb_sample == 0) return;
+        if (nb_sample >= (1ull << 56)) fail(AE_ERR_INVALID_ARG, "too many samples");
+        if (o->params.ce_mode == AE_CE_SEQUENTIAL) {
+            run_sequential(o, nb_sample, grad_step, (uint32_t)iter);
+            return;
+        }
+        hipEvent_t e0, e1;
+        AE_HIP(hipEventCreate(&e0));
+        AE_HIP(hipEventCreate(&e1));
+        AE_HIP(hipEventRecord(e0, stream()));
+        AE_DISPATCH_DIM(o->dev.dim, launch_hogwild, o, nb_sample, grad_step, (uint32_t)iter);
+        AE_HIP(hipEventRecord(e1, stream()));
+        o->events.emplace_back(e0, e1);
+        check_launch("ce_sgd_hogwild");
+    });
+}
+
+int32_t ae_entropy_optim_plan(ae_entropy_optim* o, uint64_t s_begin, uint64_t count, uint64_t iter, uint32_t* nodes7, float* w) {
+    return guard([&] {
+        require_device();
+        if (!o || !nodes7 || count == 0) fail(AE_ERR_INVALID_ARG, "bad argument");
+        DevBuf<uint32_t> dn(count * 7);
+        DevBuf<float> dw(count);
+        hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(count, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset + s_begin, count,
+                           (uint32_t)iter, dn.p, dw.p, o->err.p);
+        check_launch("ce_plan");
+        dn.download(nodes7, count * 7);
+        if (w) dw.download(w, count);
+        check_err_flag(o);
+    });
+}
+
+int32_t ae_entropy_optim_kernel_time(ae_entropy_optim* o, double* avg_ms, uint64_t* launches) {
+    return guard([&] {
+        require_device();
+        if (!o || !avg_ms || !launches) fail(AE_ERR_INVALID_ARG, "null argument");
+        sync();
+        double tot = 0.;
+        for (auto& e : o->events) {
+            float ms = 0.f;
+            AE_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        *launches = o->events.size();
+        *avg_ms = o->events.empty() ? 0. : tot / (double)o->events.size();
+        o->events.clear();
+        check_err_flag(o);
+    });
+}
+
+int32_t ae_entropy_optim_get_scales(const ae_entropy_optim* o, float* emb_scale) {
+    return guard([&] {
+        if (!o || !emb_scale) fail(AE_ERR_INVALID_ARG, "null argument");
+        o->emb_scale.download(emb_scale, o->dev.n);
+    });
+}
+int32_t ae_entropy_optim_get_embedded(const ae_entropy_optim* o, float* y) {
+    return guard([&] {
+        if (!o || !y) fail(AE_ERR_INVALID_ARG, "null argument");
+        o->y.download(y, o->dev.n * o->dev.dim);
+    });
+}
+int32_t ae_entropy_optim_device_coords(ae_entropy_optim* o, void** d_y, uint64_t* n, uint64_t* dim) {
+    return guard([&] {
+        if (!o || !d_y) fail(AE_ERR_INVALID_ARG, "null argument");
+        *d_y = (void*)o->y.p;
+        if (n) *n = o->dev.n;
+        if (dim) *dim = o->dev.dim;
+    });
+}
+
+// entropy_optimize, embedder.rs:794-904
+int32_t ae_entropy_optimize(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params* params, const float* y0,
+                            float* y, double* ce_before, double* ce_after) {
+    ae_entropy_optim* o = nullptr;
+    int32_t rc;
+    std::vector<uint32_t> hub;
+    if (params && params->hubness_weighting && g) {
+        hub.resize(g->n);
+        rc = ae_kgraph_hubness(g, hub.data());
+        if (rc) return rc;
+    }
+    rc = ae_entropy_optim_create(g, np, params, y0, hub.empty() ? nullptr : hub.data(), 0, g ? g->n : 0, &o);
+    if (rc) return rc;
+    auto cleanup = [&](int32_t code) { ae_entropy_optim_destroy(o); return code; };
+    double ce = 0.;
+    if ((rc = ae_entropy_optim_ce(o, &ce))) return cleanup(rc);  // :846
+    if (ce_before) *ce_before = ce;
+    uint64_t nnz = 0;
+    ae_entropy_optim_get_nb_edges(o, &nnz);
+    const uint64_t nb_sample = params->nb_sampling_by_edge * nnz;  // :858
+    for (uint64_t iter = 1; iter <= params->nb_grad_batch; iter++) {  // :873
+        const double step = params->grad_step * (1. - (double)iter / (double)params->nb_grad_batch);  // :875
+        if ((rc = ae_entropy_optim_gradient_iteration(o, nb_sample, step, iter))) return cleanup(rc);
+    }
+    if ((rc = ae_entropy_optim_ce(o, &ce))) return cleanup(rc);  // :885
+    if (ce_after) *ce_after = ce;
+    if (y && (rc = ae_entropy_optim_get_embedded(o, y))) return cleanup(rc);
+    double ms; uint64_t cnt;
+    if ((rc = ae_entropy_optim_kernel_time(o, &ms, &cnt))) return cleanup(rc);
+    return cleanup(AE_OK);
+}
+
+}  // extern "C"

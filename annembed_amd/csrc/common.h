@@ -1,0 +1,127 @@
+// common.h -- shared host-side plumbing of libannembed_hip: error reporting, device buffers, the
+// per-device stream, launch helpers.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/annembed_hip.h"
+
+namespace ae {
+
+// PROBA_MIN, src/embedder.rs:50
+constexpr float kProbaMin = 1.0e-4f;
+// thresholds of src/graphlaplace.rs:13-15
+constexpr uint64_t kFullMatRepr = 5000;
+constexpr uint64_t kFullSvdSizeLimit = 5000;
+// Philox stream tags (third counter word) for the non-CE random draws
+constexpr uint32_t kTagOmega = 0xFFFF0001u;
+constexpr uint32_t kTagProj = 0xFFFF0002u;
+constexpr uint32_t kTagRandInit = 0xFFFF0003u;
+constexpr uint64_t kDefaultSeed = 4664397ull;  // src/tools/svdapprox.rs:70
+
+struct Error : std::exception {
+    int32_t code;
+    std::string msg;
+    Error(int32_t c, std::string m) : code(c), msg(std::move(m)) {}
+    const char* what() const noexcept override { return msg.c_str(); }
+};
+
+[[noreturn]] inline void fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+void set_last_error(const std::string& s);
+
+#define AE_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            ::ae::fail(e_ == hipErrorOutOfMemory ? AE_ERR_OOM : AE_ERR_NO_DEVICE, "%s failed: %s (%s:%d)", #expr, \
+                       hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+// every C-ABI entry point body is wrapped in this: exceptions never cross the ABI
+template <class F>
+inline int32_t guard(F&& f) {
+    try {
+        f();
+        return AE_OK;
+    } catch (const Error& e) {
+        set_last_error(e.msg);
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return AE_ERR_OOM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return AE_ERR_INVALID_ARG;
+    }
+}
+
+// the stream every kernel of the library is launched on (one per process / current device)
+hipStream_t stream();
+void require_device();
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) AE_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void upload(const T* host, size_t count) {
+        if (count > n) alloc(count);
+        if (count) AE_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, stream()));
+    }
+    void from_host(const T* host, size_t count) { alloc(count); upload(host, count); AE_HIP(hipStreamSynchronize(stream())); }
+    void download(T* host, size_t count) const {
+        if (count) AE_HIP(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipStreamSynchronize(stream()));
+    }
+    void zero() { if (n) AE_HIP(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
+    std::vector<T> to_host() const { std::vector<T> v(n); download(v.data(), n); return v; }
+};
+
+inline unsigned blocks_for(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
+// grid-stride launches: cap the grid at 256 CUs x 8 workgroups (guide G11)
+inline unsigned grid_cap(uint64_t work, unsigned block, unsigned cap = 2048 * 4) {
+    uint64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+inline void check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail(AE_ERR_NO_DEVICE, "kernel launch %s failed: %s", what, hipGetErrorString(e));
+}
+inline void sync() { AE_HIP(hipStreamSynchronize(stream())); }
+
+}  // namespace ae

@@ -1,0 +1,17 @@
+// internal.h -- cross-file entry points of the library (C++ side, below the C ABI).
+#pragma once
+#include "objects.h"
+
+struct ae_entropy_optim;
+
+namespace ae {
+void to_proba_edges_device(const ae_kgraph* g, float scale_rho, float beta, ae_node_params* np);
+void dmap_laplacian_device(const ae_kgraph* g, const ae_diffusion_params* dp, int force_repr, ae_laplacian* lap);
+uint32_t embed_from_laplacian_device(ae_laplacian* lap, uint64_t asked_dim, float t, bool has_t, DevBuf<float>& y0,
+                                     std::vector<float>* s_out);
+void set_data_box_device(float* d_y, uint64_t n, uint64_t dim, float box_size);
+// EntropyOptim::new with the initial embedding given on the host or already on the device
+ae_entropy_optim* entropy_optim_create_impl(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params* params,
+                                            const float* y0, bool y0_on_device, const uint32_t* hub_counts, uint64_t node_lo,
+                                            uint64_t node_hi);
+}  // namespace ae

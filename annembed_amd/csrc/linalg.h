@@ -1,0 +1,37 @@
+// linalg.h -- device linear-algebra building blocks shared by svd.hip and dmap.hip.
+// All panels are tall-skinny row-major f32 (rows x l, l <= kMaxL); small l x l matrices are f64.
+#pragma once
+#include "objects.h"
+
+namespace ae {
+
+constexpr int kMaxL = 64;  // widest panel supported (reference uses rank 20; tests up to 28/32)
+
+// out[count] ~ N(0,1): element e of the (seed, tag) Philox stream (Box-Muller), row-major fill order
+void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t tag);
+
+// Y[m x l] = A * X[n x l]   (A = CSR or dense MatRepr)
+void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l);
+// Y[n x l] = A^T * X[m x l] (builds and caches the transpose CSR on first use unless a.symmetric)
+void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l);
+// builds a.transpose (CSR of A^T) on device
+void build_transpose(ae_matrepr& a);
+
+// G[l x l] (f64, device) = Y^T Y
+void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g);
+// Y <- Y * M  (M l x lout f64 device, row-major); in place allowed when lout <= l
+void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out);
+
+// Householder-QR stand-in (do_qr, svdapprox.rs:998-1013): orthonormalise the columns of Y in place.
+// Two passes of Gram + symmetric eigendecomposition + scaling (SVQB); rank-deficient directions
+// become zero columns.  d_work: >= 3*l*l doubles.
+void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work);
+
+// eigendecomposition of a symmetric l x l f64 matrix on device (cyclic Jacobi, one workgroup):
+// evals[l] descending, evecs[l x l] row-major with eigenvectors in columns.
+void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs);
+
+// exact sequential f32 sum (the reference's iter().sum::<f32>() order) of d_x[0..n) with stride
+float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride = 1);
+
+}  // namespace ae

@@ -1,0 +1,703 @@
+// svd.hip -- a6-a8: tools::svdapprox (src/tools/svdapprox.rs) and the linear-algebra kernels under it.
+//
+//   subspace_iteration_{csr,full}  svdapprox.rs:285-408   Halko-Tropp algorithm 4.4
+//   SvdApprox::direct_svd          svdapprox.rs:721-799   algorithm 5.1
+//
+// Design (MI355X): every operand is a tall-skinny row-major panel (rows x l, l = 20 in the
+// embedder); the passes are HBM-bound, so each kernel streams its panel once with
+// coalesced row reads.  LAPACK's Householder QR (do_qr :998-1013) is replaced by Gram + small
+// symmetric eigendecomposition + scaling, twice (SVQB): the Gram (l x l, f64) is the only
+// reduction, the eigenproblem runs on one workgroup, and rank-deficient panels give zero columns
+// instead of failing.  The l x n SVD of B (gesdd at :758) is done the same way through B B^T.
+
+#include "linalg.h"
+// (after <cstring>: rocprim's texture iterator calls the host memset)
+#include <rocprim/rocprim.hpp>
+#include "philox.h"
+
+using namespace ae;
+
+namespace {
+
+__global__ void gaussian_fill_kernel(float* __restrict__ out, uint64_t count, uint64_t seed, uint32_t tag) {
+    uint64_t nblk = (count + 3) / 4;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), tag, 0, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        float z[4];
+        box_muller(w[0], w[1], z[0], z[1]);
+        box_muller(w[2], w[3], z[2], z[3]);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (4 * b + t < count) out[4 * b + t] = z[t];
+    }
+}
+
+// Y = A X, A CSR.  One wave per row; the 64 lanes are (64/LP) edge slots x LP panel columns, so a
+// wave reads 64/LP neighbour rows of X (l contiguous floats each) per step.
+template <int LP>
+__global__ void __launch_bounds__(256) spmm_csr_kernel(uint64_t m, const uint64_t* __restrict__ indptr,
+                                                       const uint32_t* __restrict__ ind, const float* __restrict__ val,
+                                                       const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
+    constexpr int G = 64 / LP;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LP - 1);
+    const int g = lane / LP;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t row = wave; row < m; row += nwaves) {
+        float acc = 0.f;
+        const uint64_t e1 = indptr[row + 1];
+        for (uint64_t e = indptr[row] + g; e < e1; e += G) {
+            const float a = val[e];
+            const uint64_t col = ind[e];
+            if (c < (int)l) acc = fmaf(a, x[col * l + c], acc);
+        }
+#pragma unroll
+        for (int off = LP; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+        if (g == 0 && c < (int)l) y[row * l + c] = acc;
+    }
+}
+
+// Y = A X, A dense m x n row-major: one wave per row of A, lanes stride the contraction index.
+template <int LT>
+__global__ void __launch_bounds__(256) dense_mul_panel_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                              const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t row = wave; row < m; row += nwaves) {
+        float acc[LT];
+#pragma unroll
+        for (int c = 0; c < LT; c++) acc[c] = 0.f;
+        const float* ar = a + row * n;
+        for (uint64_t k = lane; k < n; k += 64) {
+            const float av = ar[k];
+            const float* xr = x + k * l;
+#pragma unroll
+            for (int c = 0; c < LT; c++)
+                if (c < (int)l) acc[c] = fmaf(av, xr[c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < LT; c++) {
+            float v = acc[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && c < (int)l) y[row * l + c] = v;
+        }
+    }
+}
+
+// partial[r][k][c] = sum_{i in chunk r} A[i,k] * X[i,c]  (A^T X), lanes own columns k of A (coalesced rows)
+template <int LT>
+__global__ void __launch_bounds__(64) dense_t_mul_panel_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                               const float* __restrict__ x, float* __restrict__ partial,
+                                                               uint32_t l, uint64_t rows_per_chunk) {
+    const uint64_t k = blockIdx.x * 64ull + threadIdx.x;
+    const uint64_t r = blockIdx.y;
+    const uint64_t i0 = r * rows_per_chunk;
+    const uint64_t i1 = i0 + rows_per_chunk < m ? i0 + rows_per_chunk : m;
+    float acc[LT];
+#pragma unroll
+    for (int c = 0; c < LT; c++) acc[c] = 0.f;
+    if (k < n) {
+        for (uint64_t i = i0; i < i1; i++) {
+            const float av = a[i * n + k];
+            const float* xr = x + i * l;
+#pragma unroll
+            for (int c = 0; c < LT; c++)
+                if (c < (int)l) acc[c] = fmaf(av, xr[c], acc[c]);
+        }
+        float* o = partial + (r * n + k) * l;
+#pragma unroll
+        for (int c = 0; c < LT; c++)
+            if (c < (int)l) o[c] = acc[c];
+    }
+}
+__global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t chunks, uint64_t count, float* __restrict__ out) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (uint64_t r = 0; r < chunks; r++) s += partial[r * count + i];
+    out[i] = s;
+}
+
+// Gram: partial[block][l*l] = sum over the block's row tiles of y_r^T y_r, f64 accumulation
+constexpr int kGramTile = 64;
+__global__ void __launch_bounds__(256) gram_partial_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,
+                                                           double* __restrict__ partial) {
+    __shared__ float tile[kGramTile * kMaxL];
+    const uint32_t npairs = l * l;
+    double acc[(kMaxL * kMaxL + 255) / 256];
+#pragma unroll
+    for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) acc[p] = 0.;
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t r0 = t * kGramTile;
+        const uint32_t nr = (uint32_t)(rows - r0 < kGramTile ? rows - r0 : kGramTile);
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < nr * l; idx += 256) tile[idx] = y[r0 * l + idx];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) {
+            const uint32_t pair = p * 256 + threadIdx.x;
+            if (pair < npairs) {
+                const uint32_t a = pair / l, b = pair % l;
+                double s = 0.;
+                for (uint32_t r = 0; r < nr; r++) s += (double)tile[r * l + a] * (double)tile[r * l + b];
+                acc[p] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) {
+        const uint32_t pair = p * 256 + threadIdx.x;
+        if (pair < npairs) partial[(uint64_t)blockIdx.x * npairs + pair] = acc[p];
+    }
+}
+__global__ void gram_reduce_kernel(const double* __restrict__ partial, uint32_t nblocks, uint32_t npairs, double* __restrict__ g) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    double s = 0.;
+    for (uint32_t b = 0; b < nblocks; b++) s += partial[(uint64_t)b * npairs + p];
+    g[p] = s;
+}
+
+// out tile = y tile * M ; each workgroup owns kGramTile rows, staged through LDS so that in-place is safe
+__global__ void __launch_bounds__(256) apply_panel_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,
+                                                          const double* __restrict__ mat, uint32_t lout, float* __restrict__ out) {
+    __shared__ float tile[kGramTile * kMaxL];
+    __shared__ double sm[kMaxL * kMaxL];
+    for (uint32_t idx = threadIdx.x; idx < l * lout; idx += 256) sm[idx] = mat[idx];
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t r0 = t * kGramTile;
+        const uint32_t nr = (uint32_t)(rows - r0 < kGramTile ? rows - r0 : kGramTile);
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < nr * l; idx += 256) tile[idx] = y[r0 * l + idx];
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < nr * lout; idx += 256) {
+            const uint32_t r = idx / lout, c2 = idx % lout;
+            double s = 0.;
+            for (uint32_t c = 0; c < l; c++) s += (double)tile[r * l + c] * sm[c * lout + c2];
+            out[(r0 + r) * lout + c2] = (float)s;
+        }
+    }
+}
+
+// cyclic Jacobi with round-robin parallel ordering on one workgroup; G is destroyed in LDS.
+__global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restrict__ gin, uint32_t l, double* __restrict__ evals,
+                                                          double* __restrict__ evecs) {
+    __shared__ double G[kMaxL * kMaxL];
+    __shared__ double V[kMaxL * kMaxL];
+    __shared__ double cs[kMaxL];  // c,s per pair
+    __shared__ int pp[kMaxL / 2], pq[kMaxL / 2];
+    __shared__ double offn;
+    __shared__ int order[kMaxL];
+    const uint32_t L = (l + 1) & ~1u;  // even
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t idx = tid; idx < l * l; idx += 256) {
+        G[idx] = gin[idx];
+        V[idx] = (idx / l == idx % l) ? 1. : 0.;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; sweep++) {
+        if (tid == 0) {
+            double off = 0., diag = 0.;
+            for (uint32_t a = 0; a < l; a++)
+                for (uint32_t b = 0; b < l; b++) {
+                    double v = G[a * l + b];
+                    if (a == b) diag += v * v; else off += v * v;
+                }
+            offn = (off <= 1e-30 * diag || off == 0.) ? 0. : off;
+        }
+        __syncthreads();
+        if (offn == 0.) break;
+        for (uint32_t step = 0; step + 1 < L; step++) {
+            // round-robin pairing of 0..L-1
+            if (tid < L / 2) {
+                uint32_t a, b;
+                if (tid == 0) { a = L - 1; b = step; }
+                else { a = (step + tid) % (L - 1); b = (step + (L - 1) - tid) % (L - 1); }
+                if (a > b) { uint32_t t = a; a = b; b = t; }
+                pp[tid] = (int)a; pq[tid] = (int)b;
+                double c = 1., s = 0.;
+                if (b < l) {
+                    const double apq = G[a * l + b];
+                    if (apq != 0.) {
+                        const double tau = (G[b * l + b] - G[a * l + a]) / (2. * apq);
+                        const double t = (tau >= 0. ? 1. : -1.) / (fabs(tau) + sqrt(1. + tau * tau));
+                        c = 1. / sqrt(1. + t * t);
+                        s = t * c;
+                    }
+                }
+                cs[2 * tid] = c; cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            // columns: G <- G J, V <- V J
+            for (uint32_t idx = tid; idx < l * (L / 2); idx += 256) {
+                const uint32_t r = idx / (L / 2), pr = idx % (L / 2);
+                const uint32_t a = pp[pr], b = pq[pr];
+                if (b >= l) continue;
+                const double c = cs[2 * pr], s = cs[2 * pr + 1];
+                const double ga = G[r * l + a], gb = G[r * l + b];
+                G[r * l + a] = c * ga - s * gb;
+                G[r * l + b] = s * ga + c * gb;
+                const double va = V[r * l + a], vb = V[r * l + b];
+                V[r * l + a] = c * va - s * vb;
+                V[r * l + b] = s * va + c * vb;
+            }
+            __syncthreads();
+            // rows: G <- J^T G
+            for (uint32_t idx = tid; idx < l * (L / 2); idx += 256) {
+                const uint32_t k = idx / (L / 2), pr = idx % (L / 2);
+                const uint32_t a = pp[pr], b = pq[pr];
+                if (b >= l) continue;
+                const double c = cs[2 * pr], s = cs[2 * pr + 1];
+                const double ga = G[a * l + k], gb = G[b * l + k];
+                G[a * l + k] = c * ga - s * gb;
+                G[b * l + k] = s * ga + c * gb;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {  // sort eigenvalues descending (stable selection)
+        bool used[kMaxL];
+        for (uint32_t a = 0; a < l; a++) used[a] = false;
+        for (uint32_t o = 0; o < l; o++) {
+            int best = -1;
+            for (uint32_t a = 0; a < l; a++)
+                if (!used[a] && (best < 0 || G[a * l + a] > G[best * l + best])) best = (int)a;
+            used[best] = true;
+            order[o] = best;
+        }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < l * l; idx += 256) {
+        const uint32_t r = idx / l, o = idx % l;
+        evecs[idx] = V[r * l + order[o]];
+    }
+    if (tid < l) evals[tid] = G[order[tid] * l + order[tid]];
+}
+
+// M[c][o] = evecs[c][o] * (evals[o] > tol ? evals[o]^-1/2 : 0)
+__global__ void svqb_scale_kernel(const double* __restrict__ evals, const double* __restrict__ evecs, uint32_t l, double rel_tol,
+                                  double* __restrict__ m) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= l * l) return;
+    const uint32_t o = idx % l;
+    const double lam = evals[o], lmax = evals[0];
+    m[idx] = (lam > rel_tol * lmax && lam > 0.) ? evecs[idx] / sqrt(lam) : 0.;
+}
+
+__global__ void seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float s = 0.f;
+    uint64_t i = 0;
+    for (; i + 8 <= n; i += 8) {  // loads are independent, adds keep the reference's order
+        float v0 = x[(i + 0) * stride], v1 = x[(i + 1) * stride], v2 = x[(i + 2) * stride], v3 = x[(i + 3) * stride];
+        float v4 = x[(i + 4) * stride], v5 = x[(i + 5) * stride], v6 = x[(i + 6) * stride], v7 = x[(i + 7) * stride];
+        s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+    }
+    for (; i < n; i++) s += x[i * stride];
+    *out = s;
+}
+
+// transpose support ---------------------------------------------------------------------------
+__global__ void coo_keys_kernel(uint64_t m, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ ind,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ payload) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    for (uint64_t e = indptr[i]; e < indptr[i + 1]; e++) {
+        keys[e] = ((uint64_t)ind[e] << 32) | i;  // (col, row)
+        payload[e] = (uint32_t)e;
+    }
+}
+__global__ void transpose_fill_kernel(uint64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                      const float* __restrict__ val, uint32_t* __restrict__ tind, float* __restrict__ tval) {
+    uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    tind[e] = (uint32_t)(keys[e] & 0xFFFFFFFFull);
+    tval[e] = val[perm[e]];
+}
+// rowptr[r] = first sorted position whose key's high word >= r
+__global__ void rowptr_from_sorted_keys_kernel(const uint64_t* __restrict__ keys, uint64_t nnz, uint64_t nrows,
+                                               uint64_t* __restrict__ rowptr) {
+    uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    uint64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> 32) < r) lo = mid + 1; else hi = mid;
+    }
+    rowptr[r] = lo;
+}
+__global__ void transpose_dense_kernel(const float* __restrict__ in, uint64_t rows, uint64_t cols, float* __restrict__ out) {
+    uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    uint64_t r = idx / cols, c = idx % cols;
+    out[c * rows + r] = in[idx];
+}
+
+}  // namespace
+
+namespace ae {
+
+void sort_pairs_u64_u32(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, uint64_t count) {
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, count, 0, 64, stream()) != hipSuccess)
+        fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
+    DevBuf<char> tmp(tmp_bytes ? tmp_bytes : 1);
+    if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, count, 0, 64, stream()) != hipSuccess)
+        fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs failed");
+    sync();
+}
+
+void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrows, uint64_t* d_rowptr) {
+    hipLaunchKernelGGL(rowptr_from_sorted_keys_kernel, dim3(blocks_for(nrows + 1, 256)), dim3(256), 0, stream(), d_keys, nnz, nrows,
+                       d_rowptr);
+    check_launch("rowptr_from_sorted_keys");
+}
+
+void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t tag) {
+    hipLaunchKernelGGL(gaussian_fill_kernel, dim3(grid_cap((count + 3) / 4, 256)), dim3(256), 0, stream(), d_out, count, seed, tag);
+    check_launch("gaussian_fill");
+}
+
+float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
+    DevBuf<float> out(1);
+    hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(64), 0, stream(), d_x, n, stride, out.p);
+    check_launch("seq_sum");
+    float h;
+    out.download(&h, 1);
+    return h;
+}
+
+static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
+    const unsigned grid = grid_cap(a.nrows * 64, 256);
+    if (l <= 16)
+        hipLaunchKernelGGL((spmm_csr_kernel<16>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
+    else if (l <= 32)
+        hipLaunchKernelGGL((spmm_csr_kernel<32>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
+    else
+        hipLaunchKernelGGL((spmm_csr_kernel<64>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
+    check_launch("spmm_csr");
+}
+
+void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
+    if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "panel width %u unsupported (max %d)", l, kMaxL);
+    if (a.is_csr) { spmm(a, d_x, d_y, l); return; }
+    const unsigned grid = grid_cap(a.nrows * 64, 256);
+    if (l <= 32)
+        hipLaunchKernelGGL((dense_mul_panel_kernel<32>), dim3(grid), dim3(256), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+    else
+        hipLaunchKernelGGL((dense_mul_panel_kernel<64>), dim3(grid), dim3(256), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+    check_launch("dense_mul_panel");
+}
+
+void build_transpose(ae_matrepr& a) {
+    if (a.transpose || !a.is_csr) return;
+    std::unique_ptr<ae_matrepr> t(new ae_matrepr);
+    t->is_csr = true;
+    t->nrows = a.ncols; t->ncols = a.nrows; t->nnz = a.nnz;
+    t->indptr.alloc(t->nrows + 1);
+    t->indices.alloc(a.nnz ? a.nnz : 1);
+    t->values.alloc(a.nnz ? a.nnz : 1);
+    if (a.nnz) {
+        DevBuf<uint64_t> k0(a.nnz), k1(a.nnz);
+        DevBuf<uint32_t> p0(a.nnz), p1(a.nnz);
+        hipLaunchKernelGGL(coo_keys_kernel, dim3(blocks_for(a.nrows, 256)), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, k0.p, p0.p);
+        check_launch("coo_keys");
+        sort_pairs_u64_u32(k0.p, k1.p, p0.p, p1.p, a.nnz);
+        hipLaunchKernelGGL(transpose_fill_kernel, dim3(blocks_for(a.nnz, 256)), dim3(256), 0, stream(), a.nnz, k1.p, p1.p, a.values.p,
+                           t->indices.p, t->values.p);
+        check_launch("transpose_fill");
+        rowptr_from_sorted_keys(k1.p, a.nnz, t->nrows, t->indptr.p);
+        sync();
+    } else {
+        t->indptr.zero();
+    }
+    a.transpose = std::move(t);
+}
+
+void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
+    if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "panel width %u unsupported (max %d)", l, kMaxL);
+    if (a.is_csr) {
+        if (a.symmetric) { spmm(a, d_x, d_y, l); return; }
+        build_transpose(a);
+        spmm(*a.transpose, d_x, d_y, l);
+        return;
+    }
+    const uint64_t m = a.nrows, n = a.ncols;
+    const uint64_t colblocks = (n + 63) / 64;
+    uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, std::max<uint64_t>(1, 4096 / colblocks)));
+    const uint64_t rpc = (m + chunks - 1) / chunks;
+    chunks = (m + rpc - 1) / rpc;
+    DevBuf<float> partial(chunks * n * l);
+    if (l <= 32)
+        hipLaunchKernelGGL((dense_t_mul_panel_kernel<32>), dim3((unsigned)colblocks, (unsigned)chunks), dim3(64), 0, stream(), a.values.p, m, n, d_x, partial.p, l, rpc);
+    else
+        hipLaunchKernelGGL((dense_t_mul_panel_kernel<64>), dim3((unsigned)colblocks, (unsigned)chunks), dim3(64), 0, stream(), a.values.p, m, n, d_x, partial.p, l, rpc);
+    check_launch("dense_t_mul_panel");
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for(n * l, 256)), dim3(256), 0, stream(), partial.p, chunks, n * l, d_y);
+    check_launch("reduce_chunks");
+    sync();
+}
+
+void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024));
+    DevBuf<double> partial((uint64_t)nblocks * l * l);
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, partial.p);
+    check_launch("gram_partial");
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), partial.p, nblocks, l * l, d_g);
+    check_launch("gram_reduce");
+    sync();  // partial is freed on return
+}
+
+void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out) {
+    if (d_out == d_y && lout > l) fail(AE_ERR_INVALID_ARG, "in-place apply needs lout <= l");
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 8192));
+    hipLaunchKernelGGL(apply_panel_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, d_m, lout, d_out);
+    check_launch("apply_panel");
+}
+
+void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs) {
+    hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(256), 0, stream(), d_g, l, d_evals, d_evecs);
+    check_launch("jacobi_eigh");
+}
+
+void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work) {
+    double* g = d_work;
+    double* ev = d_work + (uint64_t)l * l;
+    double* evals = d_work + 2ull * l * l;  // needs l more doubles: caller gives 3*l*l
+    for (int pass = 0; pass < 2; pass++) {
+        gram_panel(d_y, rows, l, g);
+        jacobi_eigh_device(g, l, evals, ev);
+        // first pass drops directions below f32 resolution of the panel; second pass only rescales
+        hipLaunchKernelGGL(svqb_scale_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), evals, ev, l,
+                           pass == 0 ? 1e-12 : 1e-6, g);
+        check_launch("svqb_scale");
+        apply_panel(d_y, rows, l, g, l, d_y);
+    }
+}
+
+// subspace_iteration_full / _csr, svdapprox.rs:285-408.  d_q: m x l panel (output, orthonormal columns)
+static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, DevBuf<float>& q) {
+    const uint64_t m = a.nrows, n = a.ncols;
+    const uint32_t l = (uint32_t)std::min<uint64_t>(std::min(m, n), rank);  // :294 / :358
+    if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "rank %llu unsupported (1..%d)", (unsigned long long)rank, kMaxL);
+    DevBuf<float> omega(n * l), yn(n * l);
+    DevBuf<double> work(3ull * l * l + l);
+    q.alloc(m * l);
+    gaussian_fill_device(omega.p, n * l, kDefaultSeed, kTagOmega);  // RandomGaussianMatrix::new, :69-76, :299/:363
+    mat_mul_panel(a, omega.p, q.p, l);                              // :300 / :366
+    orthonormalize_panel(q.p, m, l, work.p);                        // :307 / :374
+    for (uint64_t j = 1; j < nbiter; j++) {                         // :308 / :375
+        mat_t_mul_panel(a, q.p, yn.p, l);                           // :311 / :379
+        orthonormalize_panel(yn.p, n, l, work.p);                   // :313-319 / :381-387
+        mat_mul_panel(a, yn.p, q.p, l);                             // :321 / :390
+        orthonormalize_panel(q.p, m, l, work.p);                    // :323-329 / :392-398
+    }
+    sync();
+    return l;
+}
+
+struct SvdOut {
+    uint32_t l = 0;
+    std::vector<float> s;
+    DevBuf<float> u;   // m x l
+    DevBuf<float> vtT; // n x l  (V, i.e. Vt transposed), only if want_vt
+};
+
+// SvdApprox::direct_svd (RANK mode), svdapprox.rs:721-799
+static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, bool want_vt, SvdOut& out) {
+    DevBuf<float> q;
+    const uint32_t l = subspace_iteration_device(a, rank, nbiter, q);
+    const uint64_t m = a.nrows, n = a.ncols;
+    // B = Q^T A (l x n), kept transposed: Bt = A^T Q (n x l)                       :737-743
+    DevBuf<float> bt(n * l);
+    mat_t_mul_panel(a, q.p, bt.p, l);
+    // svd(B) through the l x l Gram B B^T = U_b S^2 U_b^T                          :758
+    DevBuf<double> work(3ull * l * l + l);
+    double* g = work.p;
+    double* ub = work.p + (uint64_t)l * l;
+    double* evals = work.p + 2ull * l * l;
+    gram_panel(bt.p, n, l, g);
+    jacobi_eigh_device(g, l, evals, ub);
+    std::vector<double> hev(l);
+    AE_HIP(hipMemcpyAsync(hev.data(), evals, sizeof(double) * l, hipMemcpyDeviceToHost, stream()));
+    sync();
+    out.l = l;
+    out.s.resize(l);
+    for (uint32_t i = 0; i < l; i++) out.s[i] = (float)std::sqrt(std::max(hev[i], 0.));
+    // U = Q U_b                                                                   :781
+    out.u.alloc(m * l);
+    apply_panel(q.p, m, l, ub, l, out.u.p);
+    if (want_vt) {
+        // Vt = S^-1 U_b^T B  <=>  V = Bt U_b S^-1 ; null directions get zero rows
+        std::vector<double> hub(l * l), hm(l * l);
+        AE_HIP(hipMemcpyAsync(hub.data(), ub, sizeof(double) * l * l, hipMemcpyDeviceToHost, stream()));
+        sync();
+        for (uint32_t c = 0; c < l; c++)
+            for (uint32_t o = 0; o < l; o++) {
+                const double sv = std::sqrt(std::max(hev[o], 0.));
+                hm[c * l + o] = (sv > 1e-7 * std::sqrt(std::max(hev[0], 0.)) && sv > 0.) ? hub[c * l + o] / sv : 0.;
+            }
+        DevBuf<double> dm(l * l);
+        dm.upload(hm.data(), l * l);
+        out.vtT.alloc(n * l);
+        apply_panel(bt.p, n, l, dm.p, l, out.vtT.p);
+    }
+    sync();
+}
+
+// Leading singular triplets of a dense symmetric matrix, converged: stands in for the full LAPACK
+// gesdd of do_full_svd / svd_f32 (graphlaplace.rs:82-94, 296-344), of which the embedder only reads
+// s[0..d] and U[:, 1..d] (diffmaps.rs:1213-1236).  Block subspace iteration on A^2 with
+// Rayleigh-Ritz every few steps until the first `rank` singular values move by < tol.
+void full_svd_leading(ae_matrepr& a, uint32_t rank, std::vector<float>& s, DevBuf<float>& u) {
+    const uint64_t n = a.nrows;
+    const uint32_t l = (uint32_t)std::min<uint64_t>(n, std::min<uint32_t>(kMaxL, rank + 12));
+    rank = std::min<uint32_t>(rank, l);
+    DevBuf<float> q(n * l), z(n * l);
+    DevBuf<double> work(3ull * l * l + l);
+    gaussian_fill_device(z.p, n * l, kDefaultSeed, kTagOmega);
+    mat_mul_panel(a, z.p, q.p, l);
+    orthonormalize_panel(q.p, n, l, work.p);
+    std::vector<double> prev(l, 0.), cur(l);
+    double* g = work.p;
+    double* ub = work.p + (uint64_t)l * l;
+    double* evals = work.p + 2ull * l * l;
+    const int max_outer = 400;
+    for (int it = 0; it < max_outer; it++) {
+        for (int inner = 0; inner < 4; inner++) {
+            mat_t_mul_panel(a, q.p, z.p, l);
+            orthonormalize_panel(z.p, n, l, work.p);
+            mat_mul_panel(a, z.p, q.p, l);
+            orthonormalize_panel(q.p, n, l, work.p);
+        }
+        // Rayleigh-Ritz on B = Q^T A: sigma^2 = eig(B B^T), rotate Q onto the Ritz vectors
+        mat_t_mul_panel(a, q.p, z.p, l);
+        gram_panel(z.p, n, l, g);
+        jacobi_eigh_device(g, l, evals, ub);
+        AE_HIP(hipMemcpyAsync(cur.data(), evals, sizeof(double) * l, hipMemcpyDeviceToHost, stream()));
+        sync();
+        apply_panel(q.p, n, l, ub, l, q.p);
+        double delta = 0.;
+        for (uint32_t i = 0; i < rank; i++) {
+            double a1 = std::sqrt(std::max(cur[i], 0.)), a0 = std::sqrt(std::max(prev[i], 0.));
+            delta = std::max(delta, std::fabs(a1 - a0) / std::max(a1, 1e-30));
+        }
+        prev = cur;
+        if (it > 0 && delta < 2e-8) break;
+    }
+    s.resize(rank);
+    for (uint32_t i = 0; i < rank; i++) s[i] = (float)std::sqrt(std::max(prev[i], 0.));
+    // keep the first `rank` Ritz vectors
+    std::vector<double> sel((uint64_t)l * rank, 0.);
+    for (uint32_t i = 0; i < rank; i++) sel[(uint64_t)i * rank + i] = 1.;
+    DevBuf<double> dsel((uint64_t)l * rank);
+    dsel.upload(sel.data(), (uint64_t)l * rank);
+    u.alloc(n * rank);
+    apply_panel(q.p, n, l, dsel.p, rank, u.p);
+    sync();
+}
+
+void direct_svd_rank(ae_matrepr& a, uint64_t rank, uint64_t nbiter, std::vector<float>& s, DevBuf<float>& u) {
+    SvdOut o;
+    direct_svd_device(a, rank, nbiter, false, o);
+    s = o.s;
+    u = std::move(o.u);
+}
+
+}  // namespace ae
+
+extern "C" {
+
+int32_t ae_matrepr_from_csr(const uint64_t* indptr, const uint32_t* indices, const float* values, uint64_t nrows, uint64_t ncols,
+                            ae_matrepr** out) {
+    return guard([&] {
+        require_device();
+        if (!indptr || !out || nrows == 0 || ncols == 0) fail(AE_ERR_INVALID_ARG, "null argument or empty matrix");
+        const uint64_t nnz = indptr[nrows];
+        if (nnz && (!indices || !values)) fail(AE_ERR_INVALID_ARG, "null indices/values");
+        for (uint64_t i = 0; i < nrows; i++)
+            if (indptr[i + 1] < indptr[i]) fail(AE_ERR_INVALID_ARG, "indptr not monotone");
+        for (uint64_t e = 0; e < nnz; e++)
+            if (indices[e] >= ncols) fail(AE_ERR_INVALID_ARG, "column index out of range");
+        std::unique_ptr<ae_matrepr> m(new ae_matrepr);
+        m->is_csr = true;
+        m->nrows = nrows; m->ncols = ncols; m->nnz = nnz;
+        m->indptr.alloc(nrows + 1);
+        m->indptr.upload(indptr, nrows + 1);
+        m->indices.alloc(nnz ? nnz : 1);
+        m->values.alloc(nnz ? nnz : 1);
+        if (nnz) { m->indices.upload(indices, nnz); m->values.upload(values, nnz); }
+        sync();
+        *out = m.release();
+    });
+}
+int32_t ae_matrepr_from_dense(const float* values, uint64_t nrows, uint64_t ncols, ae_matrepr** out) {
+    return guard([&] {
+        require_device();
+        if (!values || !out || nrows == 0 || ncols == 0) fail(AE_ERR_INVALID_ARG, "null argument or empty matrix");
+        std::unique_ptr<ae_matrepr> m(new ae_matrepr);
+        m->is_csr = false;
+        m->nrows = nrows; m->ncols = ncols; m->nnz = nrows * ncols;
+        m->values.alloc(nrows * ncols);
+        m->values.upload(values, nrows * ncols);
+        sync();
+        *out = m.release();
+    });
+}
+int32_t ae_matrepr_destroy(ae_matrepr* m) {
+    return guard([&] { delete m; });
+}
+
+int32_t ae_subspace_iteration(const ae_matrepr* m, uint64_t rank, uint64_t nbiter, float* q, uint64_t* l_out) {
+    return guard([&] {
+        require_device();
+        if (!m || !q) fail(AE_ERR_INVALID_ARG, "null argument");
+        DevBuf<float> dq;
+        const uint32_t l = subspace_iteration_device(*const_cast<ae_matrepr*>(m), rank, nbiter, dq);
+        dq.download(q, m->nrows * l);
+        if (l_out) *l_out = l;
+    });
+}
+
+int32_t ae_svd_approx_rank(const ae_matrepr* m, uint64_t rank, uint64_t nbiter, float* s, float* u, float* vt, uint64_t* l_out) {
+    return guard([&] {
+        require_device();
+        if (!m || !s) fail(AE_ERR_INVALID_ARG, "null argument");
+        SvdOut o;
+        direct_svd_device(*const_cast<ae_matrepr*>(m), rank, nbiter, vt != nullptr, o);
+        memcpy(s, o.s.data(), sizeof(float) * o.l);
+        if (u) o.u.download(u, m->nrows * o.l);
+        if (vt) {
+            DevBuf<float> t(m->ncols * o.l);
+            hipLaunchKernelGGL(transpose_dense_kernel, dim3(blocks_for(m->ncols * o.l, 256)), dim3(256), 0, stream(), o.vtT.p, m->ncols,
+                               (uint64_t)o.l, t.p);
+            check_launch("transpose_dense");
+            t.download(vt, m->ncols * o.l);
+        }
+        if (l_out) *l_out = o.l;
+    });
+}
+
+int32_t ae_transpose_dense_mult(const ae_matrepr* m, const float* q, uint64_t l, float* b) {
+    return guard([&] {
+        require_device();
+        if (!m || !q || !b || l == 0 || l > (uint64_t)kMaxL) fail(AE_ERR_INVALID_ARG, "bad argument");
+        DevBuf<float> dq(m->nrows * l), bt(m->ncols * l), bb(m->ncols * l);
+        dq.upload(q, m->nrows * l);
+        mat_t_mul_panel(*const_cast<ae_matrepr*>(m), dq.p, bt.p, (uint32_t)l);
+        hipLaunchKernelGGL(transpose_dense_kernel, dim3(blocks_for(m->ncols * l, 256)), dim3(256), 0, stream(), bt.p, m->ncols, l, bb.p);
+        check_launch("transpose_dense");
+        bb.download(b, m->ncols * l);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,329 @@
+/*
+ * annembed_hip.h -- C ABI of libannembed_hip.so, the MI355X (gfx950) implementation of
+ * annembed's embedding hot path:
+ *
+ *     kNN-graph edge weights -> diffusion-map initialisation (randomized SVD) -> cross-entropy SGD.
+ *
+ * This header is what a Rust `src/embedder.rs` shim (bindgen / hand-written `extern "C"` block, see
+ * INTEGRATION.md) binds.  Every entry point cites the reference interface it replaces as
+ * `file:line` relative to the annembed source tree (crate v0.1.7).
+ *
+ * Conventions
+ *  - every function returns an `int32_t` status: AE_OK (0) or one of the AE_ERR_* codes; the
+ *    reference's `exit(1)` / `panic!` sites are mapped to codes, nothing aborts across the ABI.
+ *    `ae_last_error_message()` returns a thread-local, human readable string for the last failure.
+ *  - all arrays are caller-allocated host memory unless the parameter name starts with `d_`
+ *    (device pointer).  The library never frees caller memory.  Opaque handles own device memory
+ *    and are released with the matching `ae_*_destroy`.
+ *  - node indices are u32 (reference: `NodeIdx = usize`, src/tools/nodeparam.rs:18), row pointers
+ *    u64, distances / probabilities / coordinates f32 (the reference examples instantiate F = f32).
+ *  - one handle = one HIP device + one HIP stream; calls on one handle must be serialised by the
+ *    caller, different handles are independent.
+ *  - the library is GPU-only: there is no CPU fallback.  Without a HIP device every compute entry
+ *    point fails with AE_ERR_NO_DEVICE.
+ */
+#ifndef ANNEMBED_HIP_H
+#define ANNEMBED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* status codes                                                                                 */
+/* ------------------------------------------------------------------------------------------- */
+enum {
+    AE_OK = 0,
+    AE_ERR_INVALID_ARG = 1,
+    AE_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime error                                */
+    AE_ERR_ISOLATED_NODE = 3, /* src/tools/kdumap.rs:75-85, src/diffmaps.rs:611-615,
+                                 src/fromhnsw/kgraph.rs:520-537                                  */
+    AE_ERR_PROBA_RANGE = 4,  /* assert at src/tools/kdumap.rs:209                                */
+    AE_ERR_SVD = 5,          /* src/graphlaplace.rs:118-122                                      */
+    AE_ERR_SPECTRUM = 6,     /* "svd spectrum not decreasing" src/diffmaps.rs:1176               */
+    AE_ERR_EMBED = 7,        /* Embedder::embed -> Err(1), src/embedder.rs:183-191               */
+    AE_ERR_STATE = 8,        /* call order violated (e.g. get_embedded before embed)             */
+    AE_ERR_BETA = 9,         /* "beta cannot be > 0." src/diffmaps.rs:827-830                    */
+    AE_ERR_OOM = 10
+};
+
+const char *ae_last_error_message(void);
+/* library / build identification: "annembed_hip <version> gfx950" */
+const char *ae_version(void);
+int32_t ae_device_count(int32_t *count);
+int32_t ae_set_device(int32_t device);
+/* synchronise the library's stream on the current device */
+int32_t ae_synchronize(void);
+/* raw hipStream_t the library launches on (for hipEvent timing by the caller) */
+int32_t ae_get_stream(void **stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* parameter PODs                                                                               */
+/* ------------------------------------------------------------------------------------------- */
+
+/* EmbedderParams, src/embedparams.rs:77-103 (field for field) + build extras */
+typedef struct ae_embedder_params {
+    uint64_t asked_dim;           /* :79  default 2  */
+    uint8_t dmap_init;            /* :81  default 1  */
+    double beta;                  /* :83  default 1. */
+    double b;                     /* :85  default 1. */
+    double scale_rho;             /* :87  default 1. */
+    double grad_step;             /* :89  default 2. */
+    uint64_t nb_sampling_by_edge; /* :91  default 10 */
+    uint64_t nb_grad_batch;       /* :93  default 20 */
+    uint64_t grad_factor;         /* :96  default 4  */
+    uint64_t hierarchy_layer;     /* :98  default 0  */
+    uint8_t hubness_weighting;    /* :102 default 0  */
+    /* ---- build extras (no reference counterpart: the reference draws from an unseeded
+     * thread RNG, src/embedder.rs:1121,1182) ---- */
+    uint64_t seed;      /* Philox key for every random draw of the embedding. default 4664397  */
+    uint32_t ce_mode;   /* AE_CE_* below. default AE_CE_HOGWILD                                 */
+    uint32_t ce_sampler; /* AE_SAMPLER_* below. default AE_SAMPLER_ROWCDF                       */
+} ae_embedder_params;
+
+enum {
+    /* Lock-free in-place updates, as the reference's rayon loop (src/embedder.rs:1311-1315,
+       "Hogwild" comment :1197).  Fast path; not reproducible run to run (neither is the reference). */
+    AE_CE_HOGWILD = 0,
+    /* Deterministic: executes exactly the sequential order sample 0,1,2,... of the reference's
+       `gradient_iteration` (src/embedder.rs:1305-1309) through a conflict-free level schedule.
+       Bit-exact against the CPU oracle; slow; meant for parity tests. */
+    AE_CE_SEQUENTIAL = 1
+};
+enum {
+    /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
+       row of probabilities sums to 1 (src/tools/kdumap.rs:215-218). */
+    AE_SAMPLER_ROWCDF = 0,
+    /* edge ~ Walker/Vose alias table over all edges, as WeightedAliasIndex at src/embedder.rs:987 */
+    AE_SAMPLER_ALIAS = 1
+};
+
+/* fills *p with EmbedderParams::default(), src/embedparams.rs:107-132 */
+int32_t ae_embedder_params_default(ae_embedder_params *p);
+
+/* DiffusionParams, src/diffmaps.rs:72-87 */
+typedef struct ae_diffusion_params {
+    uint64_t asked_dim; /* :74 */
+    float alfa;         /* :76 */
+    float beta;         /* :78 */
+    float epsil;        /* :80 */
+    float t;            /* :82  valid when has_t        */
+    uint8_t has_t;
+    uint64_t gnbn;      /* :84  valid when has_gnbn     */
+    uint8_t has_gnbn;
+} ae_diffusion_params;
+
+/* DiffusionParams::new(asked_dim, t_opt, g_opt): alfa .5, beta -.1, epsil 2 -- src/diffmaps.rs:95-105.
+   Pass has_t = 0 / has_gnbn = 0 for None. */
+int32_t ae_diffusion_params_new(ae_diffusion_params *p, uint64_t asked_dim, float t, uint8_t has_t,
+                                uint64_t gnbn, uint8_t has_gnbn);
+/* setters with the reference's clamps: set_alfa :122-136, set_beta :140-148, set_epsil :151-160 */
+int32_t ae_diffusion_params_set_alfa(ae_diffusion_params *p, float alfa);
+int32_t ae_diffusion_params_set_beta(ae_diffusion_params *p, float beta);
+int32_t ae_diffusion_params_set_epsil(ae_diffusion_params *p, float epsil);
+
+/* ------------------------------------------------------------------------------------------- */
+/* a1. KGraph -- src/fromhnsw/kgraph.rs:109-120                                                 */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct ae_kgraph ae_kgraph;
+
+/* Build from an already flattened graph: rows sorted by increasing distance (the invariant of
+   kgraph.rs:508-509), indices already dense NodeIdx.  `indptr` has n+1 entries.
+   Errors: AE_ERR_ISOLATED_NODE if a row is empty (kgraph.rs:520-537), AE_ERR_INVALID_ARG if a row is
+   not sorted, longer than max_nbng, or holds an index >= n. */
+int32_t ae_kgraph_create(const uint64_t *indptr, const uint32_t *nbr, const float *dist, uint64_t n,
+                         uint32_t max_nbng, ae_kgraph **out);
+
+/* The tail of kgraph_from_hnsw_all (kgraph.rs:496-546) on device: for each point (in iteration
+   order) concatenate its neighbour lists, remap DataId -> NodeIdx in first-seen order (IndexSet
+   semantics of :489,:500: the point itself first, then its neighbours in list order), sort
+   ascending by distance, truncate to nbng.
+   point_id[n_points]; row_ptr[n_points+1] into nbr_data_id / nbr_dist (ragged, all layers
+   concatenated).  data_id_of_idx_out (optional, n_points) receives the IndexSet (NodeIdx -> DataId). */
+int32_t ae_kgraph_from_ragged(const uint64_t *point_id, const uint64_t *row_ptr,
+                              const uint64_t *nbr_data_id, const float *nbr_dist, uint64_t n_points,
+                              uint32_t nbng, ae_kgraph **out, uint64_t *data_id_of_idx_out);
+
+int32_t ae_kgraph_destroy(ae_kgraph *g);
+int32_t ae_kgraph_get_nb_nodes(const ae_kgraph *g, uint64_t *n);   /* kgraph.rs:147 */
+int32_t ae_kgraph_get_max_nbng(const ae_kgraph *g, uint32_t *k);   /* kgraph.rs:152 */
+int32_t ae_kgraph_get_nb_edges(const ae_kgraph *g, uint64_t *nnz);
+/* get_neighbours (kgraph.rs:157): copies the CSR back. Any pointer may be NULL. */
+int32_t ae_kgraph_get_neighbours(const ae_kgraph *g, uint64_t *indptr, uint32_t *nbr, float *dist);
+
+/* "KGraph distance batching" (north star; no reference counterpart -- the reference copies
+   hnsw_rs's distances, kgraph.rs:504): recompute dist[e] = || x[i] - x[nbr[e]] ||_2 for every edge
+   from a row-major n x dim f32 coordinate matrix, then re-sort each row by the new distances. */
+int32_t ae_kgraph_fill_l2_distances(ae_kgraph *g, const float *x, uint64_t dim);
+
+/* Exact brute-force kNN graph (L2) of a row-major n x dim f32 matrix: the build's stand-in for
+   the hnsw_rs producer in benchmarks.  Self matches are excluded (kgraph.rs:502 asserts
+   index != neighbour). */
+int32_t ae_kgraph_bruteforce_l2(const float *x, uint64_t n, uint64_t dim, uint32_t nbng,
+                                ae_kgraph **out);
+
+/* Hubness::new (src/fromhnsw/hubness.rs:39-76): in-degree count of every node. counts[n] */
+int32_t ae_kgraph_hubness(const ae_kgraph *g, uint32_t *counts);
+
+/* KGraphProjection accessors, src/fromhnsw/kgproj.rs:376-410.  small: graph of the n_small first
+   nodes; large: graph on all nodes; proj_node/proj_dist[n_large]: for every node >= n_small the
+   nearest node of the small graph and its distance (entries < n_small are ignored). */
+typedef struct ae_kgraph_projection ae_kgraph_projection;
+int32_t ae_kgraph_projection_create(const ae_kgraph *small, const ae_kgraph *large,
+                                    const uint32_t *proj_node, const float *proj_dist,
+                                    ae_kgraph_projection **out);
+int32_t ae_kgraph_projection_destroy(ae_kgraph_projection *p);
+
+/* ------------------------------------------------------------------------------------------- */
+/* a2. to_proba_edges -- src/tools/kdumap.rs:26-116, 132-235                                    */
+/* ------------------------------------------------------------------------------------------- */
+/* NodeParams (src/tools/nodeparam.rs:111-114) as device CSR: proba[nnz] aligned with the graph's
+   nbr[], scale[n]. */
+typedef struct ae_node_params ae_node_params;
+int32_t ae_to_proba_edges(const ae_kgraph *g, float scale_rho, float beta, ae_node_params **out);
+/* NodeParams::new(params, max_nbng) (src/tools/nodeparam.rs:117-119) from caller-provided edge
+   probabilities (aligned with the graph's nbr[]) and per-node scales. */
+int32_t ae_node_params_from_host(const ae_kgraph *g, const float *proba, const float *scale,
+                                 ae_node_params **out);
+int32_t ae_node_params_destroy(ae_node_params *np);
+/* copies back; any pointer may be NULL.  proba has nnz entries, scale n entries. */
+int32_t ae_node_params_get(const ae_node_params *np, float *proba, float *scale);
+/* NodeParam::get_perplexity (nodeparam.rs:88-91) for every node: exp(-sum p ln p) */
+int32_t ae_node_params_perplexity(const ae_node_params *np, float *perplexity);
+
+/* ------------------------------------------------------------------------------------------- */
+/* a3-a9. diffusion-map initialisation -- src/diffmaps.rs                                       */
+/* ------------------------------------------------------------------------------------------- */
+/* GraphLaplacian (src/graphlaplace.rs:21-35) produced by DiffusionMaps::laplacian_from_kgraph
+   (diffmaps.rs:397-422 = compute_dmap_nodeparams :752-849 + kernel0_to_density :855-952 +
+   compute_laplacian :427-587).  The dense / CSR switch at FULL_MAT_REPR = 5000 nodes
+   (graphlaplace.rs:13) is reproduced; force_repr overrides it (0 = reference rule, 1 = dense,
+   2 = CSR) so tests can exercise both branches on one graph. */
+typedef struct ae_laplacian ae_laplacian;
+int32_t ae_dmap_laplacian_from_kgraph(const ae_kgraph *g, const ae_diffusion_params *dp,
+                                      int32_t force_repr, ae_laplacian **out);
+int32_t ae_laplacian_destroy(ae_laplacian *l);
+/* is_csr, nnz (CSR) or n*n (dense) */
+int32_t ae_laplacian_info(const ae_laplacian *l, int32_t *is_csr, uint64_t *n, uint64_t *nnz);
+/* copies back the symmetric kernel.  CSR: indptr[n+1], indices[nnz], values[nnz] (columns sorted,
+   duplicates summed -- TriMat::to_csr semantics, diffmaps.rs:572-578).  Dense: values[n*n]
+   row-major, indptr/indices ignored. */
+int32_t ae_laplacian_get_kernel(const ae_laplacian *l, uint64_t *indptr, uint32_t *indices,
+                                float *values);
+/* normalizer (sqrt degrees, :565,:581), normed_scales (:815-822), q density (:949) and
+   beta_scales (:842).  Any pointer may be NULL; each has n entries; mean_scale is a scalar. */
+int32_t ae_laplacian_get_vectors(const ae_laplacian *l, float *normalizer, float *normed_scales,
+                                 float *q_density, float *beta_scales, float *mean_scale);
+
+/* GraphLaplacian::do_svd (graphlaplace.rs:127-134): dense & n <= 5000 -> full SVD (here: the
+   leading `rank` singular triplets, converged to f32 roundoff, instead of all n); otherwise
+   do_approx_svd = direct_svd(RANK(rank = 20, nbiter = 5)) (graphlaplace.rs:97-125).
+   s[rank_out], u[n * rank_out] row-major.  *rank_out <= rank_cap = 20. */
+int32_t ae_laplacian_do_svd(ae_laplacian *l, float *s, float *u, uint64_t *rank_out);
+
+/* DiffusionMaps::embed_from_kgraph (diffmaps.rs:1047-1075): laplacian_from_kgraph + do_svd +
+   embed_from_laplacian (:1145-1243).  y0 receives n x real_dim row-major, real_dim =
+   min(asked_dim, rank-1) written to *real_dim. */
+int32_t ae_dmap_embed_from_kgraph(const ae_kgraph *g, const ae_diffusion_params *dp, float *y0,
+                                  uint64_t *real_dim);
+
+/* ------------------------------------------------------------------------------------------- */
+/* a7-a8. tools::svdapprox -- src/tools/svdapprox.rs                                            */
+/* ------------------------------------------------------------------------------------------- */
+/* MatRepr (src/tools/matrepr.rs:23-32) */
+typedef struct ae_matrepr ae_matrepr;
+int32_t ae_matrepr_from_csr(const uint64_t *indptr, const uint32_t *indices, const float *values,
+                            uint64_t nrows, uint64_t ncols, ae_matrepr **out);
+int32_t ae_matrepr_from_dense(const float *values /* row-major */, uint64_t nrows, uint64_t ncols,
+                              ae_matrepr **out);
+int32_t ae_matrepr_destroy(ae_matrepr *m);
+
+/* RangeApproxMode::RANK(RangeRank{rank, nbiter}) -> subspace_iteration_{csr,full}
+   (svdapprox.rs:285-333, 343-408).  q receives nrows x l row-major, l = min(nrows, ncols, rank)
+   written to *l_out. */
+int32_t ae_subspace_iteration(const ae_matrepr *m, uint64_t rank, uint64_t nbiter, float *q,
+                              uint64_t *l_out);
+
+/* SvdApprox::direct_svd(RANK) (svdapprox.rs:721-799): s[l], u[nrows*l] row-major,
+   vt[l*ncols] row-major (u / vt may be NULL). */
+int32_t ae_svd_approx_rank(const ae_matrepr *m, uint64_t rank, uint64_t nbiter, float *s, float *u,
+                           float *vt, uint64_t *l_out);
+
+/* transpose_dense_mult_csr (svdapprox.rs:116-139): b[l x ncols] = q^T * m, q is nrows x l. */
+int32_t ae_transpose_dense_mult(const ae_matrepr *m, const float *q, uint64_t l, float *b);
+
+/* ------------------------------------------------------------------------------------------- */
+/* a10-a13. EntropyOptim -- src/embedder.rs:936-1315                                            */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct ae_entropy_optim ae_entropy_optim;
+
+/* set_data_box (embedder.rs:1376-1408) on an n x dim row-major host array, in place on device. */
+int32_t ae_set_data_box(float *y, uint64_t n, uint64_t dim, float box_size);
+
+/* EntropyOptim::new (embedder.rs:964-1025).  y0: n x asked_dim row-major initial embedding.
+   hub_counts: NULL, or in-degree counts (n) when params->hubness_weighting (embedder.rs:826-833).
+   Sharding (multi-GPU, no reference counterpart): this handle draws its positive edges only from
+   source nodes [node_lo, node_hi) and runs `samples_share` = that fraction of every batch's
+   samples; pass node_lo = 0, node_hi = n for the single-GPU path. */
+int32_t ae_entropy_optim_create(const ae_kgraph *g, const ae_node_params *np,
+                                const ae_embedder_params *params, const float *y0,
+                                const uint32_t *hub_counts, uint64_t node_lo, uint64_t node_hi,
+                                ae_entropy_optim **out);
+int32_t ae_entropy_optim_destroy(ae_entropy_optim *o);
+int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz); /* :1027 */
+/* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
+int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);
+/* gradient_iteration_threaded(nb_sample, grad_step) (embedder.rs:1311-1315).  `iter` keys the RNG
+   stream (the reference passes nothing: its RNG is unseeded).  Asynchronous on the handle's
+   stream in Hogwild mode. */
+int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim *o, uint64_t nb_sample,
+                                            double grad_step, uint64_t iter);
+/* The nodes sample `s` of batch `iter` touches: nodes7 = {i, j, k1..k5} (positive edge :1182-1184,
+   accepted negatives :1241-1253) and the edge probability w.  Deterministic given graph + seed. */
+int32_t ae_entropy_optim_plan(ae_entropy_optim *o, uint64_t s_begin, uint64_t count, uint64_t iter,
+                              uint32_t *nodes7, float *w);
+/* embedded scales (embedder.rs:1356-1373), n entries */
+int32_t ae_entropy_optim_get_scales(const ae_entropy_optim *o, float *emb_scale);
+/* current coordinates, n x dim row-major */
+int32_t ae_entropy_optim_get_embedded(const ae_entropy_optim *o, float *y);
+/* device pointer to the n x dim f32 coordinate array (for RCCL all-gather by the caller) */
+int32_t ae_entropy_optim_device_coords(ae_entropy_optim *o, void **d_y, uint64_t *n, uint64_t *dim);
+/* average duration in ms of the SGD kernel launches since the last call (hipEvent on the handle's
+   stream) and their count; resets the accumulators. */
+int32_t ae_entropy_optim_kernel_time(ae_entropy_optim *o, double *avg_ms, uint64_t *launches);
+
+/* entropy_optimize (embedder.rs:794-904) in one call: CE before, nb_grad_batch batches with
+   step = grad_step * (1 - iter/nb_batch) (:875), CE after.  y: n x asked_dim out. */
+int32_t ae_entropy_optimize(const ae_kgraph *g, const ae_node_params *np,
+                            const ae_embedder_params *params, const float *y0, float *y,
+                            double *ce_before, double *ce_after);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Embedder -- src/embedder.rs:84-453                                                           */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct ae_embedder ae_embedder;
+/* Embedder::new (embedder.rs:107) -- the graph must outlive the embedder */
+int32_t ae_embedder_new(const ae_kgraph *g, const ae_embedder_params *params, ae_embedder **out);
+/* Embedder::from_hkgraph (embedder.rs:120) */
+int32_t ae_embedder_from_hkgraph(const ae_kgraph_projection *p, const ae_embedder_params *params,
+                                 ae_embedder **out);
+int32_t ae_embedder_destroy(ae_embedder *e);
+/* Embedder::embed (embedder.rs:183): one_step_embed (:298) or h_embed (:194). Ok(1) -> AE_OK */
+int32_t ae_embedder_embed(ae_embedder *e);
+int32_t ae_embedder_get_nb_nodes(const ae_embedder *e, uint64_t *n);          /* :785 */
+/* get_embedded (:378) / get_embedded_reindexed (:384; data_id_of_idx may be NULL = identity) */
+int32_t ae_embedder_get_embedded(const ae_embedder *e, float *y);
+int32_t ae_embedder_get_embedded_reindexed(const ae_embedder *e, const uint64_t *data_id_of_idx,
+                                           float *y);
+int32_t ae_embedder_get_initial_embedding(const ae_embedder *e, float *y0);   /* :426 */
+int32_t ae_embedder_get_hubness(const ae_embedder *e, uint32_t *counts);      /* :156 */
+/* CE before / after the gradient iterations (logged by the reference at :846-886) */
+int32_t ae_embedder_get_cross_entropy(const ae_embedder *e, double *before, double *after);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNEMBED_HIP_H */
