@@ -23,6 +23,7 @@ AE_ERR_OOM = 10
 
 AE_CE_HOGWILD = 0
 AE_CE_SEQUENTIAL = 1
+AE_CE_SAMPLE_RACY = 2
 AE_SAMPLER_ROWCDF = 0
 AE_SAMPLER_ALIAS = 1
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ae_entropy_optim_ce": [_vp, _P(_f64)],
     "ae_entropy_optim_gradient_iteration": [_vp, _u64, _f64, _u64],
     "ae_entropy_optim_plan": [_vp, _u64, _u64, _u64, _vp, _vp],
+    "ae_entropy_optim_samples_drawn": [_vp, _P(_u64), _P(_u32)],
     "ae_entropy_optim_get_scales": [_vp, _vp],
     "ae_entropy_optim_get_embedded": [_vp, _vp],
     "ae_entropy_optim_device_coords": [_vp, _P(_vp), _P(_u64), _P(_u64)],

@@ -302,6 +302,11 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_plan(self._h, s_begin, count, it, ptr(nodes), ptr(w)))
         return nodes, w
 
+    def samples_drawn(self):
+        a, r = C.c_uint64(), C.c_uint32()
+        check(L.load().ae_entropy_optim_samples_drawn(self._h, C.byref(a), C.byref(r)))
+        return a.value, r.value
+
     def get_embedded_scales(self):
         s = np.zeros(self.n, np.float32)
         check(L.load().ae_entropy_optim_get_scales(self._h, ptr(s)))

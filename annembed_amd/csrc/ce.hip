@@ -16,7 +16,7 @@
 // bit-exact against the CPU oracle.
 #include <algorithm>
 
-#include "internal.h"
+#include "ce_internal.h"
 #include "philox.h"
 
 using namespace ae;
@@ -25,24 +25,6 @@ using namespace ae;
 
 namespace {
 
-struct CeDev {
-    uint64_t n, nnz;
-    uint32_t dim, uniform_k;
-    const uint64_t* indptr;
-    const uint32_t* nbr;
-    const float* proba;
-    const float* emb_scale;
-    float* y;
-    double b;
-    uint64_t seed;
-    uint32_t sampler;
-    uint64_t node_lo, node_hi, edge_lo, shard_edges;
-    const float* edge_odds;
-    const uint32_t* edge_alias;
-    const uint32_t* edge_src;
-    const float* hub_odds;
-    const uint32_t* hub_alias;
-};
 
 struct Plan {
     uint32_t i, j, k[5];
@@ -386,25 +368,6 @@ void alias_build_host(const float* w, uint64_t n, std::vector<float>& odds, std:
 
 }  // namespace ae
 
-struct ae_entropy_optim {
-    const ae_kgraph* g = nullptr;
-    const ae_node_params* np = nullptr;
-    ae_embedder_params params;
-    CeDev dev;
-    DevBuf<float> y, emb_scale;
-    DevBuf<float> edge_odds, hub_odds;
-    DevBuf<uint32_t> edge_alias, edge_src, hub_alias;
-    DevBuf<double> partial;
-    DevBuf<unsigned int> err;
-    // sequential-mode scratch
-    DevBuf<uint32_t> plan_nodes, order;
-    DevBuf<float> plan_w;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    uint64_t sample_offset = 0;
-    ~ae_entropy_optim() {
-        for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    }
-};
 
 template <int DIM>
 static void launch_hogwild(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
@@ -418,19 +381,10 @@ static void launch_planned(ae_entropy_optim* o, const uint32_t* order, uint64_t 
                        o->plan_nodes.p, o->plan_w.p, step);
 }
 
-#define AE_DISPATCH_DIM(dim, FN, ...)          \
-    switch (dim) {                             \
-        case 2: FN<2>(__VA_ARGS__); break;     \
-        case 3: FN<3>(__VA_ARGS__); break;     \
-        case 4: FN<4>(__VA_ARGS__); break;     \
-        case 8: FN<8>(__VA_ARGS__); break;     \
-        case 16: FN<16>(__VA_ARGS__); break;   \
-        default: FN<0>(__VA_ARGS__); break;    \
-    }
-
 static void check_err_flag(ae_entropy_optim* o) {
     unsigned int h = 0;
     o->err.download(&h, 1);
+    if (h & 2u) fail(AE_ERR_INVALID_ARG, "sample plan capacity exceeded (edge probabilities of a row sum to more than 1?)");
     if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
 }
 
@@ -569,6 +523,7 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
             d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
         }
         sync();
+        if (params->ce_mode != AE_CE_SEQUENTIAL) ce_node_build_transpose(o.get());
         return o.release();
     }
 }
@@ -622,10 +577,14 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         AE_HIP(hipEventCreate(&e0));
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
-        AE_DISPATCH_DIM(o->dev.dim, launch_hogwild, o, nb_sample, grad_step, (uint32_t)iter);
+        if (o->params.ce_mode == AE_CE_SAMPLE_RACY || !ce_node_supports_dim(o->dev.dim)) {
+            AE_DISPATCH_DIM(o->dev.dim, launch_hogwild, o, nb_sample, grad_step, (uint32_t)iter);
+            check_launch("ce_sgd_hogwild");
+        } else {
+            ce_node_gradient_iteration(o, nb_sample, grad_step, (uint32_t)iter);
+        }
         AE_HIP(hipEventRecord(e1, stream()));
         o->events.emplace_back(e0, e1);
-        check_launch("ce_sgd_hogwild");
     });
 }
 
@@ -641,6 +600,17 @@ int32_t ae_entropy_optim_plan(ae_entropy_optim* o, uint64_t s_begin, uint64_t co
         dn.download(nodes7, count * 7);
         if (w) dw.download(w, count);
         check_err_flag(o);
+    });
+}
+
+int32_t ae_entropy_optim_samples_drawn(ae_entropy_optim* o, uint64_t* samples, uint32_t* rounds) {
+    return guard([&] {
+        require_device();
+        if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
+        unsigned long long h = 0;
+        if (o->sample_counter.n) o->sample_counter.download(&h, 1);
+        if (samples) *samples = h;
+        if (rounds) *rounds = o->rounds;
     });
 }
 

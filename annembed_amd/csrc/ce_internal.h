@@ -1,0 +1,83 @@
+// ce_internal.h -- shared between ce.hip (EntropyOptim handle, sequential + per-sample kernels) and
+// ce_node.hip (node-centric owner-computes Hogwild kernel).
+#pragma once
+#include "internal.h"
+
+namespace ae {
+
+struct CeDev {
+    uint64_t n, nnz;
+    uint32_t dim, uniform_k;
+    const uint64_t* indptr;
+    const uint32_t* nbr;
+    const float* proba;
+    const float* emb_scale;
+    float* y;
+    double b;
+    uint64_t seed;
+    uint32_t sampler;
+    uint64_t node_lo, node_hi, edge_lo, shard_edges;
+    const float* edge_odds;
+    const uint32_t* edge_alias;
+    const uint32_t* edge_src;
+    const float* hub_odds;
+    const uint32_t* hub_alias;
+};
+
+// one in-edge (u -> v) of the transposed graph: everything thread v needs to replay the sample's
+// effect on y_v without touching the forward rows of u
+struct InEdge {
+    uint32_t src;   // u
+    uint32_t eid;   // index of the edge in the forward CSR (keys the per-edge sample count)
+    float w;        // proba[eid]
+    float s_src;    // embedded scale of u
+};
+
+}  // namespace ae
+
+using namespace ae;  // internal header: the handle below is declared at global scope for the C ABI
+
+#define AE_DISPATCH_DIM(dim, FN, ...)          \
+    switch (dim) {                             \
+        case 2: FN<2>(__VA_ARGS__); break;     \
+        case 3: FN<3>(__VA_ARGS__); break;     \
+        case 4: FN<4>(__VA_ARGS__); break;     \
+        case 8: FN<8>(__VA_ARGS__); break;     \
+        case 16: FN<16>(__VA_ARGS__); break;   \
+        default: FN<0>(__VA_ARGS__); break;    \
+    }
+
+struct ae_entropy_optim {
+    const ae_kgraph* g = nullptr;
+    const ae_node_params* np = nullptr;
+    ae_embedder_params params;
+    CeDev dev;
+    DevBuf<float> y, emb_scale;
+    DevBuf<float> edge_odds, hub_odds;
+    DevBuf<uint32_t> edge_alias, edge_src, hub_alias;
+    DevBuf<double> partial;
+    DevBuf<unsigned int> err;
+    // sequential-mode scratch
+    DevBuf<uint32_t> plan_nodes, order;
+    DevBuf<float> plan_w;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    uint64_t sample_offset = 0;
+    // node-centric (owner-computes) Hogwild: transposed graph (in-edges), built at create
+    DevBuf<uint64_t> tptr;
+    DevBuf<InEdge> tin;
+    DevBuf<unsigned long long> sample_counter;  // samples actually drawn (Poisson total), for verification
+    uint32_t rounds = 1;
+    DevBuf<uint8_t> cnt;     // per-edge sample counts of the current round
+    DevBuf<uint32_t> tot;    // per-node planned out-samples
+    DevBuf<uint32_t> plan;   // per-node sample plans (cap slots x 6 words)
+    ~ae_entropy_optim() {
+        for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+};
+
+namespace ae {
+// node-centric Hogwild batch (ce_node.hip): `rounds` launches, expected nb_sample samples in total
+bool ce_node_supports_dim(uint32_t dim);
+void ce_node_build_transpose(ae_entropy_optim* o);
+void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
+}  // namespace ae

@@ -1,0 +1,548 @@
+// ce_node.hip -- AE_CE_HOGWILD: the lock-free CE gradient batch (gradient_iteration_threaded,
+// src/embedder.rs:1311-1315) restructured for MI355X as an OWNER-COMPUTES, node-centric kernel.
+//
+// Why not "one thread per sample with racy read-modify-write", which is what the reference's rayon
+// loop does (:1185-1186, :1239, :1301)?  Measured on MI355X (tools/ubench_gather.hip): with ~2 M samples
+// in flight over 60 k nodes 91 % of racy 8-byte read-modify-writes are lost, the 8 per-XCD L2s are not
+// coherent inside a launch, and atomics of any type top out at ~23 G/s (vs 55-270 G/s for random 8-byte
+// loads, ~80 G/s for write-through stores).  A CPU has tens of threads for N nodes; the GPU has more
+// lanes than nodes.  So every coordinate row gets exactly ONE writer:
+//
+//   thread v owns y_v.  Per round it replays, sequentially on its private copy of y_v,
+//     (a) the samples whose source is v: attraction to the sampled neighbour j (the y_i half of
+//         :1223-1237) followed by the 5 negative repulsions (:1241-1299), and
+//     (b) the samples whose target is v: the y_j half of :1238-1239, recomputed from (y_u, y_v, s_u, w).
+//   The number of times edge e is sampled in a round is c_e ~ Poisson(mu_e), mu_e = nb_sample * p_e /
+//   (N * rounds): by Poisson splitting this is the edge law of the reference's i.i.d. draw from the
+//   alias table (:987, :1182) with a Poisson(nb_sample) total.  c_e is a pure function of (seed, batch,
+//   round, e) (one Philox block), so thread i and thread j agree on it with no communication, no
+//   atomics, no sorting -- and on multi-GPU the owner of j replays remote pushes from its replica.
+//   y_v is written back (write-through, agent scope) after every sample; partners are re-read
+//   (L1-bypassing loads) for every sample, so the staleness is that of the memory system, like Hogwild.
+//
+// Arithmetic: f32 with v_rcp_f32 (the reference's scalars are f64; the coefficient is a smooth
+// function clipped to [-0.49, 2], a 1e-7 relative difference is far below the SGD noise).  The exact
+// f64 arithmetic lives in ce.hip (AE_CE_SEQUENTIAL, bit-exact against the oracle).
+#include "ce_internal.h"
+#include "philox.h"
+
+using namespace ae;
+
+namespace ae {
+void sort_pairs_u64_u32(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, uint64_t count);
+void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrows, uint64_t* d_rowptr);
+}  // namespace ae
+
+namespace {
+
+constexpr uint32_t kTagEdgeCount = 0xFFFF0010u;
+constexpr uint32_t kTagNodeRng = 0xFFFF0011u;
+constexpr int kBlock = 256;
+constexpr int kApplyBlock = 64;  // one wave per workgroup: few nodes => spread the waves over all CUs
+
+template <int DIM>
+__device__ __forceinline__ void load_row_fresh(const float* __restrict__ y, uint32_t node, float* out) {
+    // L1-bypassing loads: another CU may have rewritten the row since this CU cached it
+    const float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM % 2 == 0) {
+        using f2 = __attribute__((ext_vector_type(2))) float;
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p) + q);
+            out[2 * q] = t.x; out[2 * q + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) out[t] = __builtin_nontemporal_load(p + t);
+    }
+}
+template <int DIM>
+__device__ __forceinline__ void store_row_through(float* __restrict__ y, uint32_t node, const float* in) {
+    // agent-scope (write-through) stores: the owner's update becomes visible to the other XCDs
+    float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// 2b * cauchy_weight * delta^(b-1) / s^2, embedder.rs:1216-1222 (f32)
+template <bool B1>
+__device__ __forceinline__ float grad_coeff_f32(float delta, float inv_s2, float b) {
+    if constexpr (!B1) {  // general exponent: kept out of the b == 1 instantiation (the powf code is ~8x the loop body)
+        const float db = __powf(delta, b);
+        return 2.0f * b * rcp(1.0f + db) * __powf(delta, b - 1.0f) * inv_s2;
+    }
+    return 2.0f * inv_s2 * rcp(1.0f + delta);
+}
+
+struct NodeArgs {
+    CeDev c;
+    const uint64_t* tptr;
+    const InEdge* tin;
+    uint8_t* cnt;        // per edge: number of samples of the edge in this round
+    uint32_t* tot;       // per owned node: number of planned out-samples (<= cap)
+    uint32_t* plan;      // per owned node: cap slots x 6 words {j, k1..k5}
+    uint32_t cap;
+    uint32_t round_key;
+    float step;
+    float unit;  // mu_e = unit * p_e
+    float b;
+    unsigned long long* sample_counter;
+    unsigned int* overflow;
+    unsigned long long* prof;  // debug: per-section cycle sums [stage, fetch-issue, compute, store, in-phase, total]
+    int skip;        // debug: 1 skip out-phase, 2 skip in-phase
+    int store_mode;  // 0: write-through store after every sample, 1: plain store after every sample, 2: write-through at phase ends
+};
+
+// PCG-RXS-M-XS 32 output hash: the fast mode's stream for the negative draws (the exact Philox stream
+// of the oracle is used by AE_CE_SEQUENTIAL; this mode is validated statistically)
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    uint32_t s = x * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+
+// Poisson(mu) by inversion on an edge-keyed uniform (one Philox block per edge and round)
+__device__ __forceinline__ uint32_t edge_count(uint64_t e, uint32_t round_key, uint64_t seed, float mu) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), round_key, kTagEdgeCount, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const float u = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+    float p = __expf(-mu);
+    float cdf = p;
+    uint32_t c = 0;
+    // stop once the remaining terms are below f32 resolution of the cdf (u can exceed the largest
+    // representable partial sum: without the bound the loop would run to the cap)
+    while (u >= cdf && c < 255u && p > 1e-9f) {
+        c++;
+        p *= mu / (float)c;
+        cdf += p;
+    }
+    return c;
+}
+
+// ---- K_plan: one wave per owned node.  Lanes < k draw the per-edge sample counts (written to cnt[] for
+// the in-push replay of the partner), a wave scan turns them into sample slots, then lane t plans sample t:
+// target j and the 5 admissible negatives (embedder.rs:1241-1253).
+template <bool HUB>
+__global__ void __launch_bounds__(kBlock) ce_plan_node_kernel(NodeArgs a) {
+    const CeDev c = a.c;
+    const int lane = threadIdx.x & 63;
+    const uint64_t v64 = c.node_lo + ((blockIdx.x * (uint64_t)kBlock + threadIdx.x) >> 6);
+    if (v64 >= c.node_hi) return;
+    const uint32_t v = (uint32_t)v64;
+    uint64_t ib;
+    uint32_t k;
+    if (c.uniform_k) { ib = (uint64_t)v * c.uniform_k; k = c.uniform_k; }
+    else { ib = c.indptr[v]; k = (uint32_t)(c.indptr[v + 1] - ib); }
+    const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
+    uint32_t planned = 0;   // slots already used by previous 64-edge chunks (k > 64)
+    // slot-major layout: entry (slot, node) at ((slot * nodes) + node) * 2, so that the 64 nodes of an apply
+    // wave read 2 KB contiguous per slot
+    const uint64_t nodes_owned = c.node_hi - c.node_lo;
+    uint4* my_plan = reinterpret_cast<uint4*>(a.plan) + (uint64_t)(v - c.node_lo) * 2;
+    for (uint32_t e0 = 0; e0 < k; e0 += 64) {
+        const uint32_t m = e0 + lane;
+        uint32_t cm = 0, nb = 0xFFFFFFFFu;
+        float pm = 0.f;
+        if (m < k) {
+            nb = c.nbr[ib + m];
+            pm = c.proba[ib + m];
+            cm = edge_count(ib + m, a.round_key, c.seed, a.unit * pm);
+            a.cnt[ib + m] = (uint8_t)cm;
+        }
+        // inclusive scan of the counts over the wave
+        uint32_t pre = cm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(pre, off);
+            if (lane >= off) pre += o;
+        }
+        const uint32_t chunk_total = __shfl(pre, 63);
+        // 64-bit signature of the row chunk for a cheap "certainly not a neighbour" test
+        unsigned long long sig = (m < k) ? (1ull << (nb & 63u)) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sig |= __shfl_xor(sig, off);
+        for (uint32_t t0 = 0; t0 < chunk_total; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            // edge of sample t: first lane whose inclusive prefix exceeds t (wave-uniform loop over <= 64 lanes)
+            uint32_t my_edge_lane = 0;
+            const uint32_t kk = (k - e0) < 64u ? (k - e0) : 64u;
+            for (uint32_t l = 0; l < kk; l++) {
+                const uint32_t pl = __shfl(pre, (int)l);
+                if (pl <= t) my_edge_lane = l + 1;
+            }
+            const bool active = t < chunk_total;
+            const uint32_t j = __shfl(nb, (int)(my_edge_lane < 64u ? my_edge_lane : 63u));
+            const float wj = __shfl(pm, (int)(my_edge_lane < 64u ? my_edge_lane : 63u));
+            uint32_t kn[5];
+            const uint32_t sbase = node_base + (planned + t) * 64u;
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+                uint32_t cand = 0;
+                for (uint32_t attempt = 0; attempt < 12u; attempt++) {
+                    const uint32_t w0 = pcg_hash(sbase + (uint32_t)g * 12u + attempt);
+                    if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
+                        const uint32_t x = __umulhi(w0, (uint32_t)c.n);
+                        const float u = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                        cand = (u < c.hub_odds[x]) ? x : c.hub_alias[x];
+                    } else {
+                        cand = __umulhi(w0, (uint32_t)c.n);  // :1121
+                    }
+                    bool reject = (cand == v) || (cand == j);
+                    // NodeParam::get_edge (nodeparam.rs:83-85): exact row scan only when the signature hits.
+                    // (rows longer than 64 are checked chunk by chunk against the current chunk only; the
+                    // remaining k/N-probability event is accepted there)
+                    const bool maybe = (sig >> (cand & 63u)) & 1ull;
+                    if (__any(active && !reject && maybe)) {
+                        for (uint32_t l = 0; l < kk; l++) {
+                            const uint32_t nl = __shfl(nb, (int)l);
+                            if (nl == cand) reject = true;
+                        }
+                    }
+                    if (!reject) break;
+                }
+                kn[g] = cand;
+            }
+            const uint32_t slot = planned + t;
+            if (active) {
+                if (slot < a.cap) {
+                    my_plan[(uint64_t)slot * nodes_owned * 2] = make_uint4(j, kn[0], kn[1], kn[2]);
+                    my_plan[(uint64_t)slot * nodes_owned * 2 + 1] = make_uint4(kn[3], kn[4], __float_as_uint(wj), 0u);
+                } else {
+                    atomicOr(a.overflow, 2u);
+                }
+            }
+        }
+        planned += chunk_total;
+    }
+    if (lane == 0) a.tot[v - c.node_lo] = planned < a.cap ? planned : a.cap;
+}
+
+// counts of the edges whose source is NOT owned by this shard (multi-GPU): needed to replay remote pushes
+__global__ void __launch_bounds__(kBlock) ce_count_remote_kernel(NodeArgs a) {
+    const CeDev c = a.c;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < c.nnz; e += stride) {
+        if (e >= c.edge_lo && e < c.edge_lo + c.shard_edges) continue;
+        a.cnt[e] = (uint8_t)edge_count(e, a.round_key, c.seed, a.unit * c.proba[e]);
+    }
+}
+
+// ---- K_apply: thread v owns y_v and replays its planned out-samples, then the pushes of its in-edges.
+template <int DIM, bool B1>
+__device__ __forceinline__ void attract(float* yv, const float* yo, float w, float inv_s2, float step, float b, float sign) {
+    // y_i half (sign = -1: y_i -= g) or y_j half (sign = +1: y_j += g) of embedder.rs:1207-1239, g = (y_j - y_i) * c
+    float d = 0.f;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) { const float df = yv[t] - yo[t]; d += df * df; }
+    const float delta = d * inv_s2;
+    if (delta > 0.f) {
+        const float coeff = grad_coeff_f32<B1>(delta, inv_s2, b);
+        const float rep = rcp(fmaxf(delta * delta, 1.0f / kProbaMin));
+        const float cij = fmaxf(step * coeff * (-w + (1.f - w) * rep), -0.49f);
+        // source side: y_i -= (y_j - y_i) c ; target side: y_j += (y_j - y_i) c  -- both are  y += (y - y_other) c
+#pragma unroll
+        for (int t = 0; t < DIM; t++) yv[t] += (yv[t] - yo[t]) * cij;
+    }
+    (void)sign;
+}
+
+template <int DIM>
+__device__ __forceinline__ void store_row_plain(float* __restrict__ y, uint32_t node, const float* in) {
+    float* p = y + (uint64_t)node * DIM;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) p[t] = in[t];
+}
+
+template <int DIM, bool B1>
+__global__ void __launch_bounds__(kApplyBlock) ce_apply_node_kernel(NodeArgs a) {
+    const CeDev c = a.c;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t v64 = c.node_lo + blockIdx.x * (uint64_t)kApplyBlock + threadIdx.x;
+    {   // samples drawn in this round: one atomic per workgroup (a per-wave atomic on one address costs ~12 ns each)
+        __shared__ unsigned int s_cnt;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        unsigned int mine = v64 < c.node_hi ? a.tot[v64 - c.node_lo] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(a.sample_counter, (unsigned long long)s_cnt);
+    }
+    if (v64 >= c.node_hi) return;
+    const uint32_t v = (uint32_t)v64;
+    float yv[DIM], grad[DIM];
+    load_row_fresh<DIM>(c.y, v, yv);
+#pragma unroll
+    for (int t = 0; t < DIM; t++) grad[t] = 0.f;
+    const float s_v = c.emb_scale[v];
+    const float inv_s2 = rcp(s_v * s_v);
+    uint64_t ib;
+    if (c.uniform_k) ib = (uint64_t)v * c.uniform_k; else ib = c.indptr[v];
+    // ---------------- (a) samples whose source is v ----------------
+    // Depth-PD software pipeline: the coordinate rows of sample t + PD are requested right after sample t is
+    // computed and BEFORE y_v is written back, so the in-order vmcnt wait of a later sample never queues
+    // behind the (slow, write-through) store of the sample just computed.
+    const uint32_t nv = a.tot[v - c.node_lo];
+    const uint64_t nodes_owned = c.node_hi - c.node_lo;
+    const uint4* my_plan = reinterpret_cast<const uint4*>(a.plan) + (uint64_t)(v - c.node_lo) * 2;
+    // Plan entries are staged through LDS in chunks of CH samples: an entry read is then an LDS read
+    // (lgkmcnt), so requesting the coordinate rows of a later sample never has to drain the vector-memory
+    // queue -- which holds the slow write-through stores of the samples just computed (vmcnt is in order).
+    constexpr int CH = 8;
+    constexpr int PD = DIM <= 4 ? 3 : (DIM <= 8 ? 2 : 1);
+    __shared__ uint4 s_ent[CH * 2 * kApplyBlock];
+    float rows[PD][6][DIM];
+    float wq[PD];
+    auto stage = [&](uint32_t t_begin) {  // global -> LDS, this lane's entries [t_begin, t_begin + CH)
+#pragma unroll
+        for (int q = 0; q < CH; q++) {
+            if (t_begin + (uint32_t)q < nv) {
+                s_ent[(q * 2) * kApplyBlock + tid] = my_plan[(uint64_t)(t_begin + q) * nodes_owned * 2];
+                s_ent[(q * 2 + 1) * kApplyBlock + tid] = my_plan[(uint64_t)(t_begin + q) * nodes_owned * 2 + 1];
+            }
+        }
+    };
+    auto fetch = [&](uint32_t t, int slot) {  // entry from LDS, rows from global
+        const uint32_t q = t % CH;
+        const uint4 p0 = s_ent[(q * 2) * kApplyBlock + tid], p1 = s_ent[(q * 2 + 1) * kApplyBlock + tid];
+        wq[slot] = __uint_as_float(p1.z);
+        load_row_fresh<DIM>(c.y, p0.x, rows[slot][0]);
+        load_row_fresh<DIM>(c.y, p0.y, rows[slot][1]);
+        load_row_fresh<DIM>(c.y, p0.z, rows[slot][2]);
+        load_row_fresh<DIM>(c.y, p0.w, rows[slot][3]);
+        load_row_fresh<DIM>(c.y, p1.x, rows[slot][4]);
+        load_row_fresh<DIM>(c.y, p1.y, rows[slot][5]);
+    };
+    // chunk c covers samples [c*CH, (c+1)*CH); the rows of sample t are requested PD samples ahead, so chunk
+    // boundaries are handled by staging the NEXT chunk as soon as the prefetch front reaches it.  To keep the
+    // code simple the prefetch depth does not cross a chunk: each chunk is prologue + steady state.
+    unsigned long long t_stage = 0, t_fetch = 0, t_comp = 0, t_store = 0, t_in = 0;
+    const unsigned long long t_begin_all = __builtin_amdgcn_s_memtime();
+    for (uint32_t c0 = 0; c0 < (a.skip == 1 ? 0u : nv); c0 += CH) {
+        unsigned long long ts = __builtin_amdgcn_s_memtime();
+        stage(c0);
+        __builtin_amdgcn_s_waitcnt(0);
+        t_stage += __builtin_amdgcn_s_memtime() - ts;
+        const uint32_t cend = (c0 + CH < nv) ? c0 + CH : nv;
+#pragma unroll
+        for (int u = 0; u < PD; u++)
+            if (c0 + (uint32_t)u < cend) fetch(c0 + (uint32_t)u, u);
+        for (uint32_t t0 = c0; t0 < cend; t0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; u++) {
+                const uint32_t t = t0 + (uint32_t)u;
+                if (t < cend) {
+                    const float w = wq[u];
+                    unsigned long long tc = __builtin_amdgcn_s_memtime();
+                    {   // attraction, the y_i half of :1207-1237 (gradient kept for the reference's stale-gradient quirk)
+                        float d = 0.f;
+#pragma unroll
+                        for (int q = 0; q < DIM; q++) { const float df = yv[q] - rows[u][0][q]; d += df * df; }
+                        const float delta = d * inv_s2;
+                        if (delta > 0.f) {
+                            const float coeff = grad_coeff_f32<B1>(delta, inv_s2, a.b);
+                            const float rep = rcp(fmaxf(delta * delta, 1.0f / kProbaMin));
+                            const float cij = fmaxf(a.step * coeff * (-w + (1.f - w) * rep), -0.49f);
+#pragma unroll
+                            for (int q = 0; q < DIM; q++) grad[q] = (rows[u][0][q] - yv[q]) * cij;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < DIM; q++) grad[q] = 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
+                    }
+#pragma unroll
+                    for (int g = 0; g < 5; g++) {  // 5 repulsions, :1267-1297
+                        float dk = 0.f;
+#pragma unroll
+                        for (int q = 0; q < DIM; q++) { const float df = yv[q] - rows[u][1 + g][q]; dk += df * df; }
+                        if (dk > 0.f) {
+                            const float dks = dk * inv_s2;
+                            const float coeff = grad_coeff_f32<B1>(dks, inv_s2, a.b);
+                            const float cik = fminf(a.step * coeff * rcp(fmaxf(dks * dks, 1.0f / 16.0f)), 2.0f);
+#pragma unroll
+                            for (int q = 0; q < DIM; q++) grad[q] = (rows[u][1 + g][q] - yv[q]) * cik;
+                        }  // else `gradient` keeps its previous value (reference quirk B4)
+#pragma unroll
+                        for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
+                    }
+                    unsigned long long tf = __builtin_amdgcn_s_memtime();
+                    t_comp += tf - tc;
+                    if (t + PD < cend) fetch(t + PD, u);  // refill this slot before the store below
+                    unsigned long long tst = __builtin_amdgcn_s_memtime();
+                    t_fetch += tst - tf;
+                    if (a.store_mode == 0) store_row_through<DIM>(c.y, v, yv);
+                    else if (a.store_mode == 1) store_row_plain<DIM>(c.y, v, yv);
+                    t_store += __builtin_amdgcn_s_memtime() - tst;
+                }
+            }
+        }
+    }
+    const unsigned long long t_in0 = __builtin_amdgcn_s_memtime();
+    if (a.store_mode == 2) store_row_through<DIM>(c.y, v, yv);
+    // ---------------- (b) samples whose target is v: the y_j half of :1238-1239 ----------------
+    // one-deep pipeline over the in-edges: record, count and source row of the next in-edge are requested
+    // before the pushes of the current one are applied and stored
+    const uint64_t tb = a.tptr[v], te = a.tptr[v + 1];
+    if (tb < te && a.skip != 2) {
+        InEdge rec = a.tin[tb];
+        uint32_t cnt = a.cnt[rec.eid];
+        float yu[DIM];
+        load_row_fresh<DIM>(c.y, rec.src, yu);
+        for (uint64_t x = tb; x < te; x++) {
+            InEdge nrec = rec;
+            uint32_t ncnt = 0;
+            float nyu[DIM];
+#pragma unroll
+            for (int q = 0; q < DIM; q++) nyu[q] = 0.f;
+            if (x + 1 < te) {
+                nrec = a.tin[x + 1];
+                ncnt = a.cnt[nrec.eid];
+                load_row_fresh<DIM>(c.y, nrec.src, nyu);
+            }
+            if (cnt) {
+                const float inv_su2 = rcp(rec.s_src * rec.s_src);
+                for (uint32_t r = 0; r < cnt; r++) {
+                    if (r > 0) load_row_fresh<DIM>(c.y, rec.src, yu);  // repeated sample of the edge: refresh the source
+                    attract<DIM, B1>(yv, yu, rec.w, inv_su2, a.step, a.b, 1.f);
+                    if (a.store_mode == 0) store_row_through<DIM>(c.y, v, yv);
+                    else if (a.store_mode == 1) store_row_plain<DIM>(c.y, v, yv);
+                }
+            }
+            rec = nrec;
+            cnt = ncnt;
+#pragma unroll
+            for (int q = 0; q < DIM; q++) yu[q] = nyu[q];
+        }
+    }
+    if (a.store_mode == 2) store_row_through<DIM>(c.y, v, yv);
+    if (a.prof && tid == 0) {
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        t_in = tend - t_in0;
+        atomicAdd(&a.prof[0], t_stage); atomicAdd(&a.prof[1], t_fetch); atomicAdd(&a.prof[2], t_comp);
+        atomicAdd(&a.prof[3], t_store); atomicAdd(&a.prof[4], t_in); atomicAdd(&a.prof[5], tend - t_begin_all);
+        atomicAdd(&a.prof[6], 1ull);
+    }
+}
+
+__global__ void in_edge_keys_kernel(uint64_t n, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ nbr,
+                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ payload) {
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (uint64_t e = indptr[i]; e < indptr[i + 1]; e++) {
+        keys[e] = ((uint64_t)nbr[e] << 32) | i;  // (target, source)
+        payload[e] = (uint32_t)e;
+    }
+}
+__global__ void in_edge_fill_kernel(uint64_t nnz, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                    const float* __restrict__ proba, const float* __restrict__ emb_scale, InEdge* __restrict__ tin) {
+    uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (x >= nnz) return;
+    InEdge r;
+    r.src = (uint32_t)(keys[x] & 0xFFFFFFFFull);
+    r.eid = perm[x];
+    r.w = proba[r.eid];
+    r.s_src = emb_scale[r.src];
+    tin[x] = r;
+}
+
+template <int DIM>
+void launch_apply(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
+    if constexpr (DIM > 0) {
+        if (a.b == 1.0f) hipLaunchKernelGGL((ce_apply_node_kernel<DIM, true>), dim3(blocks_for(nodes, kApplyBlock)), dim3(kApplyBlock), 0, stream(), a);
+        else hipLaunchKernelGGL((ce_apply_node_kernel<DIM, false>), dim3(blocks_for(nodes, kApplyBlock)), dim3(kApplyBlock), 0, stream(), a);
+    }
+}
+
+}  // namespace
+
+namespace ae {
+
+bool ce_node_supports_dim(uint32_t dim) { return dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16; }
+
+// transposed graph (in-edges with w and the source's embedded scale), once per EntropyOptim
+void ce_node_build_transpose(ae_entropy_optim* o) {
+    const ae_kgraph* g = o->g;
+    if (g->nnz >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "graph too large for u32 edge ids");
+    DevBuf<uint64_t> k0(g->nnz), k1(g->nnz);
+    DevBuf<uint32_t> p0(g->nnz), p1(g->nnz);
+    hipLaunchKernelGGL(in_edge_keys_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), g->n, g->indptr.p, g->nbr.p, k0.p, p0.p);
+    check_launch("in_edge_keys");
+    sort_pairs_u64_u32(k0.p, k1.p, p0.p, p1.p, g->nnz);
+    o->tin.alloc(g->nnz);
+    hipLaunchKernelGGL(in_edge_fill_kernel, dim3(blocks_for(g->nnz, 256)), dim3(256), 0, stream(), g->nnz, k1.p, p1.p, o->np->proba.p,
+                       o->emb_scale.p, o->tin.p);
+    check_launch("in_edge_fill");
+    o->tptr.alloc(g->n + 1);
+    rowptr_from_sorted_keys(k1.p, g->nnz, g->n, o->tptr.p);
+    o->sample_counter.alloc(1);
+    o->sample_counter.zero();
+    sync();
+}
+
+void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
+    const uint64_t nodes = o->dev.node_hi - o->dev.node_lo;
+    const double per_node = (double)nb_sample / (double)nodes;  // expected samples per source node in the batch
+    // rounds: keep the largest per-edge Poisson mean (p_e <= 1) below 30 so that exp(-mu) stays normal in f32
+    const uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / 30.0));
+    o->rounds = rounds;
+    if (iter >= (1u << 20) || rounds >= (1u << 10)) fail(AE_ERR_INVALID_ARG, "iteration / round index too large for the RNG key");
+    const double per_round = per_node / (double)rounds;
+    // plan capacity per node and round: Poisson(per_round) exceeds mean + 8 sigma + 8 with probability < 1e-14
+    const uint32_t cap = (uint32_t)std::ceil(per_round + 8.0 * std::sqrt(per_round) + 8.0);
+    if (o->plan.n < nodes * (uint64_t)cap * 8) o->plan.alloc(nodes * (uint64_t)cap * 8);
+    if (o->tot.n < nodes) o->tot.alloc(nodes);
+    if (o->cnt.n < o->dev.nnz) { o->cnt.alloc(o->dev.nnz); o->cnt.zero(); }
+    NodeArgs a;
+    a.c = o->dev;
+    a.tptr = o->tptr.p;
+    a.tin = o->tin.p;
+    a.cnt = o->cnt.p;
+    a.tot = o->tot.p;
+    a.plan = o->plan.p;
+    a.cap = cap;
+    a.step = (float)grad_step;
+    a.unit = (float)per_round;
+    a.b = (float)o->dev.b;
+    a.sample_counter = o->sample_counter.p;
+    a.overflow = o->err.p;
+    static DevBuf<unsigned long long> prof_buf;
+    a.prof = nullptr;
+    if (getenv("AE_CE_PROF")) {
+        if (!prof_buf.n) { prof_buf.alloc(8); prof_buf.zero(); }
+        a.prof = prof_buf.p;
+    }
+    a.skip = getenv("AE_CE_SKIP") ? atoi(getenv("AE_CE_SKIP")) : 0;
+    a.store_mode = getenv("AE_CE_STORE") ? atoi(getenv("AE_CE_STORE")) : 0;
+    const bool sharded = o->dev.shard_edges != o->dev.nnz;
+    for (uint32_t r = 0; r < rounds; r++) {
+        a.round_key = (iter << 10) | r;
+        const unsigned plan_grid = blocks_for(nodes * 64, kBlock);
+        if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
+        else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
+        if (sharded) hipLaunchKernelGGL(ce_count_remote_kernel, dim3(grid_cap(o->dev.nnz, kBlock)), dim3(kBlock), 0, stream(), a);
+        AE_DISPATCH_DIM(o->dev.dim, launch_apply, o, a, nodes);
+    }
+    check_launch("ce_node");
+    if (a.prof) {
+        unsigned long long h[8];
+        prof_buf.download(h, 8);
+        if (h[6]) fprintf(stderr, "CEPROF waves=%llu per-wave cycles: stage %.0f fetch %.0f compute %.0f store %.0f in-phase %.0f total %.0f\n", h[6],
+                          (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+        prof_buf.zero();
+    }
+}
+
+}  // namespace ae

@@ -1,0 +1,110 @@
+"""Multi-GPU driver of the CE loop: one process per GPU, points sharded by source node, coordinates
+replicated and all-gathered (RCCL over xGMI through torch.distributed) once per CE batch.
+
+No reference counterpart (the reference is single-process, shared-memory rayon).  Semantics:
+  * rank r owns source nodes [lo_r, hi_r): it draws positive edges only from its own rows
+    (sum_j p_ij = 1 for every node, so equal node counts carry equal edge mass) and runs
+    nb_sampling_by_edge * nnz_r samples per batch;
+  * negatives are drawn over all N nodes from the local replica of Y;
+  * updates of a remote y_j are applied to the local replica only and overwritten by the owner's row
+    at the per-batch all-gather (hard part 4).
+The compute backend is an object with `gradient_iteration(nb_sample, grad_step, it)`; on the GPU it
+is annembed_amd.EntropyOptim (HIP), in the CPU tests it is the oracle (gloo).
+"""
+import numpy as np
+
+
+def shard_range(n, world, rank):
+    """contiguous node range of `rank`: equal sizes, the remainder spread over the first ranks"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def sample_offset(node_lo):
+    """first sample id of the shard's RNG streams (ae_entropy_optim_create: node_lo << 24)"""
+    return int(node_lo) << 24
+
+
+def shard_sizes(n, world):
+    return [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
+
+
+class ShardedCE:
+    """Per-batch protocol: local gradient iteration, then all-gather of the owned rows."""
+
+    def __init__(self, backend, y_tensor, n, dim, rank, world, group=None, pre_gather=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend, self.y, self.n, self.dim = backend, y_tensor, n, dim
+        self.rank, self.world, self.group = rank, world, group
+        self.lo, self.hi = shard_range(n, world, rank)
+        self.pre_gather = pre_gather
+        sizes = shard_sizes(n, world)
+        self.equal = len(set(sizes)) == 1
+        self.sizes = sizes
+
+    def step(self, nb_sample, grad_step, it):
+        self.backend.gradient_iteration(nb_sample, grad_step, it)
+        self.all_gather()
+
+    def all_gather(self):
+        if self.world == 1:
+            return
+        if self.pre_gather is not None:
+            self.pre_gather()
+        own = self.y[self.lo:self.hi].clone()
+        if self.equal:
+            self.dist.all_gather_into_tensor(self.y, own, group=self.group)
+        else:
+            import torch
+            parts = [torch.empty((s, self.dim), dtype=self.y.dtype, device=self.y.device) for s in self.sizes]
+            self.dist.all_gather(parts, own, group=self.group)
+            off = 0
+            for p in parts:
+                self.y[off:off + p.shape[0]].copy_(p)
+                off += p.shape[0]
+
+    def all_reduce_sum(self, value):
+        """sum of per-shard partial CE values (f64)"""
+        if self.world == 1:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device=self.y.device)
+        self.dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+
+def device_tensor(entropy_optim):
+    """torch view (no copy) of the library's n x dim device coordinate array"""
+    import torch
+    ptr, n, d = entropy_optim.device_coords()
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (n, d), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Arr(), device="cuda")
+
+
+class HipBackend:
+    def __init__(self, entropy_optim):
+        self.eo = entropy_optim
+
+    def gradient_iteration(self, nb_sample, grad_step, it):
+        self.eo.gradient_iteration_threaded(nb_sample, grad_step, it)
+
+
+def emulate_sharded_batch(make_backend, y, n, world, nb_samples, grad_step, it):
+    """Single-process emulation of one sharded batch (test helper): every rank starts from the same
+    replica `y`, runs its shard, and the owners' rows are merged."""
+    outs = []
+    for r in range(world):
+        lo, hi = shard_range(n, world, r)
+        yr = np.array(y, copy=True)
+        be = make_backend(r, lo, hi, yr)
+        be.gradient_iteration(nb_samples[r], grad_step, it)
+        outs.append((lo, hi, be.current()))
+    merged = np.array(y, copy=True)
+    for lo, hi, yr in outs:
+        merged[lo:hi] = yr[lo:hi]
+    return merged

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the annembed hot path on MI355X.
+
+Metric (BASELINE.json): embedded points/sec per CE epoch (one `gradient_iteration` batch over
+nb_sampling_by_edge * nnz SGD samples), plus the SVD-init GFLOP/s of the diffusion-map initialisation.
+
+Workload at N=1: configs[1] "MNIST-fashion 60k x 784 -> 2D, k=12, dmap init + CE loop, fp32"
+(parameters of examples/mnist_fashion.rs:92-110).  The real dataset is absent (no network): a
+synthetic Gaussian mixture of the same shape stands in and the exact kNN graph is built
+on the GPU before the timed region.  N>1: weak scaling -- every rank owns 60k source nodes of an
+N*60k point graph, coordinates are replicated and all-gathered (RCCL) once per CE batch.
+
+A "step" = one CE batch.  The timed region holds only `ae_entropy_optim_gradient_iteration` launches
+(+ the per-batch all-gather when N>1) with every input already resident in HBM.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synth_points(n, dim, seed, ncomp=10, active=50, idim=18, sigma=30.0, device="cuda"):
+    """MNIST-shaped stand-in: mixture of `ncomp` components in [0,255]^dim; component means are
+    U(0,255) on `active` random coordinates; inside a component the points live on a random `idim`-dimensional
+    subspace (sigma 30) -- idim = 18 is the intrinsic dimension the reference measures on MNIST (README.md:102),
+    which gives the kNN graph a realistic in-degree (hubness) profile instead of that of a 784-d isotropic blob."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    means = torch.zeros(ncomp, dim)
+    for c in range(ncomp):
+        idx = torch.randperm(dim, generator=g)[:active]
+        means[c, idx] = torch.rand(active, generator=g) * 255.0
+    lab = torch.randint(0, ncomp, (n,), generator=g)
+    x = torch.empty(n, dim)
+    for c in range(ncomp):
+        basis = torch.linalg.qr(torch.randn(dim, idim, generator=g))[0]
+        m = lab == c
+        x[m] = means[c] + (sigma * torch.randn(int(m.sum()), idim, generator=g)) @ basis.T
+    return x.clamp_(0, 255).to(device)
+
+
+def knn_rows(x_all, lo, hi, k):
+    """exact L2 kNN of rows [lo,hi) against all rows (torch, input preparation only)"""
+    import torch
+    sq = (x_all * x_all).sum(1)
+    nbr = torch.empty((hi - lo, k), dtype=torch.int64, device=x_all.device)
+    dist = torch.empty((hi - lo, k), dtype=torch.float32, device=x_all.device)
+    bs = 4096
+    for b in range(lo, hi, bs):
+        e = min(b + bs, hi)
+        d2 = sq[b:e, None] + sq[None, :] - 2.0 * (x_all[b:e] @ x_all.T)
+        d2[torch.arange(e - b, device=x_all.device), torch.arange(b, e, device=x_all.device)] = float("inf")
+        v, i = torch.topk(d2, k, dim=1, largest=False, sorted=True)
+        nbr[b - lo:e - lo] = i
+        dist[b - lo:e - lo] = v.clamp_min(0).sqrt()
+    return nbr, dist
+
+
+def svd_flops(n, nnz_a, l=20, nbiter=5):
+    """algorithmic flops of subspace_iteration_csr + direct_svd"""
+    return ((2 * nbiter - 1) * 2 * nnz_a * l + (2 * nbiter - 1) * 4 * n * l * l + 2 * nnz_a * l + 6 * n * l * l
+            + 2 * n * l * l)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points-per-gpu", type=int, default=60000)
+    ap.add_argument("--dim", type=int, default=784)
+    ap.add_argument("--knbn", type=int, default=12)
+    ap.add_argument("--asked-dim", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import annembed_amd as A
+    from annembed_amd import _lib as L
+    L.check(L.load().ae_set_device(local_rank))
+
+    ppg, k, d = args.points_per_gpu, args.knbn, args.asked_dim
+    n = ppg * world
+    lo, hi = rank * ppg, (rank + 1) * ppg
+
+    # ---------------- input preparation (untimed) ----------------
+    x = synth_points(n, args.dim, seed=1)
+    nbr_l, dist_l = knn_rows(x, lo, hi, k)
+    if world > 1:
+        nbr_all = torch.empty((n, k), dtype=torch.int64, device=x.device)
+        dist_all = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        dist.all_gather_into_tensor(nbr_all, nbr_l)
+        dist.all_gather_into_tensor(dist_all, dist_l)
+    else:
+        nbr_all, dist_all = nbr_l, dist_l
+    del x
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
+    dst = dist_all.cpu().numpy().reshape(-1)
+    del nbr_all, dist_all, nbr_l, dist_l
+    torch.cuda.empty_cache()
+    kg = A.KGraph(indptr, nbr, dst, k)
+
+    # ---------------- dmap initialisation (timed separately: SVD-init GFLOP/s) ----------------
+    dp = A.DiffusionParams(d, 5.0, 12)  # src/embedder.rs:317-321
+    lap = A.DiffusionMaps(dp).laplacian_from_kgraph(kg)
+    _, _, nnz_a = lap.info()
+    L.check(L.load().ae_synchronize())
+    lap.do_svd()  # warm
+    t0 = time.perf_counter()
+    lap.do_svd()
+    svd_s = time.perf_counter() - t0
+    y0 = A.DiffusionMaps(dp).embed_from_kgraph(kg)
+    y0 = A.set_data_box(y0, 10.0)
+    node_params = A.to_proba_edges(kg, 1.0, 1.0)
+
+    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0)
+    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi)
+    nnz_shard = eo.get_nb_edges()
+    nb_sample = params.nb_sampling_by_edge * nnz_shard
+    nb_batch = max(params.nb_grad_batch, args.warmup + args.steps + 1)
+    ce_before = eo.ce_compute_threaded()
+
+    y_all = None
+    if world > 1:
+        ptr, nn, dd = eo.device_coords()
+
+        class _Arr:  # wraps the library's device buffer as a torch tensor (no copy)
+            __cuda_array_interface__ = {"shape": (nn, dd), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        y_all = torch.as_tensor(_Arr(), device="cuda")
+
+    def one_step(it):
+        eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / nb_batch), it)
+        if world > 1:
+            L.check(L.load().ae_synchronize())  # library stream -> torch stream hand-off
+            dist.all_gather_into_tensor(y_all, y_all[lo:hi].clone())
+            torch.cuda.current_stream().synchronize()  # the next batch reads the gathered replica
+
+    def fence():
+        L.check(L.load().ae_synchronize())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        it += 1
+        one_step(it)
+    fence()
+    eo.kernel_time()  # reset the event accumulators
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it += 1
+        one_step(it)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eo.kernel_time()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ce_after = eo.ce_compute_threaded()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        points_per_s = n * args.steps / elapsed
+        bytes_per_sample = 24 + 4 * k + 36 * d  # SURVEY 8d / DESIGN.md
+        achieved = bytes_per_sample * nb_sample / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "embedded_points_per_sec_ce_epoch",
+            "value": points_per_s,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1]); %d points per GPU"
+                            % (n, args.dim, d, k, ppg),
+                "nb_sampling_by_edge": 10, "samples_per_step": int(nb_sample * world), "sampler": "rowcdf", "ce_mode": "hogwild",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": None, "kernel": "ce_plan_node_kernel + ce_apply_node_kernel (one CE batch = `rounds` x 2 launches)", "kernel_avg_ms": kernel_ms, "launches": int(launches),
+                "bytes_per_sample": bytes_per_sample,
+            },
+            "svd_init": {
+                "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
+            },
+            "samples_per_s": nb_sample * world * args.steps / elapsed,
+            "ce_before": ce_before, "ce_after": ce_after,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch):
+    """The CPU restatement of the reference's Hogwild loop (oracle, kind "port") on the host cores,
+    on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    proba, scale = node_params.get()
+    eo = O.EntropyOptim(indptr, nbr, proba, scale, y0, b=params.b, seed=params.seed, sampler=0)
+    nb_sample = params.nb_sampling_by_edge * len(nbr)
+    cores = O.max_threads()
+    eo.gradient_iteration_hogwild(nb_sample // 8, 1.0, 1, 0)  # warm the thread pool
+    batches = 0
+    t0 = time.perf_counter()
+    while True:
+        batches += 1
+        eo.gradient_iteration_hogwild(nb_sample, params.grad_step * (1.0 - batches / nb_batch), batches + 1, 0)
+        el = time.perf_counter() - t0
+        if el > 10.0 or batches >= 8:
+            break
+    return {
+        "value": n * batches / el, "unit": "points/s", "cores": int(cores), "kind": "port",
+        "sample": "%d CE batches (%d SGD samples each) of the same graph, OpenMP Hogwild restatement of "
+                  "src/embedder.rs:1311-1315 on all host cores" % (batches, nb_sample),
+        "samples_per_s": nb_sample * batches / el,
+    }
+
+
+if __name__ == "__main__":
+    main()

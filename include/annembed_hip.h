@@ -85,13 +85,21 @@ typedef struct ae_embedder_params {
 } ae_embedder_params;
 
 enum {
-    /* Lock-free in-place updates, as the reference's rayon loop (src/embedder.rs:1311-1315,
-       "Hogwild" comment :1197).  Fast path; not reproducible run to run (neither is the reference). */
+    /* Lock-free asynchronous updates, the counterpart of the reference's rayon loop
+       (src/embedder.rs:1311-1315, "Hogwild" comment :1197), restructured owner-computes: thread v owns
+       y_v and replays the samples whose source or target is v; per-edge sample counts are Poisson with
+       the means of the reference's i.i.d. edge draw.  Fast path; f32 arithmetic; the schedule is not
+       reproducible run to run (neither is the reference's).  Dimensions 2,3,4,8,16; other dimensions
+       fall back to AE_CE_SAMPLE_RACY. */
     AE_CE_HOGWILD = 0,
     /* Deterministic: executes exactly the sequential order sample 0,1,2,... of the reference's
        `gradient_iteration` (src/embedder.rs:1305-1309) through a conflict-free level schedule.
        Bit-exact against the CPU oracle; slow; meant for parity tests. */
-    AE_CE_SEQUENTIAL = 1
+    AE_CE_SEQUENTIAL = 1,
+    /* One thread per sample with racy read-modify-write of both end points, the literal transcription
+       of the rayon loop.  Kept for comparison only: on a GPU with more lanes than nodes most updates are
+       lost, it is NOT statistically equivalent to the reference at small N. */
+    AE_CE_SAMPLE_RACY = 2
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
@@ -285,6 +293,9 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim *o, uint64_t nb_sam
    accepted negatives :1241-1253) and the edge probability w.  Deterministic given graph + seed. */
 int32_t ae_entropy_optim_plan(ae_entropy_optim *o, uint64_t s_begin, uint64_t count, uint64_t iter,
                               uint32_t *nodes7, float *w);
+/* Hogwild mode draws a Poisson(nb_sample) number of samples per batch: total drawn so far, and the
+   number of kernel launches (rounds) the last batch was split into. */
+int32_t ae_entropy_optim_samples_drawn(ae_entropy_optim *o, uint64_t *samples, uint32_t *rounds);
 /* embedded scales (embedder.rs:1356-1373), n entries */
 int32_t ae_entropy_optim_get_scales(const ae_entropy_optim *o, float *emb_scale);
 /* current coordinates, n x dim row-major */

@@ -1,0 +1,474 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(annembed_amd.api is a ctypes veneer over include/annembed_hip.h), against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE sizes -- through size-independent
+properties.  Bars: bit-exact for index / integer work and for the b = 1 SGD arithmetic in sequential
+mode; floating-point stages within the tolerance written next to each assert."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import gaussian_mixture, knn_graph, synthetic_graph
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="module")
+def A():
+    import annembed_amd as A
+    from annembed_amd import _lib
+    lib = _lib.load()  # raises if the HIP extension is missing: no silent fallback
+    import ctypes
+    cnt = ctypes.c_int32()
+    _lib.check(lib.ae_device_count(ctypes.byref(cnt)))
+    assert cnt.value >= 1, "no GPU visible"
+    return A
+
+
+@pytest.fixture(scope="module")
+def graph():  # connected (single blob) 2500-node graph, k = 8
+    indptr, nbr, dist, x, _ = synthetic_graph(n=2500, dim=6, k=8, seed=21, ncomp=1)
+    return indptr, nbr, dist, x
+
+
+def _relmax(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 KGraph
+# ------------------------------------------------------------------------------------------------
+def test_kgraph_roundtrip_and_validation(A, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    assert g.get_nb_nodes() == 2500 and g.get_max_nbng() == 8 and g.get_nb_edges() == len(nbr)
+    ip, nb, ds = g.get_neighbours()
+    assert np.array_equal(ip, indptr) and np.array_equal(nb, nbr) and np.array_equal(ds, dist)
+    bad = dist.copy()
+    bad[0], bad[1] = bad[1] + 1, bad[0]  # row 0 no longer sorted (kgraph.rs:508-509 invariant)
+    with pytest.raises(A.AnnembedError) as e:
+        A.KGraph(indptr, nbr, bad)
+    assert e.value.code == 1
+    ip2 = indptr.copy()
+    ip2[1:] -= 8
+    ip2[1] = 0  # node 0 has no neighbour -> kgraph.rs:520-537
+    with pytest.raises(A.AnnembedError) as e:
+        A.KGraph(ip2, nbr[8:], dist[8:])
+    assert e.value.code == 3
+    nb2 = nbr.copy()
+    nb2[5] = 2500
+    with pytest.raises(A.AnnembedError):
+        A.KGraph(indptr, nb2, dist)
+
+
+def test_kgraph_from_ragged_bit_exact(A, oracle):
+    rng = np.random.default_rng(3)
+    n, nbng = 700, 6
+    ids = rng.permutation(5000)[:n].astype(np.uint64)  # non contiguous DataIds
+    order = rng.permutation(n)
+    rows, ptr = [], [0]
+    for p in order:
+        m = int(rng.integers(3, 14))  # several layers concatenated, duplicates allowed
+        cand = rng.choice(np.delete(np.arange(n), p), size=m, replace=True)
+        rows.append(cand)
+        ptr.append(ptr[-1] + m)
+    nbr_id = ids[np.concatenate(rows)]
+    nbr_d = rng.integers(1, 50, size=ptr[-1]).astype(np.float32) * 0.25  # many ties
+    rc, (oip, onb, ods, oids) = oracle.kgraph_from_ragged(ids[order], np.array(ptr, np.uint64), nbr_id, nbr_d, nbng)
+    assert rc == 0
+    g = A.KGraph.from_ragged(ids[order], np.array(ptr, np.uint64), nbr_id, nbr_d, nbng)
+    ip, nb, ds = g.get_neighbours()
+    assert np.array_equal(g.data_ids, oids)
+    assert np.array_equal(ip, oip) and np.array_equal(nb, onb) and np.array_equal(ds, ods)
+    # isolated point -> Err (kgraph.rs:520-537)
+    ptr2 = np.array(ptr, np.uint64)
+    ptr2[1:] -= ptr2[1]
+    with pytest.raises(A.AnnembedError) as e:
+        A.KGraph.from_ragged(ids[order], ptr2, nbr_id[ptr[1]:], nbr_d[ptr[1]:], nbng)
+    assert e.value.code == 3
+
+
+def test_hubness_bit_exact(A, graph, oracle):
+    indptr, nbr, dist, _ = graph
+    assert np.array_equal(A.KGraph(indptr, nbr, dist).hubness(), oracle.hubness(indptr, nbr))
+
+
+def test_distance_batching_and_bruteforce(A):
+    x, _ = gaussian_mixture(1200, 24, 3, seed=5)
+    indptr, nbr, dist = knn_graph(x, 7)
+    g = A.KGraph(indptr, nbr, np.sort(np.abs(np.random.default_rng(0).normal(size=(1200, 7))).astype(np.float32), axis=1).reshape(-1))
+    g.fill_l2_distances(x)  # recompute ||x_i - x_j|| on device and re-sort the rows
+    ip, nb, ds = g.get_neighbours()
+    assert np.array_equal(nb, nbr)
+    assert np.allclose(ds, dist, rtol=2e-6, atol=1e-6)
+    gb = A.KGraph.bruteforce_l2(x, 7)
+    ip, nb, ds = gb.get_neighbours()
+    assert np.allclose(ds, dist, rtol=1e-5, atol=1e-5)
+    assert (nb == nbr).mean() > 0.999  # ties may be ordered differently
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 to_proba_edges
+# ------------------------------------------------------------------------------------------------
+def test_to_proba_edges_golden_and_oracle(A, graph, oracle):
+    g = A.KGraph(GOLD["g_indptr"], GOLD["g_nbr"], GOLD["g_dist"])
+    p, s = A.to_proba_edges(g, 1.0, 1.0).get()
+    assert np.array_equal(s, GOLD["scale"])  # +,/ only: bit exact
+    assert _relmax(p, GOLD["proba"]) < 2e-6  # expf/powf ulps
+    p, s = A.to_proba_edges(g, 0.75, 2.0).get()
+    assert np.array_equal(s, GOLD["scale_rho075_beta2"]) and _relmax(p, GOLD["proba_rho075_beta2"]) < 2e-6
+    indptr, nbr, dist, _ = graph
+    np_ = A.to_proba_edges(A.KGraph(indptr, nbr, dist), 1.0, 1.0)
+    p, s = np_.get()
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    assert rc == 0 and np.array_equal(s, s0) and _relmax(p, p0) < 2e-6
+    assert np.allclose(p.reshape(-1, 8).sum(1), 1.0, atol=1e-5)
+    assert _relmax(np_.get_perplexity(), oracle.perplexity(indptr, p0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# a10-a13 EntropyOptim
+# ------------------------------------------------------------------------------------------------
+def _ce_pair(A, oracle, graph, dim, **kw):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    y0 = oracle.set_data_box(np.random.default_rng(dim).normal(size=(len(indptr) - 1, dim)).astype(np.float32), 10.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    hub = g.hubness() if kw.get("hubness_weighting") else None
+    par = A.EmbedderParams(asked_dim=dim, **kw)
+    eo = A.EntropyOptim(g, npar, par, y0, hub_counts=hub)
+    oo = oracle.EntropyOptim(indptr, nbr, p0, s0, y0, b=par.b, seed=par.seed, sampler=par.ce_sampler, hub_counts=hub)
+    return eo, oo, (g, npar)
+
+
+def test_set_data_box_bit_exact(A, oracle):
+    y = np.random.default_rng(1).normal(size=(4000, 3)).astype(np.float32) * 7 + 2
+    assert np.array_equal(A.set_data_box(y, 10.0), oracle.set_data_box(y, 10.0))
+    assert np.array_equal(A.set_data_box(GOLD["y_raw"], 10.0), GOLD["y_raw_box"])
+
+
+def test_embedded_scales_and_ce_value(A, oracle, graph):
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2)
+    assert np.array_equal(eo.get_embedded_scales(), oo.emb_scale)  # f32 sequential mean: bit exact
+    assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()  # f64, summation order differs
+    g = A.KGraph(GOLD["g_indptr"], GOLD["g_nbr"], GOLD["g_dist"])
+    e2 = A.EntropyOptim(g, A.NodeParams.from_host(g, GOLD["proba"], GOLD["scale"]), A.EmbedderParams(), GOLD["y_box"])
+    assert np.array_equal(e2.get_embedded_scales(), GOLD["emb_scale"])
+    assert abs(e2.ce_compute_threaded() - float(GOLD["ce_value"])) < 1e-11 * float(GOLD["ce_value"])
+
+
+@pytest.mark.parametrize("sampler,hub", [(0, False), (1, False), (0, True), (1, True)])
+def test_sample_plan_bit_exact(A, oracle, graph, sampler, hub):
+    """RNG + sampling (index work): nodes of every sample identical to the oracle's"""
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_sampler=sampler, hubness_weighting=hub)
+    nodes, w = eo.plan(0, 3000, 4)
+    ref = np.array([oo.plan(s, 4)[0] for s in range(3000)])
+    refw = np.array([oo.plan(s, 4)[1] for s in range(3000)], np.float32)
+    assert np.array_equal(nodes, ref) and np.array_equal(w, refw)
+
+
+@pytest.mark.parametrize("dim", [2, 3, 4, 5, 8, 16])
+def test_sequential_sgd_bit_exact(A, oracle, graph, dim):
+    """ce_optim_edge_shannon arithmetic (b = 1: +,-,*,/ only) executed in the sequential order through the
+    level schedule: coordinates bit-identical to the oracle after whole batches"""
+    eo, oo, _ = _ce_pair(A, oracle, graph, dim, ce_mode=1)
+    S = 10 * eo.get_nb_edges()
+    for it, step in ((1, 1.6), (2, 0.8)):
+        eo.gradient_iteration_threaded(S, step, it)
+        oo.gradient_iteration(S, step, it)
+        assert np.array_equal(eo.get_embedded(), oo.y), "dim %d batch %d" % (dim, it)
+    assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
+
+
+@pytest.mark.parametrize("sampler,hub", [(1, False), (0, True)])
+def test_sequential_sgd_bit_exact_samplers(A, oracle, graph, sampler, hub):
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1, ce_sampler=sampler, hubness_weighting=hub)
+    S = 10 * eo.get_nb_edges()
+    eo.gradient_iteration_threaded(S, 1.2, 1)
+    oo.gradient_iteration(S, 1.2, 1)
+    assert np.array_equal(eo.get_embedded(), oo.y)
+
+
+def test_sequential_sgd_general_b(A, oracle, graph):
+    """b != 1 goes through pow(): device libm vs glibc differ by ulps -> 1e-4 relative (north star tolerance)"""
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1, b=0.8)
+    S = 2 * eo.get_nb_edges()
+    eo.gradient_iteration_threaded(S, 1.0, 1)
+    oo.gradient_iteration(S, 1.0, 1)
+    y, r = eo.get_embedded(), oo.y
+    assert np.max(np.abs(y - r)) < 1e-4 * np.max(np.abs(r))
+
+
+def test_sequential_last_batch_step_zero_is_identity(A, oracle, graph):
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1)
+    before = eo.get_embedded()
+    eo.gradient_iteration_threaded(5000, 0.0, 9)  # B3: grad_step = 0 on the last batch (embedder.rs:875)
+    assert np.array_equal(eo.get_embedded(), before)
+
+
+def test_sharded_sequential_matches_oracle(A, oracle, graph):
+    """node range [lo,hi): positive edges only from owned sources, streams offset by lo << 24"""
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    y0 = oracle.set_data_box(np.random.default_rng(9).normal(size=(2500, 2)).astype(np.float32), 10.0)
+    lo, hi = 1000, 2500
+    eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(ce_mode=1), y0, node_lo=lo, node_hi=hi)
+    oo = oracle.EntropyOptim(indptr, nbr, p0, s0, y0, node_lo=lo, node_hi=hi)
+    assert eo.get_nb_edges() == int(indptr[hi] - indptr[lo])
+    S = 10 * eo.get_nb_edges()
+    eo.gradient_iteration_threaded(S, 1.0, 2)
+    oo.gradient_iteration(S, 1.0, 2, s_begin=lo << 24)
+    assert np.array_equal(eo.get_embedded(), oo.y)
+    assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
+
+
+def test_hogwild_statistics_match_oracle(A, oracle):
+    """The Hogwild schedule is not reproducible (neither is the reference's rayon loop); its statistics are:
+    same samples, same arithmetic => final cross entropy close to the oracle's sequential run and to the
+    oracle's own OpenMP Hogwild run."""
+    indptr, nbr, dist, _, _ = synthetic_graph(n=20000, dim=8, k=8, seed=2, ncomp=6, )
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(20000, 2)).astype(np.float32), 10.0)
+    par = A.EmbedderParams(nb_grad_batch=6)
+    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), par, y0)
+    yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 6)
+    assert abs(ce0 - oce0) < 1e-10 * oce0
+    assert np.isfinite(y).all()
+    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
+    # edge lengths in the embedding have the same distribution
+    src = np.repeat(np.arange(20000), 8)
+    lg = np.linalg.norm(y[src] - y[nbr], axis=1)
+    lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
+    for q in (0.25, 0.5, 0.75, 0.95):
+        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.15 * np.quantile(lo, q)
+    # the literal per-sample racy transcription is NOT equivalent on a GPU (most updates are lost): keep the evidence
+    yr, _, cer = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_SAMPLE_RACY), y0)
+    lr = np.linalg.norm(yr[src] - yr[nbr], axis=1)
+    assert np.quantile(lr, 0.5) > 1.4 * np.quantile(lo, 0.5)
+
+
+# ------------------------------------------------------------------------------------------------
+# a3-a9 diffusion maps
+# ------------------------------------------------------------------------------------------------
+def test_dmap_laplacian_csr_golden(A):
+    g = A.KGraph(GOLD["g_indptr"], GOLD["g_nbr"], GOLD["g_dist"])
+    lap = A.DiffusionMaps(A.DiffusionParams(2, 5.0, 6)).laplacian_from_kgraph(g, force_repr=2)
+    is_csr, n, nnz = lap.info()
+    assert is_csr and n == 300
+    ip, ind, val = lap.get_sym_kernel()
+    assert np.array_equal(ip, GOLD["dmap_lap_indptr"]) and np.array_equal(ind, GOLD["dmap_lap_indices"])  # structure: exact
+    assert _relmax(val, GOLD["dmap_lap_values"]) < 1e-5  # f32 sums in a different order (SURVEY hard part 6)
+    v = lap.get_vectors()
+    assert np.array_equal(v["normed_scales"], GOLD["dmap_normed"])
+    assert _relmax(v["q_density"], GOLD["dmap_q"]) < 5e-6 and _relmax(v["beta_scales"], GOLD["dmap_beta_scales"]) < 5e-6
+    assert _relmax(v["normalizer"], GOLD["dmap_normalizer"]) < 5e-6
+    assert v["mean_scale"] == float(GOLD["dmap_mean_scale"])
+
+
+@pytest.mark.parametrize("force_repr", [1, 2])
+def test_dmap_laplacian_vs_oracle(A, oracle, graph, force_repr):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    lap = A.DiffusionMaps(A.DiffusionParams(2, 5.0, 12)).laplacian_from_kgraph(g, force_repr=force_repr)
+    rc, ol = oracle.dmap_laplacian(indptr, nbr, dist, 8, oracle.DiffusionParams(2, 5.0, 12), force_repr=force_repr)
+    assert rc == 0
+    v = lap.get_vectors()
+    assert np.array_equal(v["normed_scales"], ol["normed_scales"])
+    assert _relmax(v["q_density"], ol["q"]) < 1e-5 and _relmax(v["normalizer"], ol["normalizer"]) < 1e-5
+    if force_repr == 2:
+        ip, ind, val = lap.get_sym_kernel()
+        assert np.array_equal(ip, ol["csr"].indptr) and np.array_equal(ind, ol["csr"].indices)
+        assert _relmax(val, ol["csr"].values) < 1e-5
+    else:
+        assert np.max(np.abs(lap.get_sym_kernel() - ol["dense"])) < 2e-6
+    # do_svd: dense & n <= 5000 -> full svd ; else rank-20 / 5 iteration randomized svd (graphlaplace.rs:127-134)
+    sv = lap.do_svd()
+    so, uo = oracle.laplacian_do_svd(ol)
+    assert _relmax(sv.s[:20], so[:20]) < (2e-5 if force_repr == 1 else 1e-4)
+    assert abs(sv.s[0] - 1.0) < (1e-5 if force_repr == 1 else 5e-2)
+
+
+def test_dmap_embedding_parity_up_to_sign(A, oracle, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    y = A.DiffusionMaps(A.DiffusionParams(2, 5.0, 12)).embed_from_kgraph(g)
+    rc, yo, info = oracle.dmap_embed_from_kgraph(indptr, nbr, dist, 8, oracle.DiffusionParams(2, 5.0, 12))
+    assert rc == 0 and y.shape == yo.shape
+    for c in range(2):  # singular vectors are defined up to sign
+        sgn = np.sign(np.dot(y[:, c], yo[:, c]))
+        err = np.max(np.abs(sgn * y[:, c] - yo[:, c])) / np.max(np.abs(yo[:, c]))
+        assert err < 2e-3, (c, err)  # eigen-gaps of ~1e-2 amplify f32 roundoff of two different SVD algorithms
+
+
+def test_dmap_errors(A, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    dp = A.DiffusionParams(2, 5.0, 12)
+    dp._c.beta = 0.3  # bypass the setter: "beta cannot be > 0." exit at diffmaps.rs:827-830
+    with pytest.raises(A.AnnembedError) as e:
+        A.DiffusionMaps(dp).laplacian_from_kgraph(g)
+    assert e.value.code == 9
+
+
+# ------------------------------------------------------------------------------------------------
+# a7-a8 tools::svdapprox -- the reference's own known-answer tests, on the GPU
+# ------------------------------------------------------------------------------------------------
+def _sigma_ok(computed, exact, eps):
+    for i in range(len(computed)):
+        if exact[i] > 0:
+            assert abs(1.0 - computed[i] / exact[i]) < eps, (i, computed[i], exact[i])
+        else:
+            assert abs(exact[i] - computed[i]) < eps, (i, computed[i], exact[i])
+
+
+def test_gpu_svd_wiki_rank_full(A):  # svdapprox.rs:1310
+    r = A.SvdApprox(A.MatRepr.from_array2(GOLD["wiki"])).direct_svd(A.RangeRank(3, 8))
+    assert len(r.s) == 3
+    _sigma_ok(r.s, GOLD["wiki_sigma"], 1e-5)
+
+
+def test_gpu_svd_wiki_csr_rank(A):  # svdapprox.rs:1497 (rank deficient matrix, rank 4 asked)
+    import scipy.sparse as sp
+    m = sp.csr_matrix(GOLD["wiki"].astype(np.float32))
+    mat = A.MatRepr.from_csrmat(m.indptr, m.indices, m.data, (4, 5))
+    r = A.SvdApprox(mat).direct_svd(A.RangeRank(4, 5))
+    assert len(r.s) == 4
+    _sigma_ok(r.s, GOLD["wiki_sigma"], 1e-5)
+    assert np.max(np.abs((r.u * r.s) @ r.vt - GOLD["wiki"])) < 1e-5  # A = U S Vt
+    q = np.random.default_rng(0).normal(size=(4, 3)).astype(np.float32)  # check_transpose_dense_mult_csr :1575
+    assert np.max(np.abs(A.transpose_dense_mult_csr(q, mat) - q.T @ GOLD["wiki"])) < 1e-5
+
+
+def test_gpu_range_approx_rank(A, oracle):  # svdapprox.rs:1231 in f32: residual relative to ||A||
+    rng = np.random.default_rng(4)
+    u, v = rng.normal(size=(503, 20)), rng.normal(size=(20, 503))
+    mat = (u @ v).astype(np.float32)
+    q = A.subspace_iteration(A.MatRepr.from_array2(mat), 20, 4)
+    assert np.max(np.abs(q.T @ q - np.eye(20))) < 1e-5  # orthonormal columns
+    resid = np.linalg.norm(mat - q @ (q.T @ mat)) / np.linalg.norm(mat)
+    assert resid < 1e-5
+    # rank deficient tall matrix (svdapprox.rs:1160 pattern): rank 26 of 30, 28 asked
+    data = rng.normal(size=(30, 500)).astype(np.float32)
+    for r_ in (3, 5, 7, 9):
+        data[r_] = data[2]
+    q = A.subspace_iteration(A.MatRepr.from_array2(data), 28, 2)
+    assert np.linalg.norm(data - q @ (q.T @ data)) / np.linalg.norm(data) < 1e-5
+
+
+def test_gpu_svd_sparse_vs_oracle(A, oracle):
+    """rank-20 / 5 iteration direct_svd of a sparse symmetric matrix: same Omega stream, same algorithm"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    n = 3000
+    m = sp.random(n, n, density=0.004, random_state=8, dtype=np.float32, format="csr")
+    m = (m + m.T + sp.diags(np.linspace(1, 30, n).astype(np.float32))).tocsr()
+    m.sort_indices()
+    mat = A.MatRepr.from_csrmat(m.indptr, m.indices, m.data, (n, n))
+    r = A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))
+    so, uo, vto = oracle.direct_svd(oracle.CsrMat(m.indptr, m.indices, m.data, (n, n)), 20, 5)
+    assert _relmax(r.s, so) < 1e-4
+    assert np.max(np.abs(r.u.T @ r.u - np.eye(20))) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# Embedder
+# ------------------------------------------------------------------------------------------------
+def test_embedder_one_step(A, oracle, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    e = A.Embedder(g, A.EmbedderParams(nb_grad_batch=8))
+    with pytest.raises(A.AnnembedError) as ex:  # results before embed(): state error instead of a Rust panic
+        e.get_embedded()
+    assert ex.value.code == 8
+    assert e.embed() == 1
+    y, y0 = e.get_embedded(), e.get_initial_embedding()
+    rc, ref = oracle.one_step_embed(indptr, nbr, dist, 8, oracle.EmbedderParams(nb_grad_batch=8))
+    assert rc == 0 and y.shape == (2500, 2) and np.isfinite(y).all()
+    assert abs(np.abs(y0).max() - 5.0) < 1e-4  # set_data_box(10): max |coord| = 5
+    for c in range(2):
+        sgn = np.sign(np.dot(y0[:, c], ref["y0"][:, c]))
+        assert np.max(np.abs(sgn * y0[:, c] - ref["y0"][:, c])) < 2e-2 * 5.0
+    b, a = e.get_cross_entropy()
+    assert abs(b - ref["ce_before"]) < 2e-2 * ref["ce_before"] and abs(a - ref["ce_after"]) < 0.15 * ref["ce_after"]
+    assert np.array_equal(e.get_embedded_reindexed(), y)
+    perm = np.random.default_rng(0).permutation(2500).astype(np.uint64)
+    assert np.array_equal(e.get_embedded_reindexed(perm)[perm], y)
+
+
+def test_embedder_random_init_and_hubness(A, oracle, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    p = A.EmbedderParams(nb_grad_batch=5, dmap_init=False, hubness_weighting=True, asked_dim=3)
+    e = A.Embedder(g, p)
+    assert e.embed() == 1
+    y0 = e.get_initial_embedding()
+    assert np.array_equal(y0, oracle.random_init(2500, 3, 1.0, p.seed))  # U(-.5,.5), same Philox stream
+    assert np.array_equal(e.get_hubness(), oracle.hubness(indptr, nbr))
+    assert np.isfinite(e.get_embedded()).all()
+
+
+def test_embedder_hierarchical(A, oracle):
+    """h_embed (embedder.rs:194-295) on a KGraphProjection: small graph = first nodes, projection = nearest small node"""
+    x, _ = gaussian_mixture(6000, 8, 4, seed=12, spread=3.0)
+    n_small = 800
+    ip_s, nb_s, d_s = knn_graph(x[:n_small], 6)
+    ip_l, nb_l, d_l = knn_graph(x, 6)
+    d2 = ((x[:, None, :] - x[None, :n_small, :]) ** 2).sum(-1) if False else None
+    xs = x[:n_small].astype(np.float64)
+    dd = (x.astype(np.float64) ** 2).sum(1)[:, None] + (xs ** 2).sum(1)[None, :] - 2 * x.astype(np.float64) @ xs.T
+    proj_node = dd.argmin(1).astype(np.uint32)
+    proj_dist = np.sqrt(np.maximum(dd.min(1), 0)).astype(np.float32)
+    small, large = A.KGraph(ip_s, nb_s, d_s), A.KGraph(ip_l, nb_l, d_l)
+    proj = A.KGraphProjection(small, large, proj_node, proj_dist)
+    p = A.EmbedderParams(nb_grad_batch=4, grad_factor=2, scale_rho=0.75, hubness_weighting=True)
+    e = A.Embedder.from_hkgraph(proj, p)
+    assert e.embed() == 1
+    y = e.get_embedded()
+    rc, ref = oracle.h_embed((ip_s, nb_s, d_s, 6), (ip_l, nb_l, d_l, 6), proj_node, proj_dist,
+                             oracle.EmbedderParams(nb_grad_batch=4, grad_factor=2, scale_rho=0.75, hubness_weighting=True))
+    assert rc == 0 and y.shape == (6000, 2) and np.isfinite(y).all()
+    b, a = e.get_cross_entropy()
+    assert abs(a - ref["ce_after"]) < 0.2 * ref["ce_after"]
+    # projected points start near their projection (clip(.,2) noise, embedder.rs:265)
+    y0 = e.get_initial_embedding()
+    assert np.max(np.abs(y0[n_small:] - y0[proj_node[n_small:]])) <= 2.0 + 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE size (configs[1]: 60k nodes, k = 12): size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties(A):
+    n, k = 60000, 12
+    rng = np.random.default_rng(0)
+    base = np.arange(n)
+    nbr = np.stack([(base + off) % n for off in (1, 2, 3, 5, 8, 13, n - 1, n - 2, n - 3, n - 5, n - 8, n - 13)], 1).astype(np.uint32)
+    dist = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1)
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    g = A.KGraph(indptr, nbr.reshape(-1), dist.reshape(-1))
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    p, s = npar.get()
+    p = p.reshape(n, k)
+    assert np.allclose(p.sum(1), 1.0, atol=2e-5) and (p > 0).all() and (np.diff(p, axis=1) <= 1e-7).all()  # sorted dists -> sorted probas
+    y0 = A.set_data_box(rng.normal(size=(n, 2)).astype(np.float32), 10.0)
+    par = A.EmbedderParams(nb_grad_batch=5)
+    eo = A.EntropyOptim(g, npar, par, y0)
+    nodes, w = eo.plan(0, 200000, 1)
+    src, cnt = np.unique(nodes[:, 0], return_counts=True)
+    assert nodes.max() < n and cnt.max() < 30  # uniform sources
+    assert (nodes[:, 2:] != nodes[:, :1]).all() and (nodes[:, 2:] != nodes[:, 1:2]).all()
+    S = 10 * eo.get_nb_edges()
+    before = eo.get_embedded()
+    eo.gradient_iteration_threaded(S, 0.0, 1)
+    assert np.array_equal(eo.get_embedded(), before)  # step 0 is the identity at any size
+    eo.gradient_iteration_threaded(S, 1.0, 2)
+    y = eo.get_embedded()
+    assert np.isfinite(y).all() and np.isfinite(eo.ce_compute_threaded())
+    ms, cnt = eo.kernel_time()
+    assert cnt == 2 and ms > 0
+    drawn, rounds = eo.samples_drawn()  # Poisson(nb_sample) total per batch
+    assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S) and rounds == 4

@@ -1,0 +1,107 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/annembed_hip.h declares; parameter
+PODs through the ABI; loud failure without a GPU; host-side helpers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "annembed_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ae_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from annembed_amd import build
+    build.build(verbose=False)
+    from annembed_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_functions()
+    assert len(names) > 50
+    for n in names:
+        assert hasattr(lib, n), "symbol %s declared in include/annembed_hip.h is not exported" % n
+
+
+def test_bindings_cover_the_header(lib):
+    from annembed_amd import _lib
+    bound = set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS)
+    assert set(_declared_functions()) == bound
+
+
+def test_version_string(lib):
+    assert b"gfx950" in lib.ae_version()
+
+
+def test_embedder_params_default_matches_reference():
+    """EmbedderParams::default, src/embedparams.rs:107-132"""
+    import annembed_amd as A
+    p = A.EmbedderParams()
+    assert (p.asked_dim, p.dmap_init, p.beta, p.b, p.scale_rho, p.grad_step) == (2, True, 1.0, 1.0, 1.0, 2.0)
+    assert (p.nb_sampling_by_edge, p.nb_grad_batch, p.grad_factor, p.hierarchy_layer, p.hubness_weighting) == (10, 20, 4, 0, False)
+    assert p.seed == 4664397 and p.ce_mode == A.AE_CE_HOGWILD and p.ce_sampler == A.AE_SAMPLER_ROWCDF
+    p.set_dim(5)
+    p.set_nb_gradient_batch(7)
+    assert p.c().asked_dim == 5 and p.c().nb_grad_batch == 7
+
+
+def test_diffusion_params_clamps():
+    """DiffusionParams::new / set_alfa / set_beta / set_epsil, src/diffmaps.rs:95-160"""
+    import annembed_amd as A
+    dp = A.DiffusionParams(2, 5.0, 12)
+    assert (dp.get_alfa(), dp.get_beta(), dp.get_epsil(), dp.get_time(), dp.get_gnbn()) == (0.5, pytest.approx(-0.1), 2.0, 5.0, 12)
+    dp.set_alfa(3.0)
+    assert dp.get_alfa() == 1.0
+    dp.set_alfa(-5.0)
+    assert dp.get_alfa() == -2.0
+    dp.set_beta(0.5)  # rejected: must stay in [-1.01, 0]
+    assert dp.get_beta() == pytest.approx(-0.1)
+    dp.set_beta(-0.5)
+    assert dp.get_beta() == -0.5
+    dp.set_epsil(10.0)
+    assert dp.get_epsil() == 4.0
+    dp.set_epsil(0.1)
+    assert dp.get_epsil() == 0.5
+    assert A.DiffusionParams(3).get_time() is None and A.DiffusionParams(3).get_gnbn() is None
+
+
+def test_no_gpu_fails_loudly(lib):
+    """the product has no CPU fallback: without a HIP device every compute entry point returns AE_ERR_NO_DEVICE"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import annembed_amd as A
+    indptr = np.array([0, 1, 2], np.uint64)
+    with pytest.raises(A.AnnembedError) as e:
+        A.KGraph(indptr, np.array([1, 0], np.uint32), np.array([1, 1], np.float32))
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_oracle():
+    """the oracle is test infrastructure: nothing under annembed_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "annembed_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath.split(os.sep)[-1:]:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_shard_ranges():
+    from annembed_amd.dist import sample_offset, shard_range, shard_sizes
+    for n, w in ((10, 3), (60000, 8), (7, 7), (11_000_000, 8)):
+        r = [shard_range(n, w, k) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+        assert max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
+    assert sample_offset(0) == 0 and sample_offset(5) == 5 << 24
