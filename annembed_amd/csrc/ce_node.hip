@@ -268,17 +268,6 @@ __global__ void __launch_bounds__(kApplyBlock) ce_apply_node_kernel(NodeArgs a) 
     const CeDev c = a.c;
     const uint32_t tid = threadIdx.x;
     const uint64_t v64 = c.node_lo + blockIdx.x * (uint64_t)kApplyBlock + threadIdx.x;
-    {   // samples drawn in this round: one atomic per workgroup (a per-wave atomic on one address costs ~12 ns each)
-        __shared__ unsigned int s_cnt;
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        unsigned int mine = v64 < c.node_hi ? a.tot[v64 - c.node_lo] : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, mine);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) atomicAdd(a.sample_counter, (unsigned long long)s_cnt);
-    }
     if (v64 >= c.node_hi) return;
     const uint32_t v = (uint32_t)v64;
     float yv[DIM], grad[DIM];
@@ -437,6 +426,156 @@ __global__ void __launch_bounds__(kApplyBlock) ce_apply_node_kernel(NodeArgs a) 
     }
 }
 
+
+// ---- K_apply, lane-group form: 8 lanes per node, 8 nodes per wave.  A graph with N nodes offers only N
+// sequential update chains; with one lane per node 60 k nodes are 940 waves (one per SIMD, nothing to hide
+// latency with).  Here lane r of a group fetches row r of the sample (j, k1..k5) -- one gather instruction
+// covers the 6 rows of 8 samples -- and the 6 dependent update steps are replayed by the whole group on a
+// replicated y_v with in-group broadcasts.  8x more waves, 8x shorter in-edge loops for hubs.
+constexpr int kGroup = 8;
+template <int DIM>
+__device__ __forceinline__ void group_bcast(const float* in, int src_lane, float* out) {
+#pragma unroll
+    for (int q = 0; q < DIM; q++) out[q] = __shfl(in[q], src_lane);
+}
+
+template <int DIM, bool B1>
+__global__ void __launch_bounds__(kBlock) ce_apply_group_kernel(NodeArgs a) {
+    const CeDev c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & (kGroup - 1);
+    const int gbase = lane & ~(kGroup - 1);
+    const uint64_t nodes_owned = c.node_hi - c.node_lo;
+    const uint64_t wave = (blockIdx.x * (uint64_t)kBlock + threadIdx.x) >> 6;
+    const uint64_t local = wave * (64 / kGroup) + (uint64_t)(lane >> 3);
+    const bool valid = local < nodes_owned;
+    const uint64_t lv = valid ? local : nodes_owned - 1;  // idle groups shadow the last node (no stores)
+    const uint32_t v = (uint32_t)(c.node_lo + lv);
+    float yv[DIM], grad[DIM];
+    load_row_fresh<DIM>(c.y, v, yv);
+#pragma unroll
+    for (int q = 0; q < DIM; q++) grad[q] = 0.f;
+    const float s_v = c.emb_scale[v];
+    const float inv_s2 = rcp(s_v * s_v);
+    // ---------------- (a) samples whose source is v ----------------
+    const uint32_t nv = valid ? a.tot[lv] : 0u;
+    uint32_t nmax = nv;
+#pragma unroll
+    for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
+    const uint32_t* plan_words = a.plan + lv * 8 + r;  // entry (slot, node): 8 words at ((slot * nodes) + node) * 8
+    for (uint32_t t = 0; t < nmax; t++) {
+        const bool act = t < nv;
+        uint32_t word = 0;
+        if (act) word = plan_words[(uint64_t)t * nodes_owned * 8];
+        float row[DIM];
+#pragma unroll
+        for (int q = 0; q < DIM; q++) row[q] = 0.f;
+        if (act && r < 6) {
+            if (a.skip == 7) { const float* pp = c.y + (uint64_t)word * DIM; for (int q = 0; q < DIM; q++) row[q] = pp[q]; }
+            else load_row_fresh<DIM>(c.y, word, row);
+        }
+        const float w = __uint_as_float(__shfl(word, gbase + 6));
+        float other[DIM];
+        group_bcast<DIM>(row, gbase + 0, other);
+        {   // attraction, the y_i half of embedder.rs:1207-1237
+            float d = 0.f;
+#pragma unroll
+            for (int q = 0; q < DIM; q++) { const float df = yv[q] - other[q]; d += df * df; }
+            const float delta = d * inv_s2;
+            if (act && delta > 0.f) {
+                const float coeff = grad_coeff_f32<B1>(delta, inv_s2, a.b);
+                const float rep = rcp(fmaxf(delta * delta, 1.0f / kProbaMin));
+                const float cij = fmaxf(a.step * coeff * (-w + (1.f - w) * rep), -0.49f);
+#pragma unroll
+                for (int q = 0; q < DIM; q++) grad[q] = (other[q] - yv[q]) * cij;
+            } else {
+#pragma unroll
+                for (int q = 0; q < DIM; q++) grad[q] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
+        }
+#pragma unroll
+        for (int g = 1; g <= 5; g++) {  // 5 repulsions, :1267-1297
+            group_bcast<DIM>(row, gbase + g, other);
+            float dk = 0.f;
+#pragma unroll
+            for (int q = 0; q < DIM; q++) { const float df = yv[q] - other[q]; dk += df * df; }
+            if (act && dk > 0.f) {
+                const float dks = dk * inv_s2;
+                const float coeff = grad_coeff_f32<B1>(dks, inv_s2, a.b);
+                const float cik = fminf(a.step * coeff * rcp(fmaxf(dks * dks, 1.0f / 16.0f)), 2.0f);
+#pragma unroll
+                for (int q = 0; q < DIM; q++) grad[q] = (other[q] - yv[q]) * cik;
+            }  // else `gradient` keeps its previous value (reference quirk B4)
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
+            }
+        }
+        if (act && r == 0) { if (a.store_mode == 0) store_row_through<DIM>(c.y, v, yv); else if (a.store_mode == 1) store_row_plain<DIM>(c.y, v, yv); }
+    }
+    if (a.store_mode >= 2 && r == 0 && valid) store_row_through<DIM>(c.y, v, yv);
+    if (a.skip == 2) return;
+    // ---------------- (b) samples whose target is v: the y_j half of :1238-1239 ----------------
+    const uint64_t tb = a.tptr[v];
+    const uint32_t indeg = valid ? (uint32_t)(a.tptr[v + 1] - tb) : 0u;
+    uint32_t dmax = indeg;
+#pragma unroll
+    for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(dmax, off); dmax = o > dmax ? o : dmax; }
+    for (uint32_t x0 = 0; x0 < dmax; x0 += kGroup) {
+        const uint32_t x = x0 + (uint32_t)r;
+        uint32_t cnt = 0;
+        float wu = 0.f, su = 1.f;
+        float yu[DIM];
+#pragma unroll
+        for (int q = 0; q < DIM; q++) yu[q] = 0.f;
+        if (x < indeg) {
+            const InEdge rec = a.tin[tb + x];
+            cnt = a.cnt[rec.eid];
+            wu = rec.w;
+            su = rec.s_src;
+            if (cnt) load_row_fresh<DIM>(c.y, rec.src, yu);
+        }
+        bool changed = false;
+#pragma unroll
+        for (int sl = 0; sl < kGroup; sl++) {
+            const uint32_t bc = __shfl(cnt, gbase + sl);
+            uint32_t cmax = bc;
+#pragma unroll
+            for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(cmax, off); cmax = o > cmax ? o : cmax; }
+            if (cmax == 0) continue;  // wave-uniform
+            float other[DIM];
+            group_bcast<DIM>(yu, gbase + sl, other);
+            const float wb = __shfl(wu, gbase + sl);
+            const float sb = __shfl(su, gbase + sl);
+            const float inv_su2 = rcp(sb * sb);
+            for (uint32_t rep_i = 0; rep_i < cmax; rep_i++) {
+                if (rep_i < bc) {
+                    attract<DIM, B1>(yv, other, wb, inv_su2, a.step, a.b, 1.f);
+                    changed = true;
+                }
+            }
+        }
+        if (changed && r == 0 && valid && a.store_mode < 2) store_row_through<DIM>(c.y, v, yv);
+    }
+    if (a.store_mode >= 2 && r == 0 && valid) store_row_through<DIM>(c.y, v, yv);
+}
+
+// samples planned in this round (one workgroup; a per-wave atomic on one address would cost ~12 ns each)
+__global__ void __launch_bounds__(1024) ce_sum_tot_kernel(const uint32_t* __restrict__ tot, uint64_t n, unsigned long long* counter) {
+    __shared__ unsigned long long red[1024];
+    unsigned long long s = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += 1024) s += tot[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *counter += red[0];
+}
+
 __global__ void in_edge_keys_kernel(uint64_t n, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ nbr,
                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ payload) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -456,6 +595,15 @@ __global__ void in_edge_fill_kernel(uint64_t nnz, const uint64_t* __restrict__ k
     r.w = proba[r.eid];
     r.s_src = emb_scale[r.src];
     tin[x] = r;
+}
+
+template <int DIM>
+void launch_apply_group(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
+    if constexpr (DIM > 0) {
+        const unsigned grid = blocks_for(((nodes + 7) / 8) * 64, kBlock);
+        if (a.b == 1.0f) hipLaunchKernelGGL((ce_apply_group_kernel<DIM, true>), dim3(grid), dim3(kBlock), 0, stream(), a);
+        else hipLaunchKernelGGL((ce_apply_group_kernel<DIM, false>), dim3(grid), dim3(kBlock), 0, stream(), a);
+    }
 }
 
 template <int DIM>
@@ -496,7 +644,11 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     const uint64_t nodes = o->dev.node_hi - o->dev.node_lo;
     const double per_node = (double)nb_sample / (double)nodes;  // expected samples per source node in the batch
     // rounds: keep the largest per-edge Poisson mean (p_e <= 1) below 30 so that exp(-mu) stays normal in f32
-    const uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / 30.0));
+    // ~12 samples per node and round: measured trade-off between fidelity to the sequential reference (final
+    // cross entropy within ~10-15 %, edge-length quantiles within ~10 %) and per-round fixed costs
+    double per_round_target = 12.0;
+    if (getenv("AE_CE_PER_ROUND")) per_round_target = atof(getenv("AE_CE_PER_ROUND"));
+    const uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / per_round_target));
     o->rounds = rounds;
     if (iter >= (1u << 20) || rounds >= (1u << 10)) fail(AE_ERR_INVALID_ARG, "iteration / round index too large for the RNG key");
     const double per_round = per_node / (double)rounds;
@@ -525,7 +677,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
         a.prof = prof_buf.p;
     }
     a.skip = getenv("AE_CE_SKIP") ? atoi(getenv("AE_CE_SKIP")) : 0;
-    a.store_mode = getenv("AE_CE_STORE") ? atoi(getenv("AE_CE_STORE")) : 0;
+    a.store_mode = getenv("AE_CE_STORE") ? atoi(getenv("AE_CE_STORE")) : 2;
     const bool sharded = o->dev.shard_edges != o->dev.nnz;
     for (uint32_t r = 0; r < rounds; r++) {
         a.round_key = (iter << 10) | r;
@@ -533,7 +685,9 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
         if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
         else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
         if (sharded) hipLaunchKernelGGL(ce_count_remote_kernel, dim3(grid_cap(o->dev.nnz, kBlock)), dim3(kBlock), 0, stream(), a);
-        AE_DISPATCH_DIM(o->dev.dim, launch_apply, o, a, nodes);
+        hipLaunchKernelGGL(ce_sum_tot_kernel, dim3(1), dim3(1024), 0, stream(), (const uint32_t*)o->tot.p, nodes, o->sample_counter.p);
+        if (getenv("AE_CE_THREAD_PER_NODE")) { AE_DISPATCH_DIM(o->dev.dim, launch_apply, o, a, nodes); }
+        else { AE_DISPATCH_DIM(o->dev.dim, launch_apply_group, o, a, nodes); }
     }
     check_launch("ce_node");
     if (a.prof) {
