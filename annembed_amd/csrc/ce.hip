@@ -608,7 +608,10 @@ int32_t ae_entropy_optim_samples_drawn(ae_entropy_optim* o, uint64_t* samples, u
         require_device();
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
         unsigned long long h = 0;
-        if (o->sample_counter.n) o->sample_counter.download(&h, 1);
+        if (o->sample_counter.n) {
+            std::vector<unsigned long long> hc = o->sample_counter.to_host();
+            for (auto x : hc) h += x;
+        }
         if (samples) *samples = h;
         if (rounds) *rounds = o->rounds;
     });
