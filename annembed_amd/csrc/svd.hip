@@ -49,7 +49,16 @@ __global__ void __launch_bounds__(256) spmm_csr_kernel(uint64_t m, const uint64_
     for (uint64_t row = wave; row < m; row += nwaves) {
         float acc = 0.f;
         const uint64_t e1 = indptr[row + 1];
-        for (uint64_t e = indptr[row] + g; e < e1; e += G) {
+        uint64_t e = indptr[row] + g;
+        for (; e + 3 * G < e1; e += 4 * G) {  // 4 neighbour rows in flight per lane
+            const float a0 = val[e], a1 = val[e + G], a2 = val[e + 2 * G], a3 = val[e + 3 * G];
+            const uint64_t c0 = ind[e], c1 = ind[e + G], c2 = ind[e + 2 * G], c3 = ind[e + 3 * G];
+            if (c < (int)l) {
+                const float x0 = x[c0 * l + c], x1 = x[c1 * l + c], x2 = x[c2 * l + c], x3 = x[c3 * l + c];
+                acc = fmaf(a0, x0, acc); acc = fmaf(a1, x1, acc); acc = fmaf(a2, x2, acc); acc = fmaf(a3, x3, acc);
+            }
+        }
+        for (; e < e1; e += G) {
             const float a = val[e];
             const uint64_t col = ind[e];
             if (c < (int)l) acc = fmaf(a, x[col * l + c], acc);
@@ -159,9 +168,16 @@ __global__ void __launch_bounds__(256) gram_partial_kernel(const float* __restri
 __global__ void gram_reduce_kernel(const double* __restrict__ partial, uint32_t nblocks, uint32_t npairs, double* __restrict__ g) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npairs) return;
-    double s = 0.;
-    for (uint32_t b = 0; b < nblocks; b++) s += partial[(uint64_t)b * npairs + p];
-    g[p] = s;
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;  // fixed 4-way interleave: deterministic
+    uint32_t b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += partial[(uint64_t)b * npairs + p];
+        s1 += partial[(uint64_t)(b + 1) * npairs + p];
+        s2 += partial[(uint64_t)(b + 2) * npairs + p];
+        s3 += partial[(uint64_t)(b + 3) * npairs + p];
+    }
+    for (; b < nblocks; b++) s0 += partial[(uint64_t)b * npairs + p];
+    g[p] = (s0 + s1) + (s2 + s3);
 }
 
 // out tile = y tile * M ; each workgroup owns kGramTile rows, staged through LDS so that in-place is safe
@@ -188,7 +204,8 @@ __global__ void __launch_bounds__(256) apply_panel_kernel(const float* __restric
 
 // cyclic Jacobi with round-robin parallel ordering on one workgroup; G is destroyed in LDS.
 __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restrict__ gin, uint32_t l, double* __restrict__ evals,
-                                                          double* __restrict__ evecs) {
+                                                          double* __restrict__ evecs, const int* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;  // the Cholesky route succeeded: nothing to do
     __shared__ double G[kMaxL * kMaxL];
     __shared__ double V[kMaxL * kMaxL];
     __shared__ double cs[kMaxL];  // c,s per pair
@@ -203,14 +220,18 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
     }
     __syncthreads();
     for (int sweep = 0; sweep < 30; sweep++) {
-        if (tid == 0) {
+        {   // off-diagonal vs diagonal mass, reduced by the first wave (l*l <= 4096 entries)
             double off = 0., diag = 0.;
-            for (uint32_t a = 0; a < l; a++)
-                for (uint32_t b = 0; b < l; b++) {
-                    double v = G[a * l + b];
-                    if (a == b) diag += v * v; else off += v * v;
+            if (tid < 64) {
+                for (uint32_t idx = tid; idx < l * l; idx += 64) {
+                    const double v = G[idx];
+                    if (idx / l == idx % l) diag += v * v; else off += v * v;
                 }
-            offn = (off <= 1e-30 * diag || off == 0.) ? 0. : off;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); diag += __shfl_xor(diag, o); }
+                // converged when the off-diagonal mass is at f64 roundoff of the diagonal (relative 1e-13 in norm)
+                if (tid == 0) offn = (off <= 1e-26 * diag || off == 0.) ? 0. : off;
+            }
         }
         __syncthreads();
         if (offn == 0.) break;
@@ -281,27 +302,80 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
     if (tid < l) evals[tid] = G[order[tid] * l + order[tid]];
 }
 
+// Cholesky attempt on the Gram matrix (one lane, l <= 64: a few thousand f64 flops).  G = R^T R, M = R^-1 so that
+// Y M has orthonormal columns.  flag[0] = 1 when a pivot is not safely positive (rank-deficient / ill-conditioned
+// panel): the caller's next kernels then take the eigen (SVQB) route instead.
+__global__ void __launch_bounds__(64) chol_inverse_kernel(const double* __restrict__ g, uint32_t l, double rel_tol, double* __restrict__ m,
+                                                          int* __restrict__ flag) {
+    // one wave: lane i owns column i of R during the factorisation and column i of M = R^-1 afterwards
+    __shared__ double R[kMaxL * kMaxL];
+    __shared__ int s_bad;
+    const uint32_t i = threadIdx.x;
+    double dmax = 0.;
+    for (uint32_t q = 0; q < l; q++) dmax = g[q * l + q] > dmax ? g[q * l + q] : dmax;
+    if (i == 0) s_bad = dmax > 0. ? 0 : 1;
+    __syncthreads();
+    for (uint32_t j = 0; j < l; j++) {  // upper Cholesky G = R^T R, row j of R per step
+        double v = 0.;
+        if (i >= j && i < l) {
+            v = g[j * l + i];
+            for (uint32_t k = 0; k < j; k++) v -= R[k * l + j] * R[k * l + i];
+        }
+        const double d = __shfl(v, (int)j);
+        if (!(d > rel_tol * dmax)) { if (i == 0) s_bad = 1; break; }  // wave-uniform
+        const double rjj = sqrt(d);
+        if (i >= j && i < l) R[j * l + i] = (i == j) ? rjj : v / rjj;
+        __syncthreads();
+    }
+    __syncthreads();
+    const bool ok = s_bad == 0;
+    if (ok && i < l) {  // column i of M = R^-1 by back substitution
+        double col[kMaxL];
+        for (uint32_t q = 0; q < l; q++) col[q] = 0.;
+        col[i] = 1. / R[i * l + i];
+        for (int r = (int)i - 1; r >= 0; r--) {
+            double v = 0.;
+            for (uint32_t k = r + 1; k <= i; k++) v -= R[r * l + k] * col[k];
+            col[r] = v / R[r * l + r];
+        }
+        for (uint32_t q = 0; q < l; q++) m[q * l + i] = col[q];
+    }
+    if (i == 0) *flag = ok ? 0 : 1;
+}
+
 // M[c][o] = evecs[c][o] * (evals[o] > tol ? evals[o]^-1/2 : 0)
 __global__ void svqb_scale_kernel(const double* __restrict__ evals, const double* __restrict__ evecs, uint32_t l, double rel_tol,
-                                  double* __restrict__ m) {
+                                  double* __restrict__ m, const int* __restrict__ run_if) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= l * l) return;
+    if (run_if && *run_if == 0) return;
     const uint32_t o = idx % l;
     const double lam = evals[o], lmax = evals[0];
     m[idx] = (lam > rel_tol * lmax && lam > 0.) ? evecs[idx] / sqrt(lam) : 0.;
 }
 
-__global__ void seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
+    // exact left-to-right f32 sum (the reference's iter().sum::<f32>() order): the workgroup stages chunks in LDS
+    // with coalesced loads, lane 0 adds them in order
+    constexpr int CH = 4096;
+    __shared__ float buf[CH];
     float s = 0.f;
-    uint64_t i = 0;
-    for (; i + 8 <= n; i += 8) {  // loads are independent, adds keep the reference's order
-        float v0 = x[(i + 0) * stride], v1 = x[(i + 1) * stride], v2 = x[(i + 2) * stride], v3 = x[(i + 3) * stride];
-        float v4 = x[(i + 4) * stride], v5 = x[(i + 5) * stride], v6 = x[(i + 6) * stride], v7 = x[(i + 7) * stride];
-        s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+        const uint32_t m = (uint32_t)((n - c0) < (uint64_t)CH ? (n - c0) : (uint64_t)CH);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += 256) buf[i] = x[(c0 + i) * stride];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t i = 0;
+            for (; i + 8 <= m; i += 8) {
+                const float v0 = buf[i], v1 = buf[i + 1], v2 = buf[i + 2], v3 = buf[i + 3];
+                const float v4 = buf[i + 4], v5 = buf[i + 5], v6 = buf[i + 6], v7 = buf[i + 7];
+                s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+            }
+            for (; i < m; i++) s += buf[i];
+        }
     }
-    for (; i < n; i++) s += x[i * stride];
-    *out = s;
+    if (threadIdx.x == 0) *out = s;
 }
 
 // transpose support ---------------------------------------------------------------------------
@@ -367,7 +441,7 @@ void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t 
 
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
     DevBuf<float> out(1);
-    hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(64), 0, stream(), d_x, n, stride, out.p);
+    hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(256), 0, stream(), d_x, n, stride, out.p);
     check_launch("seq_sum");
     float h;
     out.download(&h, 1);
@@ -447,13 +521,13 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
 
 void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
-    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024));
-    DevBuf<double> partial((uint64_t)nblocks * l * l);
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 512));
+    static DevBuf<double> partial;  // scratch reused by every call (stream ordered, no sync needed)
+    if (partial.n < (uint64_t)nblocks * l * l) { sync(); partial.alloc((uint64_t)512 * kMaxL * kMaxL); }
     hipLaunchKernelGGL(gram_partial_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, partial.p);
     check_launch("gram_partial");
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), partial.p, nblocks, l * l, d_g);
     check_launch("gram_reduce");
-    sync();  // partial is freed on return
 }
 
 void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out) {
@@ -465,22 +539,31 @@ void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m,
 }
 
 void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs) {
-    hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(256), 0, stream(), d_g, l, d_evals, d_evecs);
+    hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(256), 0, stream(), d_g, l, d_evals, d_evecs, (const int*)nullptr);
     check_launch("jacobi_eigh");
 }
 
 void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work) {
-    double* g = d_work;
-    double* ev = d_work + (uint64_t)l * l;
-    double* evals = d_work + 2ull * l * l;  // needs l more doubles: caller gives 3*l*l
+    double* g = d_work;                       // Gram
+    double* mt = d_work + (uint64_t)l * l;    // transform M (Cholesky route: R^-1; eigen route: V diag(lambda^-1/2))
+    double* ev = d_work + 2ull * l * l;       // eigenvectors (eigen route)
+    static DevBuf<double> evals_buf;          // caller's work area is 3*l*l + l doubles: eigenvalues live here
+    if (evals_buf.n < (size_t)kMaxL) evals_buf.alloc(kMaxL);
+    static DevBuf<int> flag;
+    if (!flag.n) flag.alloc(1);
     for (int pass = 0; pass < 2; pass++) {
         gram_panel(d_y, rows, l, g);
-        jacobi_eigh_device(g, l, evals, ev);
-        // first pass drops directions below f32 resolution of the panel; second pass only rescales
-        hipLaunchKernelGGL(svqb_scale_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), evals, ev, l,
-                           pass == 0 ? 1e-12 : 1e-6, g);
+        // fast route: Cholesky QR (the panels of the power iteration are well conditioned).  When a pivot is not
+        // safely positive the device flag routes the SAME launch sequence through the eigen (SVQB) kernels, which
+        // turn rank-deficient directions into zero columns; no host round trip either way.
+        hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(64), 0, stream(), g, l, 1e-10, mt, flag.p);
+        check_launch("chol_inverse");
+        hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(256), 0, stream(), g, l, evals_buf.p, ev, (const int*)flag.p);
+        check_launch("jacobi_eigh");
+        hipLaunchKernelGGL(svqb_scale_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), evals_buf.p, ev, l,
+                           pass == 0 ? 1e-12 : 1e-6, mt, (const int*)flag.p);
         check_launch("svqb_scale");
-        apply_panel(d_y, rows, l, g, l, d_y);
+        apply_panel(d_y, rows, l, mt, l, d_y);
     }
 }
 
