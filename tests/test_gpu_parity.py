@@ -472,3 +472,51 @@ def test_full_size_properties(A):
     assert cnt == 2 and ms > 0
     drawn, rounds = eo.samples_drawn()  # Poisson(nb_sample) total per batch
     assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S) and rounds == 10
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU plumbing that can be exercised on one GPU
+# ------------------------------------------------------------------------------------------------
+def test_device_coords_alias_and_sharded_hogwild(A, oracle, graph):
+    """bench.py --gpus N all-gathers the coordinate rows through a torch view of the library's device buffer:
+    the view must alias (no copy).  Two shards run one after the other on one GPU emulate the per-batch protocol
+    of annembed_amd.dist.ShardedCE: every source node is sampled by exactly one shard."""
+    import torch
+    from annembed_amd.dist import device_tensor, shard_range
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    y0 = oracle.set_data_box(np.random.default_rng(4).normal(size=(2500, 2)).astype(np.float32), 10.0)
+    shards = []
+    for r in range(2):
+        lo, hi = shard_range(2500, 2, r)
+        shards.append((lo, hi, A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0, node_lo=lo, node_hi=hi)))
+    views = [device_tensor(eo) for _, _, eo in shards]
+    assert views[0].shape == (2500, 2) and views[0].is_cuda
+    views[0][7, 1] = 123.5  # write through torch, read through the C ABI
+    torch.cuda.synchronize()
+    assert shards[0][2].get_embedded()[7, 1] == np.float32(123.5)
+    views[0][7, 1] = float(y0[7, 1])
+    torch.cuda.synchronize()
+    total = 0
+    for it in range(1, 4):
+        for lo, hi, eo in shards:
+            eo.gradient_iteration_threaded(10 * eo.get_nb_edges(), 1.0, it)
+        from annembed_amd import _lib
+        _lib.check(_lib.load().ae_synchronize())
+        merged = torch.cat([views[r][shards[r][0]:shards[r][1]] for r in range(2)])  # the all-gather
+        for v in views:
+            v.copy_(merged)
+        torch.cuda.synchronize()
+    ys = [eo.get_embedded() for _, _, eo in shards]
+    assert np.array_equal(ys[0], ys[1]) and np.isfinite(ys[0]).all()
+    drawn = sum(eo.samples_drawn()[0] for _, _, eo in shards)
+    assert abs(drawn - 3 * 10 * len(nbr)) < 6 * np.sqrt(3 * 10 * len(nbr))
+    # the union of the two shards behaves like the single-GPU run: same statistics
+    full = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0)
+    for it in range(1, 4):
+        full.gradient_iteration_threaded(10 * len(nbr), 1.0, it)
+    ce_full = full.ce_compute_threaded()
+    ce_sh = sum(eo.ce_compute_threaded() for _, _, eo in shards)
+    assert abs(ce_sh - ce_full) < 0.2 * ce_full  # replicas are refreshed once per batch only
