@@ -124,6 +124,110 @@ __global__ void __launch_bounds__(64) dense_t_mul_panel_kernel(const float* __re
             if (c < (int)l) o[c] = acc[c];
     }
 }
+
+// ---- dense tall-skinny products on the matrix cores (subspace_iteration_full, svdapprox.rs:285-333; B = Q^T A :738)
+// v_mfma_f32_32x32x2_f32: exact f32 (an fmaf chain), A operand lane -> A[i = lane & 31][k = lane >> 5],
+// B operand lane -> B[k = lane >> 5][j = lane & 31], C: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// The panel width l <= 32 is padded to the 32 MFMA columns.  Both kernels stream A once: HBM-bound (16 flop / B with
+// the padded panel, below the ~20 flop/B ridge of 157 TF / 8 TB/s).
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Y[m x l] = A[m x n] * X[n x l].  A is row-major with the contraction index contiguous, so the 32 x KT tile of each
+// wave goes through LDS (coalesced 16-byte row segments in, conflict-free column reads out: row stride KT + 1).
+constexpr int kMfmaKT = 32;
+template <bool VEC4>
+__global__ void __launch_bounds__(256) dense_mul_panel_mfma_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                                   const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
+    __shared__ float sA[128 * (kMfmaKT + 1)];
+    __shared__ float sX[kMfmaKT * 32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t row_base = blockIdx.x * 128ull;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    for (uint64_t k0 = 0; k0 < n; k0 += kMfmaKT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // A tile: 128 rows x 32 k, one 16-byte segment per thread and pass
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, kc = (idx & 7) * 4;
+            const uint64_t row = row_base + r, kk = k0 + kc;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (row < m) {
+                if (VEC4 && kk + 3 < n) {
+                    const float4 t = *reinterpret_cast<const float4*>(a + row * n + kk);
+                    v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                } else {
+                    const float* p = a + row * n;
+                    if (kk < n) v0 = p[kk];
+                    if (kk + 1 < n) v1 = p[kk + 1];
+                    if (kk + 2 < n) v2 = p[kk + 2];
+                    if (kk + 3 < n) v3 = p[kk + 3];
+                }
+            }
+            float* d = sA + r * (kMfmaKT + 1) + kc;
+            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // X slab: 32 k x 32 j (zero padded beyond l)
+            const int idx = tid + q * 256;
+            const int kk = idx >> 5, j = idx & 31;
+            sX[idx] = (k0 + kk < n && (uint32_t)j < l) ? x[(k0 + kk) * l + j] : 0.f;
+        }
+        __syncthreads();
+        const float* pa = sA + (w * 32 + (lane & 31)) * (kMfmaKT + 1) + (lane >> 5);
+        const float* pb = sX + (lane >> 5) * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < kMfmaKT; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk * 32], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int j = lane & 31;
+    if ((uint32_t)j < l) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint64_t row = row_base + w * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (row < m) y[row * l + j] = acc[q];
+        }
+    }
+}
+
+// partial[chunk][n x l] = A[rows of chunk]^T * X[rows of chunk]: for a fixed row of A the 32 columns of the tile are
+// contiguous, so both operands are read straight from global memory in fragment order (no LDS).
+__global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                                     const float* __restrict__ x, float* __restrict__ partial,
+                                                                     uint32_t l, uint64_t rows_per_chunk) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t c0 = blockIdx.x * 32ull;
+    const uint64_t chunk = blockIdx.y;
+    const uint64_t i0 = chunk * rows_per_chunk;
+    const uint64_t i1 = i0 + rows_per_chunk < m ? i0 + rows_per_chunk : m;
+    const uint64_t col = c0 + (lane & 31);
+    const int kh = lane >> 5;
+    const bool cok = col < n, jok = (uint32_t)(lane & 31) < l;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    // the 4 waves of the workgroup interleave the rows of the chunk; their accumulators are summed through LDS
+    for (uint64_t r = i0 + 2 * w; r < i1; r += 8) {
+        const uint64_t rr = r + kh;
+        const bool ok = rr < i1;
+        const float av = (ok && cok) ? a[rr * n + col] : 0.f;
+        const float bv = (ok && jok) ? x[rr * l + (lane & 31)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __shared__ float red[4 * 64 * 16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) red[(w * 16 + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    if (w == 0 && jok) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float v = (red[q * 64 + lane] + red[(16 + q) * 64 + lane]) + (red[(32 + q) * 64 + lane] + red[(48 + q) * 64 + lane]);
+            const uint64_t crow = c0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);  // row of the output = column of A
+            if (crow < n) partial[(chunk * n + crow) * l + (lane & 31)] = v;
+        }
+    }
+}
+
 __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t chunks, uint64_t count, float* __restrict__ out) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -462,6 +566,15 @@ static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) 
 void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "panel width %u unsupported (max %d)", l, kMaxL);
     if (a.is_csr) { spmm(a, d_x, d_y, l); return; }
+    if (l <= 32 && !getenv("AE_NO_MFMA")) {  // matrix-core path
+        const unsigned g2 = blocks_for(a.nrows, 128);
+        if (a.ncols % 4 == 0)
+            hipLaunchKernelGGL((dense_mul_panel_mfma_kernel<true>), dim3(g2), dim3(256), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+        else
+            hipLaunchKernelGGL((dense_mul_panel_mfma_kernel<false>), dim3(g2), dim3(256), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+        check_launch("dense_mul_panel_mfma");
+        return;
+    }
     const unsigned grid = grid_cap(a.nrows * 64, 256);
     if (l <= 32)
         hipLaunchKernelGGL((dense_mul_panel_kernel<32>), dim3(grid), dim3(256), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
@@ -504,6 +617,20 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
         return;
     }
     const uint64_t m = a.nrows, n = a.ncols;
+    if (l <= 32 && !getenv("AE_NO_MFMA")) {  // matrix-core path: 32-column tiles x row chunks, then a deterministic reduce
+        const uint64_t ctiles = (n + 31) / 32;
+        uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, std::max<uint64_t>(1, 2048 / ctiles)));
+        const uint64_t rpc = ((m + chunks - 1) / chunks + 7) & ~7ull;
+        chunks = (m + rpc - 1) / rpc;
+        static DevBuf<float> part;
+        if (part.n < chunks * n * l) { sync(); part.alloc(chunks * n * l); }
+        hipLaunchKernelGGL(dense_t_mul_panel_mfma_kernel, dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m, n, d_x,
+                           part.p, l, rpc);
+        check_launch("dense_t_mul_panel_mfma");
+        hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for(n * l, 256)), dim3(256), 0, stream(), part.p, chunks, n * l, d_y);
+        check_launch("reduce_chunks");
+        return;
+    }
     const uint64_t colblocks = (n + 63) / 64;
     uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, std::max<uint64_t>(1, 4096 / colblocks)));
     const uint64_t rpc = (m + chunks - 1) / chunks;
