@@ -190,8 +190,13 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         points_per_s = n * args.steps / elapsed
         bytes_per_sample = 24 + 4 * k + 36 * d  # SURVEY 8d / DESIGN.md
-        # kernel_ms: hipEvent duration of one batch = `rounds` launches of the dominant kernel, on the library stream
-        achieved = bytes_per_sample * nb_sample / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # dominant kernel: ce_round_node_kernel, one launch per round; kernel_ms = hipEvent duration of one batch
+        # (= `rounds` back-to-back launches) on the library's stream, averaged over the timed steps
+        rounds = int(eo.samples_drawn()[1])
+        launch_ms = kernel_ms / rounds if rounds else 0.0
+        bytes_per_launch = bytes_per_sample * nb_sample / max(rounds, 1)
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        traffic = pmc_traffic()
         out = {
             "metric": "embedded_points_per_sec_ce_epoch",
             "value": points_per_s,
@@ -212,8 +217,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None, "kernel": "ce_round_group_kernel (one CE batch = `rounds` launches)", "rounds": int(eo.samples_drawn()[1]), "kernel_avg_ms": kernel_ms, "launches": int(launches),
-                "bytes_per_sample": bytes_per_sample,
+                "traffic": traffic, "kernel": "ce_round_node_kernel (one launch per round, `rounds` launches per CE batch)",
+                "rounds": rounds, "launch_avg_ms": launch_ms, "batch_kernel_ms": kernel_ms, "batches_timed": int(launches),
+                "bytes_per_sample": bytes_per_sample, "bytes_per_launch": bytes_per_launch,
             },
             "svd_init": {
                 "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
@@ -227,6 +233,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/pmc_ce_round.json, written by tools_prof.sh: FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, KiB -> bytes); None when no profile of the current kernel is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_ce_round.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            j = json.load(f)
+        return float(j["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch):
