@@ -577,7 +577,9 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         AE_HIP(hipEventCreate(&e0));
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
-        if (o->params.ce_mode == AE_CE_SAMPLE_RACY || !ce_node_supports_dim(o->dev.dim)) {
+        if (o->params.ce_mode != AE_CE_SAMPLE_RACY && !ce_node_supports(o))
+            fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
+        if (o->params.ce_mode == AE_CE_SAMPLE_RACY) {
             AE_DISPATCH_DIM(o->dev.dim, launch_hogwild, o, nb_sample, grad_step, (uint32_t)iter);
             check_launch("ce_sgd_hogwild");
         } else {

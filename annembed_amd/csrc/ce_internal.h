@@ -77,7 +77,7 @@ struct ae_entropy_optim {
 
 namespace ae {
 // node-centric Hogwild batch (ce_node.hip): `rounds` launches, expected nb_sample samples in total
-bool ce_node_supports_dim(uint32_t dim);
+bool ce_node_supports(const ae_entropy_optim* o);
 void ce_node_build_transpose(ae_entropy_optim* o);
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
 }  // namespace ae

@@ -1,0 +1,472 @@
+// ce_node_round.h -- the node-per-lane CE round kernel (template) and its launcher; instantiated for the exact
+// dimensions in ce_node_round_exact.hip and for the zero-padded ones in ce_node_round_pad.hip (two translation
+// units: the kernel is large and hipcc compiles them in parallel).
+#pragma once
+#include <type_traits>
+#include "ce_node_common.h"
+
+namespace ae {
+
+// ---- Node-per-lane round kernel (default for rows of <= 16 neighbours): one lane owns one node, 64 nodes per
+// wave, one launch per round.  The lane-group kernel above spends 8 lanes on every dependent update chain; here
+// a chain costs one lane, and latency is hidden by memory-level parallelism instead of by waves: the rows of S
+// samples (6 S gathers per lane) are in flight before their replay starts -- the sample's node set does not
+// depend on y_v.
+//   stage A  per lane: Poisson counts of the node's out-edges (edge-keyed hash); neighbour ids, weights and
+//            counts parked in an LDS column private to the lane (dynamically indexable scratch, no barrier).
+//   stage B  per chunk of S samples: resolve the sampled edge (walk the counts), draw 5 admissible negatives
+//            (exact rejection against the LDS column, nodeparam.rs:83-85), issue the 6 S gathers, replay
+//            the 6 dependent steps of embedder.rs:1207-1297 per sample.
+//   stage C  the in-edge pushes (y_j halves, :1238-1239): the in-edges of the wave's 64 nodes are contiguous in
+//            the transposed graph, so the wave evaluates their counts and gathers the source rows *balanced*
+//            (edge x -> lane x mod 64, a hub's 100 in-edges cost every lane 2), parks the active ones in LDS, and
+//            each lane replays the slice that targets its node.
+template <int DIM>
+struct NodeKernelCfg {
+    static constexpr int S = DIM <= 2 ? 4 : (DIM <= 4 ? 2 : 1);  // samples whose rows are gathered together
+    static constexpr int NQ = 4;                                  // in-edge records per lane and pass of stage C
+    static constexpr int CH = 64 * NQ;
+    static constexpr int EC = DIM <= 4 ? 512 : (DIM <= 8 ? 256 : 128);  // pushes parked in LDS per window
+};
+
+// N independent Poisson inversions advanced together, branch-free (same operations, same order per variate as
+// edge_count(): the source and the target owner of an edge must get the same count), so that the dependent
+// chains of different variates overlap -- a lone wave per SIMD has nothing else to hide their latency with.
+template <int N>
+__device__ __forceinline__ void poisson_batch(const float* u, const float* mu, uint32_t* cnt) {
+    float p[N], cdf[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { p[i] = __expf(-mu[i]); cdf[i] = p[i]; cnt[i] = 0u; }
+    for (uint32_t c = 1; c <= 255u; c++) {
+        const float inv_c = 1.0f / (float)c;
+        bool more = false;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const bool go = u[i] >= cdf[i];  // once false it stays false: cdf only moves while go holds
+            p[i] = p[i] * (mu[i] * inv_c);
+            cdf[i] += go ? p[i] : 0.f;
+            cnt[i] += go ? 1u : 0u;
+            more |= go;
+        }
+        if (!__any(more)) break;
+    }
+}
+
+// one pair step on y_v with a single reciprocal (b == 1):  attraction  c = max(2 step/s^2 (-w M + 1 - w) /
+// ((1 + delta) M), -0.49), M = max(delta^2, 1e4)  (embedder.rs:1216-1233);  repulsion  c = min(2 step/s^2 /
+// ((1 + delta) max(delta^2, 1/16)), 2)  (:1286-1293).  y_v += (y_v - y_o) c in both roles (source: y_i -= g;
+// target: y_j += g, g = (y_j - y_i) c).
+template <int DIM, bool B1>
+__device__ __forceinline__ float attract_coeff(float d, float w, float inv_s2, float step2, float step, float b) {
+    const float delta = d * inv_s2;
+    if constexpr (B1) {
+        const float M = fmaxf(delta * delta, 1.0f / kProbaMin);
+        return fmaxf(step2 * inv_s2 * ((1.f - w) - w * M) * rcp((1.f + delta) * M), -0.49f);
+    } else {
+        const float coeff = grad_coeff_f32<false>(delta, inv_s2, b);
+        const float rep = rcp(fmaxf(delta * delta, 1.0f / kProbaMin));
+        return fmaxf(step * coeff * (-w + (1.f - w) * rep), -0.49f);
+    }
+}
+template <int DIM, bool B1>
+__device__ __forceinline__ float repulse_coeff(float d, float inv_s2, float step2, float step, float b) {
+    const float delta = d * inv_s2;
+    if constexpr (B1) {
+        return fminf(step2 * inv_s2 * rcp((1.f + delta) * fmaxf(delta * delta, 1.0f / 16.0f)), 2.0f);
+    } else {
+        const float coeff = grad_coeff_f32<false>(delta, inv_s2, b);
+        return fminf(step * coeff * rcp(fmaxf(delta * delta, 1.0f / 16.0f)), 2.0f);
+    }
+}
+
+template <int DIM, bool PAD, bool B1, int KMAX>
+__global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
+    using Cfg = NodeKernelCfg<DIM>;
+    constexpr int LS = 65, S = Cfg::S, CH = Cfg::CH, NQ = Cfg::NQ, EC = Cfg::EC, KP = KMAX / 4;
+    __shared__ uint32_t s_nbr[KMAX * LS];
+    __shared__ float s_w[KMAX * LS];
+    __shared__ float s_in_row[EC * DIM];
+    __shared__ float s_in_a[EC];      // b == 1: 2 step / s_u^2 * (1 - w); else w
+    __shared__ float s_in_b[EC];      // b == 1: 2 step / s_u^2 * w
+    __shared__ float s_in_is2[EC];
+    __shared__ uint32_t s_pos[CH + 1];
+    const CeDev c = a.c;
+    const int lane = threadIdx.x;
+    // row access: exact dimension = vector loads of the whole row; PAD = asked_dim < DIM, the registers beyond
+    // asked_dim stay 0 (they add nothing to a distance and never move)
+    auto ld = [&](uint32_t node, float* out) {
+        if constexpr (!PAD) load_row_fresh<DIM>(c.y, node, out);
+        else {
+            const float* p = c.y + (uint64_t)node * c.dim;
+#pragma unroll
+            for (int t = 0; t < DIM; t++) out[t] = (uint32_t)t < c.dim ? __builtin_nontemporal_load(p + t) : 0.f;
+        }
+    };
+    auto st = [&](uint32_t node, const float* in) {
+        if constexpr (!PAD) store_row_through<DIM>(c.y, node, in);
+        else {
+            float* p = c.y + (uint64_t)node * c.dim;
+#pragma unroll
+            for (int t = 0; t < DIM; t++)
+                if ((uint32_t)t < c.dim) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    const bool hub = c.hub_odds != nullptr;
+    const uint64_t nodes_owned = c.node_hi - c.node_lo;
+    const uint64_t local0 = blockIdx.x * 64ull;
+    const uint64_t local = local0 + (uint64_t)lane;
+    const bool valid = local < nodes_owned;
+    const uint32_t v = (uint32_t)(c.node_lo + (valid ? local : nodes_owned - 1));
+    uint64_t ib;
+    uint32_t k;
+    if (c.uniform_k) { ib = (uint64_t)v * c.uniform_k; k = c.uniform_k; }
+    else { ib = c.indptr[v]; k = (uint32_t)(c.indptr[v + 1] - ib); }
+    const uint32_t rk = round_hash_key(a.round_key, c.seed);
+    const float step2 = 2.0f * a.step;
+    unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tk_begin = tk0;
+#define AE_TICK(i) if (a.prof) { const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); tk_acc[i] += tk1 - tk0; tk0 = tk1; }
+    // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
+    // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
+    const uint32_t v0 = (uint32_t)(c.node_lo + local0);
+    const uint64_t n_here = (nodes_owned - local0) < 64ull ? (nodes_owned - local0) : 64ull;
+    const uint64_t t_begin = a.tptr[v0], t_end = a.tptr[v0 + n_here];
+    const uint64_t tb_v = valid ? a.tptr[v] : 0ull, te_v = valid ? a.tptr[v + 1] : 0ull;
+    InEdge recA[NQ], recB[NQ];
+    auto load_recs = [&](uint64_t cb, InEdge* rec) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint64_t x = cb + (uint64_t)(lane * NQ + q);
+            rec[q] = a.tin[x < t_end ? x : t_begin];
+        }
+    };
+    if (t_begin < t_end) load_recs(t_begin, recA);
+    // ---- stage A: the node's row in registers (rejection test) and in an LDS column private to the lane
+    // (dynamic index, no barrier needed), cumulative Poisson counts of the out-edges packed 4 per register
+    uint32_t nbr_reg[KMAX], cumP[KP];
+    uint32_t nv;
+    {
+        float pr[KMAX], mu[KMAX], u[KMAX];
+        uint32_t cnt[KMAX];
+#pragma unroll
+        for (int m = 0; m < KMAX; m++) {  // unconditional loads (clamped index): all in flight together
+            const uint32_t mm = (uint32_t)m < k ? (uint32_t)m : k - 1u;
+            nbr_reg[m] = c.nbr[ib + mm];
+            pr[m] = c.proba[ib + mm];
+        }
+#pragma unroll
+        for (int m = 0; m < KMAX; m++) {
+            const bool has = (uint32_t)m < k;
+            nbr_reg[m] = has ? nbr_reg[m] : 0xFFFFFFFFu;  // the pad never equals a candidate
+            pr[m] = has ? pr[m] : 0.f;
+            s_nbr[m * LS + lane] = nbr_reg[m];
+            s_w[m * LS + lane] = pr[m];
+            mu[m] = (has && valid) ? a.unit * pr[m] : 0.f;
+            u[m] = edge_uniform(ib + m, rk);
+        }
+        poisson_batch<KMAX>(u, mu, cnt);
+        uint32_t run = 0;
+#pragma unroll
+        for (int m = 0; m < KMAX; m++) {  // inclusive prefix, saturated at 127 (SWAR search below; Poisson(12) never gets there)
+            run += cnt[m];
+            run = run < 127u ? run : 127u;
+            if (m % 4 == 0) cumP[m / 4] = run;
+            else cumP[m / 4] |= run << (8 * (m % 4));
+        }
+        nv = run;
+    }
+    uint32_t nmax = nv;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    float yv[DIM];
+    ld(v, yv);
+    const float s_v = c.emb_scale[v];
+    const float inv_s2 = rcp(s_v * s_v);
+    const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
+    AE_TICK(0)
+    // ---- stage B.  prepare(t0): node sets of samples t0 .. t0+S-1 and their 6 S gathers;  replay(): the
+    // dependent updates.  The gathers of chunk i+1 are in flight while chunk i is replayed.
+    struct Chunk {
+        float rows[S][6][DIM];
+        float ws[S];
+        uint32_t act;
+    };
+    auto prepare = [&](uint32_t t0, Chunk& ck) {
+        uint32_t idx[S][6];
+        uint32_t need = 0;  // bit s * 8 + g: draw (s, g) still has to be (re)drawn
+        ck.act = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const uint32_t t = t0 + (uint32_t)s;  // wave-uniform
+            const bool act = t < nv;
+            // sampled edge of sample t: the first m with cum[m] > t, i.e. KMAX - #{m : cum[m] > t}; bytes < 128,
+            // so byte + (127 - t) carries into bit 7 exactly when cum[m] > t
+            const uint32_t bias = (127u - (t < 127u ? t : 127u)) * 0x01010101u;
+            uint32_t above = 0;
+#pragma unroll
+            for (int q = 0; q < KP; q++) above += (uint32_t)__builtin_popcount((cumP[q] + bias) & 0x80808080u);
+            uint32_t m_s = (uint32_t)KMAX - above;
+            m_s = m_s < (uint32_t)KMAX ? m_s : (uint32_t)KMAX - 1u;
+            idx[s][0] = s_nbr[m_s * LS + lane];
+            ck.ws[s] = s_w[m_s * LS + lane];
+            if (act) { ck.act |= 1u << s; need |= 0x3Eu << (8 * s); }
+        }
+        auto draw = [&](auto hub_tag) {
+            constexpr bool HUB = decltype(hub_tag)::value;
+#pragma nounroll
+            for (uint32_t attempt = 0; attempt < 16u; attempt++) {  // embedder.rs:1241-1253; one pass unless a draw is rejected
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const uint32_t j = idx[s][0];
+#pragma unroll
+                    for (int g = 1; g <= 5; g++) {
+                        const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
+                        uint32_t cand;
+                        if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
+                            const uint32_t x = __umulhi(w0, (uint32_t)c.n);
+                            const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                            cand = (uu < c.hub_odds[x]) ? x : c.hub_alias[x];
+                        } else {
+                            cand = __umulhi(w0, (uint32_t)c.n);  // :1121
+                        }
+                        // reject k in {i, j} or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85): min over xors is 0
+                        uint32_t acc = (cand ^ v) < (cand ^ j) ? (cand ^ v) : (cand ^ j);
+#pragma unroll
+                        for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
+                        const uint32_t bit = 1u << (8 * s + g);
+                        const bool mine = (need & bit) != 0u;
+                        idx[s][g] = (mine || attempt == 0u) ? cand : idx[s][g];
+                        need = (mine && acc != 0u) ? (need & ~bit) : need;
+                    }
+                }
+                if (!__any(need != 0u)) break;
+            }
+        };
+        if (hub) draw(std::true_type{});
+        else draw(std::false_type{});
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const bool act = (ck.act >> s) & 1u;
+#pragma unroll
+            for (int g = 0; g < 6; g++) ld(act ? idx[s][g] : v, ck.rows[s][g]);
+        }
+    };
+    auto replay = [&](const Chunk& ck) {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const bool act = (ck.act >> s) & 1u;
+            float grad[DIM];
+            {   // attraction, the y_i half of embedder.rs:1207-1237
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < DIM; q++) { const float df = yv[q] - ck.rows[s][0][q]; d += df * df; }
+                float cij = attract_coeff<DIM, B1>(d, ck.ws[s], inv_s2, step2, a.step, a.b);
+                cij = (act && d > 0.f) ? cij : 0.f;
+#pragma unroll
+                for (int q = 0; q < DIM; q++) { grad[q] = (ck.rows[s][0][q] - yv[q]) * cij; yv[q] -= grad[q]; }
+            }
+#pragma unroll
+            for (int g = 1; g <= 5; g++) {  // 5 repulsions, :1267-1297
+                float dk = 0.f;
+#pragma unroll
+                for (int q = 0; q < DIM; q++) { const float df = yv[q] - ck.rows[s][g][q]; dk += df * df; }
+                const float cik = repulse_coeff<DIM, B1>(dk, inv_s2, step2, a.step, a.b);
+                const bool upd = dk > 0.f;  // else `gradient` keeps its previous value (reference quirk B4)
+#pragma unroll
+                for (int q = 0; q < DIM; q++) {
+                    const float gn = (ck.rows[s][g][q] - yv[q]) * cik;
+                    grad[q] = upd ? gn : grad[q];
+                    yv[q] -= act ? grad[q] : 0.f;
+                }
+            }
+        }
+    };
+    if constexpr (DIM <= 16) {
+        Chunk cA, cB;
+#pragma nounroll
+        for (uint32_t t0 = 0; t0 < nmax + S; t0 += S) {  // iteration i prepares chunk i and replays chunk i - 1
+            if (t0 < nmax) prepare(t0, cB);
+            AE_TICK(1)
+            if (t0 > 0) {
+                replay(cA);
+                // optional write-through after every chunk (AE_CE_STORE=0, see ce_node.hip)
+                if (a.store_mode != 2 && valid && cA.act) st(v, yv);
+            }
+            cA = cB;
+            AE_TICK(2)
+        }
+    } else {  // 32 padded columns: one chunk in registers at a time
+        Chunk cA;
+#pragma nounroll
+        for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
+            prepare(t0, cA);
+            replay(cA);
+            if (a.store_mode != 2 && valid && cA.act) st(v, yv);
+        }
+    }
+    if (a.store_mode == 2 && valid && nv) st(v, yv);
+    // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,
+    // gathers of the sources' rows, an exclusive scan of the counts = position of every push in the list of
+    // pushes of the pass (zero counts vanish, a count of c takes c slots, a node's pushes are contiguous since
+    // the records are sorted by target); the list is parked in LDS in windows of EC pushes.
+    bool any_push = false;
+    if (t_begin < t_end) {
+        uint32_t cn[NQ];
+        float yu[NQ][DIM];
+        auto count_and_gather = [&](uint64_t cb) {
+            float mu[NQ], u[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const bool in = cb + (uint64_t)(lane * NQ + q) < t_end;
+                mu[q] = in ? a.unit * recA[q].w : 0.f;
+                u[q] = edge_uniform(recA[q].eid, rk);
+            }
+            poisson_batch<NQ>(u, mu, cn);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) ld(cn[q] ? recA[q].src : v, yu[q]);
+        };
+        if (t_begin + CH < t_end) load_recs(t_begin + CH, recB);
+        count_and_gather(t_begin);
+#pragma nounroll
+        for (uint64_t cb = t_begin; cb < t_end; cb += CH) {
+            // exclusive scan over the pass (lane-major record order)
+            uint32_t mine_tot = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) mine_tot += cn[q];
+            uint32_t incl = mine_tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); incl += lane >= off ? o : 0u; }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t pos[NQ];
+            {
+                uint32_t run = incl - mine_tot;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) { pos[q] = run; s_pos[lane * NQ + q] = run; run += cn[q]; }
+            }
+            if (lane == 0) s_pos[CH] = total;
+            float pa[NQ], pb[NQ], pis2[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                pis2[q] = rcp(recA[q].s_src * recA[q].s_src);
+                pa[q] = B1 ? step2 * pis2[q] * (1.f - recA[q].w) : recA[q].w;
+                pb[q] = B1 ? step2 * pis2[q] * recA[q].w : 0.f;
+            }
+            const uint64_t lo = tb_v > cb ? tb_v : cb;
+            const uint64_t hi = te_v < cb + CH ? te_v : cb + CH;
+            const bool has_range = hi > lo;
+            const bool more = cb + CH < t_end;
+#pragma nounroll
+            for (uint32_t w0 = 0; w0 < total; w0 += EC) {  // one window unless the pass holds more than EC pushes
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    for (uint32_t r = 0; r < cn[q]; r++) {
+                        const uint32_t e = pos[q] + r - w0;  // wraps below the window
+                        if (e < (uint32_t)EC) {
+#pragma unroll
+                            for (int t = 0; t < DIM; t++) s_in_row[e * DIM + t] = yu[q][t];
+                            s_in_a[e] = pa[q];
+                            s_in_b[e] = pb[q];
+                            s_in_is2[e] = pis2[q];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (more && w0 + EC >= total) {  // last window: the next pass's counts and rows are in flight during the replay
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) recA[q] = recB[q];
+                    count_and_gather(cb + CH);
+                    if (cb + 2 * CH < t_end) load_recs(cb + 2 * CH, recB);
+                }
+                AE_TICK(3)
+                uint32_t pbeg = 0, pend = 0;
+                if (has_range) { pbeg = s_pos[(uint32_t)(lo - cb)]; pend = s_pos[(uint32_t)(hi - cb)]; }
+                pbeg = pbeg > w0 ? pbeg : w0;
+                pend = pend < w0 + EC ? pend : w0 + EC;
+                const uint32_t len = pend > pbeg ? pend - pbeg : 0u;
+                uint32_t lmax = len;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(lmax, off); lmax = o > lmax ? o : lmax; }
+                lmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)lmax);
+                const uint32_t e0 = len ? pbeg - w0 : 0u;
+                constexpr int U = 4;
+#pragma nounroll
+                for (uint32_t i0 = 0; i0 < lmax; i0 += U) {
+                    float ru[U][DIM], au[U], bu[U], su[U];
+                    bool on[U];
+#pragma unroll
+                    for (int q = 0; q < U; q++) {
+                        on[q] = i0 + (uint32_t)q < len;
+                        const uint32_t e = on[q] ? e0 + i0 + (uint32_t)q : 0u;
+#pragma unroll
+                        for (int t = 0; t < DIM; t++) ru[q][t] = s_in_row[e * DIM + t];
+                        au[q] = s_in_a[e];
+                        bu[q] = s_in_b[e];
+                        su[q] = s_in_is2[e];
+                    }
+#pragma unroll
+                    for (int q = 0; q < U; q++) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int t = 0; t < DIM; t++) { const float df = yv[t] - ru[q][t]; d += df * df; }
+                        float cij;
+                        if constexpr (B1) {
+                            const float delta = d * su[q];
+                            const float M = fmaxf(delta * delta, 1.0f / kProbaMin);
+                            cij = fmaxf((au[q] - bu[q] * M) * rcp((1.f + delta) * M), -0.49f);
+                        } else {
+                            cij = attract_coeff<DIM, false>(d, au[q], su[q], step2, a.step, a.b);
+                        }
+                        cij = (on[q] && d > 0.f) ? cij : 0.f;
+#pragma unroll
+                        for (int t = 0; t < DIM; t++) yv[t] += (yv[t] - ru[q][t]) * cij;
+                    }
+                }
+                any_push |= len != 0u;
+                if (a.store_mode != 2 && valid && len) st(v, yv);
+                __syncthreads();
+                AE_TICK(4)
+            }
+            if (more && total == 0u) {  // no window ran: advance the pipeline here
+#pragma unroll
+                for (int q = 0; q < NQ; q++) recA[q] = recB[q];
+                count_and_gather(cb + CH);
+                if (cb + 2 * CH < t_end) load_recs(cb + 2 * CH, recB);
+            }
+        }
+    }
+    if (a.store_mode == 2 && any_push && valid) st(v, yv);
+    // samples drawn: one atomic per wave, spread over 1024 counters (a single address serialises at ~12 ns each)
+    unsigned long long mine = valid ? (unsigned long long)nv : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0 && mine) atomicAdd(&a.sample_counter[blockIdx.x & 1023u], mine);
+    if (a.prof && lane == 0) {
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; i++) atomicAdd(&a.prof[i], tk_acc[i]);
+        atomicAdd(&a.prof[5], tend - tk_begin);
+        atomicAdd(&a.prof[6], 1ull);
+    }
+#undef AE_TICK
+}
+
+
+template <int DIM, bool PAD, int KMAX>
+void launch_round_node_k(const NodeArgs& a, uint64_t nodes) {
+    const unsigned grid = blocks_for(nodes, 64);
+    if (a.b == 1.0f) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, true, KMAX>), dim3(grid), dim3(64), 0, stream(), a);
+    else if constexpr (KMAX == 16 || KMAX == 32) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, false, KMAX>), dim3(grid), dim3(64), 0, stream(), a);
+    else fail(AE_ERR_INVALID_ARG, "ce_round_node_kernel: b != 1 is instantiated for KMAX 16 / 32 only");
+}
+// rows of <= 8 / 12 / 16 / 24 / 32 neighbours (the exponent b != 1 only for 16 / 32: its powf code is large)
+template <int DIM, bool PAD>
+void launch_round_node_dim(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
+    const uint32_t k = o->g->max_nbng;
+    const bool b1 = a.b == 1.0f;
+    if (k <= 8 && b1) launch_round_node_k<DIM, PAD, 8>(a, nodes);
+    else if (k <= 12 && b1) launch_round_node_k<DIM, PAD, 12>(a, nodes);
+    else if (k <= 16) launch_round_node_k<DIM, PAD, 16>(a, nodes);
+    else if (k <= 24 && b1) launch_round_node_k<DIM, PAD, 24>(a, nodes);
+    else launch_round_node_k<DIM, PAD, 32>(a, nodes);
+}
+}  // namespace ae

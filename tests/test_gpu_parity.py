@@ -252,6 +252,43 @@ def test_hogwild_statistics_match_oracle(A, oracle):
     assert np.quantile(lr, 0.5) > 1.4 * np.quantile(lo, 0.5)
 
 
+@pytest.mark.parametrize("dim,k,hub", [(5, 8, False), (10, 20, True), (20, 28, False), (3, 32, False), (7, 12, True)])
+def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub):
+    """asked_dim without an exact kernel instantiation (run zero-padded to 8 / 16 / 32 columns) and rows of up to 32
+    neighbours: same statistical bar as the 2-D case against the oracle's sequential run."""
+    n = 4000
+    indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    y0 = oracle.set_data_box(np.random.default_rng(dim).normal(size=(n, dim)).astype(np.float32), 10.0)
+    hubc = g.hubness() if hub else None
+    par = A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub)
+    eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), par, y0, hub_counts=hubc)
+    nb_sample = 10 * len(nbr)
+    for it in range(1, 6):
+        eo.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
+    y, ce1 = eo.get_embedded(), eo.ce_compute_threaded()
+    yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc)
+    assert np.isfinite(y).all() and y.shape == (n, dim)
+    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
+    src = np.repeat(np.arange(n), k)
+    lg = np.linalg.norm(y[src] - y[nbr], axis=1)
+    lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
+    for q in (0.5, 0.9):
+        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.2 * np.quantile(lo, q), (q, np.quantile(lg, q), np.quantile(lo, q))
+
+
+def test_hogwild_unsupported_shape_fails_loudly(A, oracle):
+    indptr, nbr, dist, _, _ = synthetic_graph(n=600, dim=6, k=6, seed=1, ncomp=1)
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(600, 40)).astype(np.float32), 10.0)
+    eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=40), y0)
+    with pytest.raises(A.AnnembedError) as e:  # no silent fall-back to the racy per-sample kernel
+        eo.gradient_iteration_threaded(1000, 1.0, 1)
+    assert e.value.code == 1
+
+
 # ------------------------------------------------------------------------------------------------
 # a3-a9 diffusion maps
 # ------------------------------------------------------------------------------------------------
