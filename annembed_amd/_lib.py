@@ -43,6 +43,14 @@ class CEmbedderParams(C.Structure):
     ]
 
 
+class CQualityReport(C.Structure):
+    _fields_ = [
+        ("nb_nodes", C.c_uint64), ("nb_edges", C.c_uint64), ("kgraph_nbng", C.c_uint32), ("nbng", C.c_uint32),
+        ("nb_without_match", C.c_uint64), ("mean_nbmatch", C.c_double), ("radii_quantiles", C.c_double * 6),
+        ("ratio_quantiles", C.c_double * 6), ("median_ratio", C.c_double), ("mean_ratio", C.c_double), ("quality", C.c_double),
+    ]
+
+
 class CDiffusionParams(C.Structure):
     _fields_ = [
         ("asked_dim", C.c_uint64), ("alfa", C.c_float), ("beta", C.c_float), ("epsil", C.c_float), ("t", C.c_float),
@@ -123,6 +131,8 @@ SIGNATURES = {
     "ae_embedder_get_initial_embedding": [_vp, _vp],
     "ae_embedder_get_hubness": [_vp, _vp],
     "ae_embedder_get_cross_entropy": [_vp, _P(_f64), _P(_f64)],
+    "ae_quality_estimate_from_edge_length": [_vp, _vp, _u32, _u32, _P(CQualityReport), _vp, _vp],
+    "ae_embedder_get_quality_estimate_from_edge_length": [_vp, _u32, _P(CQualityReport), _vp, _vp],
 }
 STRING_GETTERS = ["ae_last_error_message", "ae_version"]
 

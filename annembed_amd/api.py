@@ -548,3 +548,47 @@ class Embedder(_Handle):
         a, b = C.c_double(), C.c_double()
         check(L.load().ae_embedder_get_cross_entropy(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def get_quality_estimate_from_edge_length(self, nbng):
+        """Embedder::get_quality_estimate_from_edge_length, src/embedder.rs:620-753 -> QualityReport"""
+        n = self.get_nb_nodes()
+        rep = L.CQualityReport()
+        ratio, first = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        check(L.load().ae_embedder_get_quality_estimate_from_edge_length(self._h, int(nbng), C.byref(rep), ptr(ratio), ptr(first)))
+        return QualityReport(rep, ratio, first)
+
+
+QUALITY_PROBAS = (0.05, 0.25, 0.5, 0.75, 0.85, 0.95)
+
+
+class QualityReport:
+    """the figures get_quality_estimate_from_edge_length logs / prints (src/embedder.rs:690-731) and the two per-node
+    vectors it dumps to continuity_ratio.csv / first_dist.csv (:735-747)"""
+
+    def __init__(self, rep, ratio_by_node, first_dist):
+        self.nb_nodes, self.nb_edges = int(rep.nb_nodes), int(rep.nb_edges)
+        self.kgraph_nbng, self.nbng = int(rep.kgraph_nbng), int(rep.nbng)
+        self.nb_without_match, self.mean_nbmatch = int(rep.nb_without_match), float(rep.mean_nbmatch)
+        self.radii_quantiles = np.array(list(rep.radii_quantiles))
+        self.ratio_quantiles = np.array(list(rep.ratio_quantiles))
+        self.median_ratio, self.mean_ratio, self.quality = float(rep.median_ratio), float(rep.mean_ratio), float(rep.quality)
+        self.ratio_by_node, self.first_dist = ratio_by_node, first_dist
+
+    def __str__(self):  # the reference's text, :695-731
+        fq = lambda q: " , ".join("%.2g : %.2e" % (p, v) for p, v in zip(QUALITY_PROBAS, q))
+        return ("\n a guess at quality\n  neighbourhood size used in embedding : %d\n  nb neighbourhoods without a match : %d,  "
+                "mean number of neighbours conserved when match : %.3e\n  embedded radii quantiles at %s\n\n statistics on "
+                "conservation of neighborhood (of size nbng)\n  neighbourhood size used in target space : %d\n  quantiles at %s\n"
+                "  neighborhood are conserved in radius multiplied by median  : %.2e, mean %.2e" %
+                (self.kgraph_nbng, self.nb_without_match, self.mean_nbmatch, fq(self.radii_quantiles), self.nbng,
+                 fq(self.ratio_quantiles), self.median_ratio, self.mean_ratio))
+
+
+def quality_estimate_from_edge_length(kgraph, y, nbng):
+    """stage-level entry: the same estimate for any embedding y (n x d, node order of the graph)"""
+    y = _f32(y)
+    n = y.shape[0]
+    rep = L.CQualityReport()
+    ratio, first = np.zeros(n, np.float64), np.zeros(n, np.float64)
+    check(L.load().ae_quality_estimate_from_edge_length(kgraph.handle, ptr(y), y.shape[1], int(nbng), C.byref(rep), ptr(ratio), ptr(first)))
+    return QualityReport(rep, ratio, first)

@@ -261,6 +261,16 @@ int32_t ae_embedder_get_hubness(const ae_embedder* e, uint32_t* counts) {
         memcpy(counts, e->hubness.data(), sizeof(uint32_t) * e->hubness.size());
     });
 }
+int32_t ae_embedder_get_quality_estimate_from_edge_length(const ae_embedder* e, uint32_t nbng, ae_quality_report* rep,
+                                                          double* ratio_by_node, double* first_dist) {
+    if (!e || !e->done) {  // "cannot ask for embedded quality before embedding", embedder.rs:633-636
+        set_last_error("get_quality_estimate_from_edge_length called before embed()");
+        return e ? AE_ERR_STATE : AE_ERR_INVALID_ARG;
+    }
+    const ae_kgraph* g = e->g ? e->g : e->proj->large_graph;  // :481-487
+    return ae_quality_estimate_from_edge_length(g, e->embedding.data(), (uint32_t)(e->embedding.size() / e->n), nbng, rep, ratio_by_node,
+                                                first_dist);
+}
 int32_t ae_embedder_get_cross_entropy(const ae_embedder* e, double* before, double* after) {
     return guard([&] {
         if (!e) fail(AE_ERR_INVALID_ARG, "null argument");

@@ -334,6 +334,36 @@ int32_t ae_embedder_get_hubness(const ae_embedder *e, uint32_t *counts);      /*
 /* CE before / after the gradient iterations (logged by the reference at :846-886) */
 int32_t ae_embedder_get_cross_entropy(const ae_embedder *e, double *before, double *after);
 
+/* ------------------------------------------------------------------------------------------------
+ * Quality estimate: Embedder::get_quality_estimate_from_edge_length,
+ * src/embedder.rs:620-753 (+ get_transformed_kgraph :478-522, get_max_edge_length_embedded_kgraph
+ * :527-554, KGraph::compute_max_edge src/fromhnsw/kgraph.rs:167-183).
+ * The numbers the reference logs / prints at :690-731.  The radius of a node is the distance of its
+ * nbng-th neighbour in the EMBEDDED space: exact here (device brute force), an hnsw_rs approximation
+ * in the reference; quantiles are exact order statistics at rank floor(q*count) (CKMS eps = 0.01 in
+ * the reference). `quality` is 0 as in the reference (:630, :751).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ae_quality_report {
+    uint64_t nb_nodes, nb_edges;
+    uint32_t kgraph_nbng;        /* "neighbourhood size used in embedding"                       */
+    uint32_t nbng;               /* "neighbourhood size used in target space"                    */
+    uint64_t nb_without_match;   /* neighbourhoods without a match                               */
+    double mean_nbmatch;         /* mean number of neighbours conserved when match               */
+    double radii_quantiles[6];   /* embedded radii at 0.05 0.25 0.5 0.75 0.85 0.95               */
+    double ratio_quantiles[6];   /* embedded edge length / radius, same probabilities            */
+    double median_ratio, mean_ratio;
+    double quality;
+} ae_quality_report;
+/* y: n x dim row-major embedding in the node order of g.  ratio_by_node[n] ("continuity_ratio.csv",
+   :743) and first_dist[n] ("first_dist.csv", :735) may be NULL. */
+int32_t ae_quality_estimate_from_edge_length(const ae_kgraph *g, const float *y, uint32_t dim,
+                                             uint32_t nbng, ae_quality_report *rep,
+                                             double *ratio_by_node, double *first_dist);
+/* same on an Embedder after embed(): its kgraph (or the large graph of its projection, :481-487) */
+int32_t ae_embedder_get_quality_estimate_from_edge_length(const ae_embedder *e, uint32_t nbng,
+                                                          ae_quality_report *rep,
+                                                          double *ratio_by_node, double *first_dist);
+
 #ifdef __cplusplus
 }
 #endif

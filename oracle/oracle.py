@@ -547,3 +547,56 @@ def h_embed(small, large, proj_node, proj_dist, params, hogwild_threads=None):
     y, ce0, ce1 = entropy_optimize(indptr, nbr, proba, scale, y0, params.nb_grad_batch, params.nb_sampling_by_edge,
                                    params.grad_step, params.b, params.seed, params.sampler, hub, hogwild_threads)
     return 0, dict(y=y, y0=y0, ce_before=ce0, ce_after=ce1, hubness=hub, first=res1)
+
+
+# ------------------------------------------------------------------------------------------------
+# quality estimate
+# ------------------------------------------------------------------------------------------------
+QUALITY_PROBAS = (0.05, 0.25, 0.5, 0.75, 0.85, 0.95)
+
+
+def _distl2_f32(a, b):
+    """distl2, src/embedder.rs:54-65: f32 sum of squares in coordinate order, sqrt"""
+    s = np.zeros(a.shape[0], np.float32)
+    for t in range(a.shape[1]):
+        df = (a[:, t] - b[:, t]).astype(np.float32)
+        s = (s + df * df).astype(np.float32)
+    return np.sqrt(s).astype(np.float32)
+
+
+def quality_estimate(indptr, nbr, y, nbng):
+    """get_quality_estimate_from_edge_length, src/embedder.rs:620-753, with get_transformed_kgraph (:478-522: running
+    minimum of the embedded edge lengths in neighbour order, then sorted) and the radius of
+    get_max_edge_length_embedded_kgraph (:527-554) taken from the EXACT nbng-nearest-neighbour graph of the embedded
+    points (the reference's hnsw_rs graph is approximate: parity unpinned); exact order statistics at rank
+    floor(q * count) stand for the CKMS(0.01) sketches."""
+    from scipy.spatial import cKDTree
+    y = np.ascontiguousarray(y, np.float32)
+    n = y.shape[0]
+    indptr = np.asarray(indptr, np.int64)
+    nbr = np.asarray(nbr, np.int64)
+    src = np.repeat(np.arange(n), np.diff(indptr))
+    d = _distl2_f32(y[src], y[nbr])
+    tw = np.empty_like(d)
+    for i in range(n):  # :499-512
+        b, e = indptr[i], indptr[i + 1]
+        tw[b:e] = np.minimum.accumulate(d[b:e])[::-1]
+    # candidates from a k-d tree, distances recomputed with the f32 arithmetic of the device path
+    _, idx = cKDTree(y.astype(np.float64)).query(y.astype(np.float64), k=nbng + 3)
+    radius = np.zeros(n, np.float64)
+    for c0 in range(0, n, 4096):
+        c1 = min(n, c0 + 4096)
+        cand = idx[c0:c1]
+        dd = np.stack([_distl2_f32(y[c0:c1], y[cand[:, t]]) for t in range(cand.shape[1])], 1)
+        dd[cand == np.arange(c0, c1)[:, None]] = np.inf
+        radius[c0:c1] = np.sort(dd, axis=1)[:, nbng - 1].astype(np.float64)
+    ratio = tw.astype(np.float64) / radius[src]
+    match = np.add.reduceat((tw.astype(np.float64) <= radius[src]).astype(np.int64), indptr[:-1])
+    nb_without = int((match == 0).sum())
+    q = lambda v: np.array([np.sort(v)[min(len(v) - 1, int(p * len(v)))] for p in QUALITY_PROBAS])
+    return {
+        "nb_without_match": nb_without, "mean_nbmatch": match.sum() / max(1, n - nb_without),
+        "radii_quantiles": q(radius), "ratio_quantiles": q(ratio), "median_ratio": q(ratio)[2], "mean_ratio": ratio.mean(),
+        "ratio_by_node": np.add.reduceat(ratio, indptr[:-1]) / np.maximum(1, np.diff(indptr)), "first_dist": tw[indptr[:-1]].astype(np.float64),
+        "radius": radius,
+    }

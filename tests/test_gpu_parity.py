@@ -557,3 +557,35 @@ def test_device_coords_alias_and_sharded_hogwild(A, oracle, graph):
     ce_full = full.ce_compute_threaded()
     ce_sh = sum(eo.ce_compute_threaded() for _, _, eo in shards)
     assert abs(ce_sh - ce_full) < 0.2 * ce_full  # replicas are refreshed once per batch only
+
+
+# ------------------------------------------------------------------------------------------------
+# 8f-1 quality estimate
+# ------------------------------------------------------------------------------------------------
+def test_quality_estimate_vs_oracle(A, oracle, graph):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    emb = A.Embedder(g, A.EmbedderParams(nb_grad_batch=4))
+    assert emb.embed() == 1
+    rep = emb.get_quality_estimate_from_edge_length(20)
+    y = emb.get_embedded()
+    o = oracle.quality_estimate(indptr, nbr, y, 20)
+    assert rep.nb_nodes == 2500 and rep.kgraph_nbng == 8 and rep.nbng == 20 and rep.quality == 0.0
+    assert np.array_equal(rep.first_dist, o["first_dist"])  # f32 arithmetic in the same order: bit exact
+    assert np.allclose(rep.ratio_by_node, o["ratio_by_node"], rtol=1e-12)
+    assert rep.nb_without_match == o["nb_without_match"] and abs(rep.mean_nbmatch - o["mean_nbmatch"]) < 1e-12
+    assert np.allclose(rep.radii_quantiles, o["radii_quantiles"], rtol=1e-12)
+    assert np.allclose(rep.ratio_quantiles, o["ratio_quantiles"], rtol=1e-12)
+    assert abs(rep.mean_ratio - o["mean_ratio"]) < 1e-9 * o["mean_ratio"] and rep.median_ratio == rep.ratio_quantiles[2]
+    # stage-level entry on an arbitrary embedding, ragged rows
+    ip2 = np.concatenate([[0], np.cumsum(np.where(np.arange(2500) % 3 == 0, 5, 8))]).astype(np.uint64)
+    keep = np.concatenate([np.arange(int(indptr[i]), int(indptr[i]) + (5 if i % 3 == 0 else 8)) for i in range(2500)])
+    g2 = A.KGraph(ip2, nbr[keep], dist[keep])
+    y2 = np.random.default_rng(5).normal(size=(2500, 3)).astype(np.float32)
+    r2 = A.quality_estimate_from_edge_length(g2, y2, 7)
+    o2 = oracle.quality_estimate(ip2, nbr[keep], y2, 7)
+    assert r2.nb_without_match == o2["nb_without_match"] and np.allclose(r2.ratio_quantiles, o2["ratio_quantiles"], rtol=1e-12)
+    assert np.array_equal(r2.first_dist, o2["first_dist"])
+    assert "a guess at quality" in str(r2)
+    with pytest.raises(A.AnnembedError):
+        A.Embedder(g, A.EmbedderParams()).get_quality_estimate_from_edge_length(10)  # before embed(): embedder.rs:633-636
