@@ -8,12 +8,13 @@ calling it without a GPU, fails loudly.
 from ._lib import (AE_CE_HOGWILD, AE_CE_SAMPLE_RACY, AE_CE_SEQUENTIAL, AE_SAMPLER_ALIAS, AE_SAMPLER_ROWCDF, AnnembedError, LIB_PATH,  # noqa: F401
                    load)
 from .api import (DiffusionMaps, DiffusionParams, Embedder, EmbedderParams, EntropyOptim, GraphLaplacian, KGraph,  # noqa: F401
-                  KGraphProjection, MatRepr, NodeParams, QualityReport, RangeRank, SvdApprox, SvdResult, entropy_optimize,
-                  quality_estimate_from_edge_length, set_data_box, subspace_iteration, to_proba_edges, transpose_dense_mult_csr)
+                  KGraphProjection, MatRepr, NodeParams, QualityReport, RangeApprox, RangePrecision, RangeRank, SvdApprox, SvdResult, entropy_optimize,
+                  adaptative_range_finder_matrep, quality_estimate_from_edge_length, set_data_box, subspace_iteration, to_proba_edges, transpose_dense_mult_csr)
 
 __all__ = [
     "KGraph", "KGraphProjection", "NodeParams", "EmbedderParams", "DiffusionParams", "Embedder", "EntropyOptim",
     "DiffusionMaps", "GraphLaplacian", "MatRepr", "RangeRank", "SvdApprox", "SvdResult", "to_proba_edges", "set_data_box",
-    "entropy_optimize", "subspace_iteration", "transpose_dense_mult_csr", "QualityReport", "quality_estimate_from_edge_length",
+    "entropy_optimize", "subspace_iteration", "transpose_dense_mult_csr", "QualityReport", "quality_estimate_from_edge_length", "RangePrecision", "RangeApprox",
+    "adaptative_range_finder_matrep",
     "AnnembedError", "load",
 ]

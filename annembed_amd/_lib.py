@@ -107,6 +107,8 @@ SIGNATURES = {
     "ae_matrepr_destroy": [_vp],
     "ae_subspace_iteration": [_vp, _u64, _u64, _vp, _P(_u64)],
     "ae_svd_approx_rank": [_vp, _u64, _u64, _vp, _vp, _vp, _P(_u64)],
+    "ae_adaptative_range_finder": [_vp, _f64, _u64, _u64, _vp, _P(_u64)],
+    "ae_svd_approx_epsil": [_vp, _f64, _u64, _u64, _vp, _vp, _vp, _P(_u64)],
     "ae_transpose_dense_mult": [_vp, _vp, _u64, _vp],
     "ae_set_data_box": [_vp, _u64, _u64, _f32],
     "ae_entropy_optim_create": [_vp, _vp, _P(CEmbedderParams), _vp, _vp, _u64, _u64, _P(_vp)],

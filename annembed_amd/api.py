@@ -369,6 +369,35 @@ class RangeRank:
         self.rank, self.nbiter = rank, nbiter
 
 
+class RangePrecision:
+    """RangePrecision, src/tools/svdapprox.rs:155-180 (step <= 1 is reset to 2)."""
+
+    def __init__(self, epsil, step, max_rank):
+        self.epsil, self.step, self.max_rank = float(epsil), (2 if step <= 1 else int(step)), int(max_rank)
+
+
+def adaptative_range_finder_matrep(mat, epsil, r, max_rank):
+    """adaptative_range_finder_matrep, src/tools/svdapprox.rs:444-597 -> Q (m, l), l <= max_rank"""
+    m, n = mat.shape
+    cap = min(int(max_rank), 64)
+    q = np.zeros((m, cap), np.float32)
+    lo = C.c_uint64()
+    check(L.load().ae_adaptative_range_finder(mat.handle, float(epsil), int(r), int(max_rank), ptr(q), C.byref(lo)))
+    return np.ascontiguousarray(q.reshape(-1)[:m * lo.value].reshape(m, lo.value))
+
+
+class RangeApprox:
+    """RangeApprox, src/tools/svdapprox.rs:211-266: get_approximator() dispatches on the mode"""
+
+    def __init__(self, mat, mode):
+        self.mat, self.mode = mat, mode
+
+    def get_approximator(self):
+        if isinstance(self.mode, RangePrecision):
+            return adaptative_range_finder_matrep(self.mat, self.mode.epsil, self.mode.step, self.mode.max_rank)
+        return subspace_iteration(self.mat, self.mode.rank, self.mode.nbiter)
+
+
 def subspace_iteration(mat, rank, nbiter):
     """subspace_iteration_full / _csr, src/tools/svdapprox.rs:285-408."""
     m, n = mat.shape
@@ -404,6 +433,13 @@ class SvdApprox:
 
     def direct_svd(self, mode):
         m, n = self.data.shape
+        if isinstance(mode, RangePrecision):  # RangeApproxMode::EPSIL
+            cap = min(mode.max_rank, 64)
+            s, u, vt = np.zeros(cap, np.float32), np.zeros(m * cap, np.float32), np.zeros(cap * n, np.float32)
+            lo = C.c_uint64()
+            check(L.load().ae_svd_approx_epsil(self.data.handle, mode.epsil, mode.step, mode.max_rank, ptr(s), ptr(u), ptr(vt), C.byref(lo)))
+            l = lo.value
+            return SvdResult(s[:l].copy(), u[:m * l].reshape(m, l).copy(), vt[:l * n].reshape(l, n).copy())
         l = min(m, n, mode.rank)
         s = np.zeros(l, np.float32)
         u = np.zeros((m, l), np.float32)

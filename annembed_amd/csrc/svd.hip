@@ -11,6 +11,8 @@
 // instead of failing.  The l x n SVD of B (gesdd at :758) is done the same way through B B^T.
 
 #include "linalg.h"
+#include <cfloat>
+#include <cmath>
 // (after <cstring>: rocprim's texture iterator calls the host memset)
 #include <rocprim/rocprim.hpp>
 #include "philox.h"
@@ -723,9 +725,14 @@ struct SvdOut {
 };
 
 // SvdApprox::direct_svd (RANK mode), svdapprox.rs:721-799
+static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out);
 static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, bool want_vt, SvdOut& out) {
     DevBuf<float> q;
     const uint32_t l = subspace_iteration_device(a, rank, nbiter, q);
+    direct_svd_from_q(a, q, l, want_vt, out);
+}
+// the part of direct_svd after the range approximation Q (m x l), :737-799
+static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out) {
     const uint64_t m = a.nrows, n = a.ncols;
     // B = Q^T A (l x n), kept transposed: Bt = A^T Q (n x l)                       :737-743
     DevBuf<float> bt(n * l);
@@ -816,6 +823,128 @@ void full_svd_leading(ae_matrepr& a, uint32_t rank, std::vector<float>& s, DevBu
     sync();
 }
 
+// ---- adaptative_range_finder_matrep, svdapprox.rs:444-597 (Halko-Martinsson-Tropp algorithm 4.2) ------------
+// Vector-at-a-time, as the reference: r probe vectors y_k = A w_k (w ~ N(0, 1/n)), each iteration turns the
+// oldest into the next basis vector q, replaces it by a fresh probe made orthogonal to Q, removes q from the
+// other probes, and stops when the largest probe norm is below the threshold, at max_rank, or on a vanishing
+// vector.  Q and Y live on the device as row-major panels (m x max_rank, m x r); the two decisions per
+// iteration (||y_j||, max_k ||y_k||) are the only host round trips.
+__global__ void col_dots_kernel(const float* __restrict__ qp, uint32_t ldq, uint32_t nq, const float* __restrict__ y, uint32_t ldy,
+                                uint64_t rows, double* __restrict__ out) {
+    // out[i] += sum_row Q[row, i] * y[row]   (one wave per block of rows, f64 accumulation)
+    const uint32_t i = blockIdx.y;
+    double acc = 0.;
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < rows; row += (uint64_t)gridDim.x * blockDim.x)
+        acc += (double)qp[row * ldq + i] * (double)y[row * ldy];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[i], part[0] + part[1] + part[2] + part[3]);
+    (void)nq;
+}
+__global__ void col_axpy_kernel(float* __restrict__ y, uint32_t ldy, const float* __restrict__ qp, uint32_t ldq, uint32_t nq,
+                                const double* __restrict__ coef, uint64_t rows) {
+    // y[row] -= sum_i Q[row, i] * coef[i]   (orthogonalize_with_q, :975-992)
+    const uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double p = 0.;
+    for (uint32_t i = 0; i < nq; i++) p += (double)qp[row * ldq + i] * coef[i];
+    y[row * ldy] = (float)((double)y[row * ldy] - p);
+}
+__global__ void col_norms2_kernel(const float* __restrict__ y, uint32_t ldy, uint32_t ncol, uint64_t rows, double* __restrict__ out) {
+    const uint32_t k = blockIdx.y;
+    double acc = 0.;
+    for (uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; row < rows; row += (uint64_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[row * ldy + k];
+        acc += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[k], part[0] + part[1] + part[2] + part[3]);
+    (void)ncol;
+}
+__global__ void col_scale_copy_kernel(const float* __restrict__ src, uint32_t lds, float* __restrict__ dst, uint32_t ldd, float scale, uint64_t rows) {
+    const uint64_t row = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (row < rows) dst[row * ldd] = src[row * lds] * scale;
+}
+__global__ void scale_vec_f32_kernel(float* __restrict__ x, uint64_t n, float c) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= c;
+}
+
+uint32_t adaptive_range_finder_device(ae_matrepr& a, double epsil, uint64_t r_arg, uint64_t max_rank_arg, DevBuf<float>& q_out) {
+    const uint64_t m = a.nrows, n = a.ncols;
+    const uint32_t r = (uint32_t)r_arg;
+    if (r < 1 || r > (uint32_t)kMaxL) fail(AE_ERR_INVALID_ARG, "range finder: step must be in 1..%d", kMaxL);
+    if (max_rank_arg == 0) fail(AE_ERR_INVALID_ARG, "range finder: max_rank must be positive");
+    const uint32_t max_rank = (uint32_t)std::min<uint64_t>(max_rank_arg, std::min<uint64_t>((uint64_t)kMaxL, std::min(m, n) + 1));
+    const unsigned rg = std::min<unsigned>(blocks_for(m, 256), 512);
+    DevBuf<float> omega(n * r), yp(m * r), qp(m * (uint64_t)max_rank), wv(n), yv(m);
+    DevBuf<double> coef(kMaxL), norms(kMaxL);
+    std::vector<double> hn(r);
+    auto col_norms = [&]() {  // squared norms of the r probes
+        norms.zero();
+        hipLaunchKernelGGL(col_norms2_kernel, dim3(rg, r), dim3(256), 0, stream(), (const float*)yp.p, r, r, m, norms.p);
+        norms.download(hn.data(), r);
+    };
+    auto orthogonalize = [&](float* y, uint32_t ldy, uint32_t first, uint32_t nq) {  // y -= sum_{i in [first, first+nq)} q_i (q_i . y)
+        if (!nq) return;
+        coef.zero();
+        hipLaunchKernelGGL(col_dots_kernel, dim3(rg, nq), dim3(256), 0, stream(), (const float*)qp.p + first, max_rank, nq, (const float*)y, ldy, m, coef.p);
+        hipLaunchKernelGGL(col_axpy_kernel, dim3(blocks_for(m, 256)), dim3(256), 0, stream(), y, ldy, (const float*)qp.p + first, max_rank, nq,
+                           (const double*)coef.p, m);
+    };
+    const float coeff_norm = (float)(1.0 / std::sqrt((double)n));                       // :481
+    gaussian_fill_device(omega.p, n * r, kDefaultSeed, kTagOmega);                        // :479
+    hipLaunchKernelGGL(scale_vec_f32_kernel, dim3(blocks_for(n * r, 256)), dim3(256), 0, stream(), omega.p, n * r, coeff_norm);
+    mat_mul_panel(a, omega.p, yp.p, r);                                                   // :485-491
+    col_norms();
+    double norm_sup = 0.;
+    for (uint32_t k = 0; k < r; k++) {
+        if (!(hn[k] == hn[k])) fail(AE_ERR_SVD, "adaptative_range_finder: NaN in the probe norms");  // :505-509
+        norm_sup = std::max(norm_sup, std::sqrt(hn[k]));
+    }
+    const double stop_rel = epsil / (10. * std::sqrt(2. * M_PI));                         // :465
+    const double stop_val = norm_sup * stop_rel;                                          // :515
+    const uint64_t max_iter = std::min(m, n);
+    uint32_t nq = 0, j = 0;
+    uint64_t nb_iter = 0;
+    while (norm_sup > stop_val && nb_iter <= max_iter && nq < max_rank) {                 // :517
+        orthogonalize(yp.p + j, r, 0, nq);                                                // :519-521
+        norms.zero();
+        hipLaunchKernelGGL(col_norms2_kernel, dim3(rg, 1), dim3(256), 0, stream(), (const float*)yp.p + j, r, 1u, m, norms.p);
+        double nj2 = 0.;
+        norms.download(&nj2, 1);
+        const double n_j = std::sqrt(nj2);
+        if (n_j < std::sqrt((double)FLT_EPSILON)) break;                                  // :524-532
+        hipLaunchKernelGGL(col_scale_copy_kernel, dim3(blocks_for(m, 256)), dim3(256), 0, stream(), (const float*)yp.p + j, r, qp.p + nq, max_rank,
+                           (float)(1.0 / n_j), m);                                        // :533-535
+        nq++;
+        gaussian_fill_device(wv.p, n, kDefaultSeed, 0xFFFE0000u + (uint32_t)nb_iter);     // :537-538
+        hipLaunchKernelGGL(scale_vec_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), wv.p, n, coeff_norm);
+        mat_mul_panel(a, wv.p, yv.p, 1);                                                  // :539
+        orthogonalize(yv.p, 1, 0, nq);                                                    // :541
+        hipLaunchKernelGGL(col_scale_copy_kernel, dim3(blocks_for(m, 256)), dim3(256), 0, stream(), (const float*)yv.p, 1u, yp.p + j, r, 1.0f, m);  // :544
+        for (uint32_t k = 0; k < r; k++)                                                  // :546-553
+            if (k != j) orthogonalize(yp.p + k, r, nq - 1, 1);
+        col_norms();                                                                      // :555-561
+        norm_sup = 0.;
+        for (uint32_t k = 0; k < r; k++) norm_sup = std::max(norm_sup, std::sqrt(hn[k]));
+        j = (j + 1) % r;
+        nb_iter++;
+    }
+    // compact m x nq copy
+    q_out.alloc(m * (uint64_t)std::max(nq, 1u));
+    if (nq) {
+        AE_HIP(hipMemcpy2DAsync(q_out.p, sizeof(float) * nq, qp.p, sizeof(float) * max_rank, sizeof(float) * nq, m, hipMemcpyDeviceToDevice, stream()));
+    }
+    sync();
+    return nq;
+}
+
 void direct_svd_rank(ae_matrepr& a, uint64_t rank, uint64_t nbiter, std::vector<float>& s, DevBuf<float>& u) {
     SvdOut o;
     direct_svd_device(a, rank, nbiter, false, o);
@@ -894,6 +1023,42 @@ int32_t ae_svd_approx_rank(const ae_matrepr* m, uint64_t rank, uint64_t nbiter, 
             t.download(vt, m->ncols * o.l);
         }
         if (l_out) *l_out = o.l;
+    });
+}
+
+int32_t ae_adaptative_range_finder(const ae_matrepr* m, double epsil, uint64_t r, uint64_t max_rank, float* q, uint64_t* l_out) {
+    return guard([&] {
+        require_device();
+        if (!m || !q || !l_out) fail(AE_ERR_INVALID_ARG, "null argument");
+        DevBuf<float> dq;
+        const uint32_t l = adaptive_range_finder_device(*const_cast<ae_matrepr*>(m), epsil, r, max_rank, dq);
+        if (l) dq.download(q, m->nrows * l);
+        *l_out = l;
+    });
+}
+
+int32_t ae_svd_approx_epsil(const ae_matrepr* m, double epsil, uint64_t step, uint64_t max_rank, float* s, float* u, float* vt,
+                            uint64_t* l_out) {
+    return guard([&] {
+        require_device();
+        if (!m || !s || !l_out) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (step <= 1) step = 2;  // RangePrecision::new, svdapprox.rs:167-179
+        DevBuf<float> dq;
+        ae_matrepr& a = *const_cast<ae_matrepr*>(m);
+        const uint32_t l = adaptive_range_finder_device(a, epsil, step, max_rank, dq);
+        if (l == 0) fail(AE_ERR_SVD, "adaptative range finder returned an empty basis");
+        SvdOut o;
+        direct_svd_from_q(a, dq, l, vt != nullptr, o);
+        memcpy(s, o.s.data(), sizeof(float) * o.l);
+        if (u) o.u.download(u, m->nrows * o.l);
+        if (vt) {
+            DevBuf<float> t(m->ncols * o.l);
+            hipLaunchKernelGGL(transpose_dense_kernel, dim3(blocks_for(m->ncols * o.l, 256)), dim3(256), 0, stream(), o.vtT.p, m->ncols,
+                               (uint64_t)o.l, t.p);
+            check_launch("transpose_dense");
+            t.download(vt, m->ncols * o.l);
+        }
+        *l_out = o.l;
     });
 }
 

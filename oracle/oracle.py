@@ -372,6 +372,62 @@ def direct_svd(mat, rank, nbiter, omega=None):
     return s, u, vt
 
 
+def adaptative_range_finder(mat, epsil, r, max_rank, rng=None):
+    """adaptative_range_finder_matrep, svdapprox.rs:444-597 (Halko-Martinsson-Tropp 4.2), line by line.  `rng`
+    supplies the N(0,1) draws (the reference's Xoshiro stream is unpinned)."""
+    rng = rng if rng is not None else np.random.default_rng(OMEGA_SEED)
+    dot = (lambda v: mat.dot(v.reshape(-1, 1)).reshape(-1)) if isinstance(mat, CsrMat) else (lambda v: mat @ v)
+    dtype = mat.values.dtype if isinstance(mat, CsrMat) else mat.dtype
+    m, n = mat.shape
+    q_mat = []
+    stop_rel = epsil / (10.0 * np.sqrt(2.0 / (1.0 / np.pi)))                   # :465
+    omega = rng.standard_normal((n, r)).astype(dtype) * dtype.type(1.0 / np.sqrt(n))  # :479-482
+    y_vec = [dot(np.ascontiguousarray(omega[:, j])) for j in range(r)]         # :485-491
+    norms = np.array([np.linalg.norm(y) for y in y_vec])
+    if np.isnan(norms).any():
+        raise FloatingPointError("adaptative_range_finder: NaN norms")          # :505-509
+    norm_sup = norms.max()
+    stop_val = norm_sup * stop_rel                                             # :515
+    j = nb_iter = 0
+    max_iter = min(m, n)
+
+    def orth(qs, y):                                                           # orthogonalize_with_q, :975-992
+        if not qs:
+            return y
+        proj = np.zeros_like(y)
+        for it in qs:
+            proj += it * it.dot(y)
+        return y - proj
+
+    while norm_sup > stop_val and nb_iter <= max_iter and len(q_mat) < max_rank:   # :517
+        y_vec[j] = orth(q_mat, y_vec[j])                                       # :519-521
+        n_j = np.linalg.norm(y_vec[j])
+        if n_j < np.sqrt(np.finfo(dtype).eps):                                 # :524-532
+            break
+        q_j = y_vec[j] / n_j
+        q_mat.append(q_j.copy())                                               # :535
+        w = rng.standard_normal(n).astype(dtype) * dtype.type(1.0 / np.sqrt(n))    # :537-538
+        y_vec[j] = orth(q_mat, dot(w))                                         # :539-544
+        for k in range(r):                                                     # :546-553
+            if k != j:
+                y_vec[k] = y_vec[k] - q_j * q_j.dot(y_vec[k])
+        norms = np.array([np.linalg.norm(y) for y in y_vec])                   # :555-561
+        norm_sup = norms.max()
+        j = (j + 1) % r
+        nb_iter += 1
+    return np.ascontiguousarray(np.stack(q_mat, 1)) if q_mat else np.zeros((m, 0), dtype)  # :586-594
+
+
+def direct_svd_epsil(mat, epsil, step, max_rank, rng=None):
+    """SvdApprox::direct_svd with RangeApproxMode::EPSIL(RangePrecision), svdapprox.rs:721-799"""
+    import scipy.linalg as sla
+    step = 2 if step <= 1 else step                                            # RangePrecision::new, :167-179
+    q = adaptative_range_finder(mat, epsil, step, max_rank, rng)
+    b = np.ascontiguousarray(mat.tdot(q).T) if isinstance(mat, CsrMat) else q.T @ mat
+    ub, s, vt = sla.svd(b, full_matrices=False, lapack_driver="gesdd", check_finite=False)
+    return s, q @ ub, vt
+
+
 def svd_full(mat):
     """svd_f32, graphlaplace.rs:296-344: gesdd JobSvd::Some -> s, u."""
     import scipy.linalg as sla

@@ -589,3 +589,41 @@ def test_quality_estimate_vs_oracle(A, oracle, graph):
     assert "a guess at quality" in str(r2)
     with pytest.raises(A.AnnembedError):
         A.Embedder(g, A.EmbedderParams()).get_quality_estimate_from_edge_length(10)  # before embed(): embedder.rs:633-636
+
+
+
+# ------------------------------------------------------------------------------------------------
+# 8f-3 adaptative range finder / RangeApproxMode::EPSIL
+# ------------------------------------------------------------------------------------------------
+def test_svd_wiki_epsil(A):
+    """svdapprox.rs:1459 test_svd_wiki_csr_epsil and :1530 test_svd_wiki_full_epsil (here f32: 1e-5)"""
+    import scipy.sparse as sp
+    wiki = GOLD["wiki"].astype(np.float32)
+    m = sp.csr_matrix(wiki)
+    for mat, max_rank in ((A.MatRepr.from_csrmat(m.indptr, m.indices, m.data, (4, 5)), 10), (A.MatRepr.from_array2(wiki), 4)):
+        res = A.SvdApprox(mat).direct_svd(A.RangePrecision(0.1, 5, max_rank))
+        s = res.get_sigma()
+        assert 3 <= len(s) <= 4
+        for i in range(len(s)):
+            exact = GOLD["wiki_sigma"][i]
+            assert (abs(1 - s[i] / exact) < 1e-5) if exact > 0 else (abs(s[i]) < 1e-5)
+        u, vt = res.get_u(), res.get_vt()
+        assert np.allclose((u * s) @ vt, wiki, atol=1e-5)  # rank 3 matrix: exact reconstruction
+
+
+def test_adaptative_range_finder_vs_oracle(A, oracle):
+    """same stopping rule as the oracle restatement (rank found within the probes' randomness), orthonormal basis,
+    residual ||A - Q Q^T A|| at the level the oracle reaches"""
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((300, 15)) @ rng.standard_normal((15, 700))).astype(np.float32)
+    a += 1e-4 * rng.standard_normal(a.shape).astype(np.float32)
+    q = A.RangeApprox(A.MatRepr.from_array2(a), A.RangePrecision(0.05, 6, 40)).get_approximator()
+    qo = oracle.adaptative_range_finder(a, 0.05, 6, 40)
+    assert q.shape[0] == 300 and abs(q.shape[1] - qo.shape[1]) <= 2 and q.shape[1] >= 15
+    assert np.allclose(q.T @ q, np.eye(q.shape[1]), atol=2e-5)
+    res, reso = np.linalg.norm(a - q @ (q.T @ a)), np.linalg.norm(a - qo @ (qo.T @ a))
+    assert res < 3 * reso + 1e-6 * np.linalg.norm(a), (res, reso)
+    import scipy.sparse as sp
+    sm = sp.random(2000, 1500, density=0.01, random_state=3, dtype=np.float32, format="csr")
+    qs = A.adaptative_range_finder_matrep(A.MatRepr.from_csrmat(sm.indptr, sm.indices, sm.data, sm.shape), 0.1, 5, 30)
+    assert qs.shape == (2000, 30) and np.allclose(qs.T @ qs, np.eye(30), atol=2e-5)  # full-rank input: stops at max_rank

@@ -56,6 +56,26 @@ def test_svd_wiki_csr_rank(oracle):  # :1497 test_svd_wiki_csr_rank (f32 CSR, ra
     _check_sigma(s, GOLD["wiki_sigma"], 1e-5)
 
 
+def test_svd_wiki_csr_epsil(oracle):  # :1459 test_svd_wiki_csr_epsil (f32 CSR, epsil 0.1, step 5, max_rank 10)
+    s, u, vt = oracle.direct_svd_epsil(_wiki_csr(oracle, np.float32), 0.1, 5, 10)
+    assert 3 <= len(s) <= 4
+    _check_sigma(s, GOLD["wiki_sigma"], 1e-5)
+
+
+def test_svd_wiki_full_epsil(oracle):  # :1530 test_svd_wiki_full_epsil (f64 dense, max_rank 4, f32::EPSILON)
+    s, u, vt = oracle.direct_svd_epsil(GOLD["wiki"].astype(np.float64), 0.1, 5, 4)
+    assert 3 <= len(s) <= 4
+    _check_sigma(s, GOLD["wiki_sigma"], float(np.finfo(np.float32).eps))
+
+
+def test_range_approx_epsil(oracle):  # :1200 test_range_approx_epsil shape (50 x 500, rank-limited): residual small
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((50, 12)) @ rng.standard_normal((12, 500))).astype(np.float64)
+    q = oracle.adaptative_range_finder(a, 0.05, 5, 40)
+    assert 12 <= q.shape[1] <= 40 and np.allclose(q.T @ q, np.eye(q.shape[1]), atol=1e-10)
+    assert np.linalg.norm(a - q @ (q.T @ a)) < 1e-8 * np.linalg.norm(a)
+
+
 def test_svd_f32_wiki(oracle):  # src/graphlaplace.rs:362 test_svd_wiki_rank_svd_f32
     s, u = oracle.svd_full(GOLD["wiki"].astype(np.float32))
     _check_sigma(s, GOLD["wiki_sigma"], 1e-5)
