@@ -155,6 +155,20 @@ class KGraph(_Handle):
         return o
 
     @classmethod
+    def load(cls, path):
+        """KGraph from a `.kgraph` file (annembed_amd/io.py); `.data_ids` keeps the DataIds"""
+        from . import io as _io
+        d = _io.read_kgraph(path)
+        g = cls(d["indptr"], d["nbr"], d["dist"], d["max_nbng"])
+        g.data_ids = d["data_ids"]
+        return g
+
+    def save(self, path):
+        from . import io as _io
+        indptr, nbr, dist = self.get_neighbours()
+        _io.write_kgraph(path, indptr, nbr, dist, self.get_max_nbng(), getattr(self, "data_ids", None))
+
+    @classmethod
     def from_ragged(cls, point_id, row_ptr, nbr_data_id, nbr_dist, nbng):
         """Tail of kgraph_from_hnsw_all (kgraph.rs:486-546): flatten, reindex, sort, truncate."""
         point_id, row_ptr, nbr_data_id, nbr_dist = _u64(point_id), _u64(row_ptr), _u64(nbr_data_id), _f32(nbr_dist)

@@ -90,6 +90,17 @@ def test_kgraph_from_ragged_bit_exact(A, oracle):
     assert e.value.code == 3
 
 
+def test_kgraph_file_roundtrip(A, graph, tmp_path):
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    g.data_ids = np.arange(2500, dtype=np.uint64) * 3
+    g.save(tmp_path / "g.kgraph")
+    g2 = A.KGraph.load(tmp_path / "g.kgraph")
+    ip, nb, ds = g2.get_neighbours()
+    assert np.array_equal(ip, indptr) and np.array_equal(nb, nbr) and np.array_equal(ds, dist) and g2.get_max_nbng() == 8
+    assert np.array_equal(g2.data_ids, g.data_ids)
+
+
 def test_hubness_bit_exact(A, graph, oracle):
     indptr, nbr, dist, _ = graph
     assert np.array_equal(A.KGraph(indptr, nbr, dist).hubness(), oracle.hubness(indptr, nbr))

@@ -1,0 +1,75 @@
+"""File formats of the path's callers: CSV wire format of src/tools/io.rs and the .kgraph
+container.  CPU only (host logic)."""
+import numpy as np
+import pytest
+
+from annembed_amd import io as aio
+
+
+def test_format_5e_is_rust_lower_exp():
+    # Rust `format!("{:.5e}", v)` for f32 v: mantissa with 5 decimals, bare exponent (src/tools/io.rs:37, :60)
+    cases = {1234.5678: "1.23457e3", 0.0: "0.00000e0", -0.015625: "-1.56250e-2", 1.0: "1.00000e0", 9.999996: "1.00000e1",
+             6.02214076e23: "6.02214e23", 1e-10: "1.00000e-10", -5.0: "-5.00000e0"}
+    for v, s in cases.items():
+        assert aio.format_5e(v) == s, (v, aio.format_5e(v), s)
+    assert aio.format_5e(float("inf")) == "inf" and aio.format_5e(float("nan")) == "NaN"
+    # the f32 value is what is printed (to_f32, :37): 0.1f32 = 0.100000001490116...
+    assert aio.format_5e(np.float64(0.1)) == "1.00000e-1" and aio.format_5e(16777217.0) == "1.67772e7"
+
+
+def test_write_csv_and_read_back(tmp_path):
+    y = np.array([[1.5, -2.25], [1e-3, 1234.5678], [0.0, 3.0]], np.float32)
+    p = tmp_path / "emb.csv"
+    assert aio.write_csv_labeled_array2(p, [7, 3, 9], y) == 1
+    assert p.read_text() == "7,1.50000e0,-2.25000e0\n3,1.00000e-3,1.23457e3\n9,0.00000e0,3.00000e0\n"
+    p2 = tmp_path / "emb2.csv"
+    aio.write_csv_array2(p2, y)
+    assert p2.read_text() == "1.50000e0,-2.25000e0\n1.00000e-3,1.23457e3\n0.00000e0,3.00000e0\n"
+    # reader: headers '#' / '%' skipped, FIRST record dropped (io.rs:170-186), constant field count enforced
+    src = tmp_path / "data.csv"
+    src.write_text("# a header\n% another\n1.0,2.0,3.0\n4.0,5.0,6.0\n7.5,8.5,9.5\n")
+    assert aio.get_header_size(src) == 2
+    x = aio.get_toembed_from_csv(src, ",", 1.0)
+    assert x.dtype == np.float32 and np.array_equal(x, np.array([[4, 5, 6], [7.5, 8.5, 9.5]], np.float32))
+    assert aio.get_toembed_from_csv(src, ",", 0.0).shape == (0, 3)  # xsi >= 0 always: nothing sampled
+    bad = tmp_path / "bad.csv"
+    bad.write_text("1,2,3\n4,5\n")
+    with pytest.raises(ValueError, match="non constant number of fields"):
+        aio.get_toembed_from_csv(bad)
+    one = tmp_path / "one.csv"
+    one.write_text("1;2;3\n4;5;6\n")
+    with pytest.raises(ValueError, match="only one field"):
+        aio.get_toembed_from_csv(one, ",")
+    assert np.array_equal(aio.get_toembed_from_csv(one, ";"), np.array([[4, 5, 6]], np.float32))
+    bad2 = tmp_path / "bad2.csv"
+    bad2.write_text("1,2\n3,x\n")
+    with pytest.raises(ValueError, match="error decoding"):
+        aio.get_toembed_from_csv(bad2)
+
+
+def test_kgraph_file_roundtrip_and_validation(tmp_path):
+    rng = np.random.default_rng(0)
+    n = 50
+    deg = rng.integers(1, 7, n)
+    indptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)
+    nbr = rng.integers(0, n, int(indptr[-1])).astype(np.uint32)
+    dist = rng.random(int(indptr[-1])).astype(np.float32)
+    ids = rng.permutation(1000)[:n].astype(np.uint64)
+    p = tmp_path / "g.kgraph"
+    aio.write_kgraph(p, indptr, nbr, dist, data_ids=ids)
+    d = aio.read_kgraph(p)
+    assert np.array_equal(d["indptr"], indptr) and np.array_equal(d["nbr"], nbr) and np.array_equal(d["dist"], dist)
+    assert np.array_equal(d["data_ids"], ids) and d["max_nbng"] == int(deg.max())
+    raw = p.read_bytes()
+    assert raw[:8] == b"AEKGRAPH" and len(raw) == 32 + 8 * (n + 1) + 8 * int(indptr[-1]) + 8 * n
+    (tmp_path / "t.kgraph").write_bytes(raw[:-3])
+    with pytest.raises(ValueError, match="truncated"):
+        aio.read_kgraph(tmp_path / "t.kgraph")
+    (tmp_path / "m.kgraph").write_bytes(b"XXKGRAPH" + raw[8:])
+    with pytest.raises(ValueError, match="not a .kgraph"):
+        aio.read_kgraph(tmp_path / "m.kgraph")
+    (tmp_path / "x.kgraph").write_bytes(raw + b"\0")
+    with pytest.raises(ValueError, match="trailing"):
+        aio.read_kgraph(tmp_path / "x.kgraph")
+    with pytest.raises(ValueError):
+        aio.write_kgraph(tmp_path / "bad.kgraph", indptr, nbr[:-1], dist)
