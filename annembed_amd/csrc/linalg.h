@@ -27,6 +27,12 @@ void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m,
 // become zero columns.  d_work: >= 3*l*l doubles.
 void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work);
 
+// Optimistic single-pass CholeskyQR on an f64 (MFMA) Gram: no host round trip; a failed pivot leaves Y untouched and
+// raises a sticky flag that orthonormalize_fast_failed() reports (and clears) -- the caller then redoes its
+// computation with orthonormalize_panel (eigen route for rank-deficient panels).
+void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l);
+bool orthonormalize_fast_failed();
+
 // eigendecomposition of a symmetric l x l f64 matrix on device (cyclic Jacobi, one workgroup):
 // evals[l] descending, evecs[l x l] row-major with eigenvectors in columns.
 void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs);

@@ -648,17 +648,175 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     sync();
 }
 
-void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
-    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
-    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 512));
-    static DevBuf<double> partial;  // scratch reused by every call (stream ordered, no sync needed)
-    if (partial.n < (uint64_t)nblocks * l * l) { sync(); partial.alloc((uint64_t)512 * kMaxL * kMaxL); }
-    hipLaunchKernelGGL(gram_partial_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, partial.p);
-    check_launch("gram_partial");
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(blocks_for(l * l, 256)), dim3(256), 0, stream(), partial.p, nblocks, l * l, d_g);
-    check_launch("gram_reduce");
+// ---- f64 Gram on the matrix cores: G (l x l, f64) += Y^T Y with v_mfma_f64_16x16x4_f64.  For G = Y^T Y both
+// operands of a 16x16 tile are the same register: lane (k = lane / 16, c = lane % 16) holds Y[row0 + k][16 a + c]
+// for column tile a (4 rows per step).  One wave accumulates TB x TB tiles over its rows, the four waves of a block
+// meet in LDS, one f64 atomic per entry and block lands in G.  Products of f32 values are exact in f64, so one
+// Cholesky pass on this Gram orthonormalises the panel to f32 rounding (CholeskyQR with an f64 Gram).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <int TB>
+__global__ void __launch_bounds__(256) gram_mfma_f64_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l, double* __restrict__ g) {
+    __shared__ double sg[TB * 16 * TB * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    d4_t acc[TB][TB];
+#pragma unroll
+    for (int a = 0; a < TB; a++)
+#pragma unroll
+        for (int b = 0; b < TB; b++) acc[a][b] = d4_t{0., 0., 0., 0.};
+    const uint64_t nsteps = (rows + 3) / 4;
+    for (uint64_t s = blockIdx.x * 4ull + wave; s < nsteps; s += gridDim.x * 4ull) {
+        const uint64_t row = s * 4 + kq;
+        double v[TB];
+#pragma unroll
+        for (int a = 0; a < TB; a++) {
+            const uint32_t col = 16u * a + c;
+            v[a] = (row < rows && col < l) ? (double)y[row * l + col] : 0.;
+        }
+#pragma unroll
+        for (int a = 0; a < TB; a++)
+#pragma unroll
+            for (int b = 0; b < TB; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[a], v[b], acc[a][b], 0, 0, 0);
+    }
+    constexpr int W = TB * 16;
+    for (int idx = threadIdx.x; idx < W * W; idx += 256) sg[idx] = 0.;
+    __syncthreads();
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < TB; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sg[(16 * a + kq + 4 * q) * W + 16 * b + c] += acc[a][b][q];  // D[i = lane / 16 + 4 q][j = lane % 16] (tools/test_mfma_f64.hip)
+        }
+        __syncthreads();
+    }
+    for (uint32_t idx = threadIdx.x; idx < l * l; idx += 256) atomicAdd(&g[idx], sg[(idx / l) * W + idx % l]);
 }
 
+static void launch_gram_mfma(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
+    const uint64_t nsteps = (rows + 3) / 4;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nsteps + 63) / 64, 512));
+    const int tb = (int)((l + 15) / 16);
+    switch (tb) {
+        case 1: hipLaunchKernelGGL((gram_mfma_f64_kernel<1>), dim3(grid), dim3(256), 0, stream(), d_y, rows, l, d_g); break;
+        case 2: hipLaunchKernelGGL((gram_mfma_f64_kernel<2>), dim3(grid), dim3(256), 0, stream(), d_y, rows, l, d_g); break;
+        case 3: hipLaunchKernelGGL((gram_mfma_f64_kernel<3>), dim3(grid), dim3(256), 0, stream(), d_y, rows, l, d_g); break;
+        default: hipLaunchKernelGGL((gram_mfma_f64_kernel<4>), dim3(grid), dim3(256), 0, stream(), d_y, rows, l, d_g); break;
+    }
+    check_launch("gram_mfma_f64");
+}
+
+// Cholesky of the Gram, R^-1, and the panel update Y <- Y R^-1 in ONE launch: every workgroup redoes the tiny
+// factorisation in LDS (a few microseconds, in parallel) instead of waiting for a single-workgroup kernel.  A pivot
+// that is not safely positive (rank-deficient / ill-conditioned panel) sets the sticky flag and leaves Y alone: the
+// caller then repeats its computation through the eigen (SVQB) route.  Workgroup 0 also clears `g_zero`, the
+// accumulator of the next Gram.
+__global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ g,
+                                                         double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero) {
+    __shared__ double R[kMaxL * kMaxL];
+    __shared__ double M[kMaxL * kMaxL];
+    __shared__ float tile[kGramTile * kMaxL];
+    __shared__ double s_d, s_dmax;
+    __shared__ int s_bad;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t idx = tid; idx < l * l; idx += 256) { R[idx] = g[idx]; M[idx] = 0.; }
+    if (blockIdx.x == 0 && g_zero)
+        for (uint32_t idx = tid; idx < l * l; idx += 256) g_zero[idx] = 0.;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double dm = 0.;
+        for (uint32_t q = 0; q < l; q++) dm = R[q * l + q] > dm ? R[q * l + q] : dm;
+        s_dmax = dm;
+    }
+    __syncthreads();
+    const double dmax = s_dmax;
+    for (uint32_t j = 0; j < l; j++) {  // upper Cholesky G = R^T R, row j per step; lane i (< l) of wave 0 owns column i
+        double v = 0.;
+        if (tid >= j && tid < l) {
+            v = R[j * l + tid];
+            for (uint32_t k = 0; k < j; k++) v -= R[k * l + j] * R[k * l + tid];
+            if (tid == j) s_d = v;
+        }
+        __syncthreads();
+        const double dd = s_d;
+        if (!(dd > rel_tol * dmax)) { if (tid == 0) s_bad = 1; break; }  // uniform: every thread reads the same s_d
+        const double rjj = sqrt(dd);
+        if (tid >= j && tid < l) R[j * l + tid] = (tid == j) ? rjj : v / rjj;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (blockIdx.x == 0 && tid == 0) atomicOr(flag, 1);
+        return;
+    }
+    if (tid < l) {  // column tid of M = R^-1 by back substitution (upper triangular)
+        const uint32_t i = tid;
+        M[i * l + i] = 1. / R[i * l + i];
+        for (int r = (int)i - 1; r >= 0; r--) {
+            double v = 0.;
+            for (uint32_t k = r + 1; k <= i; k++) v -= R[r * l + k] * M[k * l + i];
+            M[r * l + i] = v / R[r * l + r];
+        }
+    }
+    __syncthreads();
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t r0 = t * kGramTile;
+        const uint32_t nr = (uint32_t)(rows - r0 < kGramTile ? rows - r0 : kGramTile);
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nr * l; idx += 256) tile[idx] = y[r0 * l + idx];
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nr * l; idx += 256) {
+            const uint32_t r = idx / l, c2 = idx % l;
+            double s2 = 0.;
+            for (uint32_t cc = 0; cc <= c2; cc++) s2 += (double)tile[r * l + cc] * M[cc * l + c2];
+            y[(r0 + r) * l + c2] = (float)s2;
+        }
+    }
+}
+
+// optimistic orthonormalisation state: two Gram accumulators used alternately (the update kernel of call k clears
+// the accumulator of call k + 1) and the sticky failure flag
+struct FastOrth {
+    DevBuf<double> g[2];
+    DevBuf<int> flag;
+    unsigned k = 0;
+    void init() {
+        if (!flag.n) {
+            g[0].alloc(kMaxL * kMaxL); g[1].alloc(kMaxL * kMaxL); flag.alloc(1);
+            g[0].zero(); g[1].zero(); flag.zero();
+        }
+    }
+};
+static FastOrth& fast_orth() { static FastOrth f; f.init(); return f; }
+
+void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) {
+    FastOrth& f = fast_orth();
+    double* g = f.g[f.k & 1].p;
+    double* gz = f.g[(f.k + 1) & 1].p;
+    f.k++;
+    launch_gram_mfma(d_y, rows, l, g);
+    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 2048));
+    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz);
+    check_launch("chol_apply");
+}
+// true when a Cholesky pivot failed since the last call (synchronises the stream)
+bool orthonormalize_fast_failed() {
+    FastOrth& f = fast_orth();
+    int h = 0;
+    f.flag.download(&h, 1);
+    if (h) { f.flag.zero(); f.g[0].zero(); f.g[1].zero(); sync(); }
+    return h != 0;
+}
+
+void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
+    AE_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * l * l, stream()));
+    launch_gram_mfma(d_y, rows, l, d_g);
+}
 void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out) {
     if (d_out == d_y && lout > l) fail(AE_ERR_INVALID_ARG, "in-place apply needs lout <= l");
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
@@ -704,14 +862,24 @@ static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t
     DevBuf<float> omega(n * l), yn(n * l);
     DevBuf<double> work(3ull * l * l + l);
     q.alloc(m * l);
-    gaussian_fill_device(omega.p, n * l, kDefaultSeed, kTagOmega);  // RandomGaussianMatrix::new, :69-76, :299/:363
-    mat_mul_panel(a, omega.p, q.p, l);                              // :300 / :366
-    orthonormalize_panel(q.p, m, l, work.p);                        // :307 / :374
-    for (uint64_t j = 1; j < nbiter; j++) {                         // :308 / :375
-        mat_t_mul_panel(a, q.p, yn.p, l);                           // :311 / :379
-        orthonormalize_panel(yn.p, n, l, work.p);                   // :313-319 / :381-387
-        mat_mul_panel(a, yn.p, q.p, l);                             // :321 / :390
-        orthonormalize_panel(q.p, m, l, work.p);                    // :323-329 / :392-398
+    // do_qr (Householder, :998-1013) is replaced by CholeskyQR on an f64 Gram.  First optimistically (two launches per
+    // QR, no host round trip); if any panel was rank deficient (sticky device flag) the whole iteration is redone
+    // with the eigen route, which turns the dependent directions into zero columns.
+    for (int robust = 0; robust < 2; robust++) {
+        auto qr = [&](float* y, uint64_t rows) {
+            if (robust) orthonormalize_panel(y, rows, l, work.p);
+            else orthonormalize_panel_fast(y, rows, l);
+        };
+        gaussian_fill_device(omega.p, n * l, kDefaultSeed, kTagOmega);  // RandomGaussianMatrix::new, :69-76, :299/:363
+        mat_mul_panel(a, omega.p, q.p, l);                              // :300 / :366
+        qr(q.p, m);                                                     // :307 / :374
+        for (uint64_t j = 1; j < nbiter; j++) {                         // :308 / :375
+            mat_t_mul_panel(a, q.p, yn.p, l);                           // :311 / :379
+            qr(yn.p, n);                                                // :313-319 / :381-387
+            mat_mul_panel(a, yn.p, q.p, l);                             // :321 / :390
+            qr(q.p, m);                                                 // :323-329 / :392-398
+        }
+        if (robust || !orthonormalize_fast_failed()) break;
     }
     sync();
     return l;
@@ -781,9 +949,14 @@ void full_svd_leading(ae_matrepr& a, uint32_t rank, std::vector<float>& s, DevBu
     rank = std::min<uint32_t>(rank, l);
     DevBuf<float> q(n * l), z(n * l);
     DevBuf<double> work(3ull * l * l + l);
+    bool robust = false;  // optimistic CholeskyQR until a pivot fails (checked at the per-iteration sync below)
+    auto qr = [&](float* y) {
+        if (robust) orthonormalize_panel(y, n, l, work.p);
+        else orthonormalize_panel_fast(y, n, l);
+    };
     gaussian_fill_device(z.p, n * l, kDefaultSeed, kTagOmega);
     mat_mul_panel(a, z.p, q.p, l);
-    orthonormalize_panel(q.p, n, l, work.p);
+    qr(q.p);
     std::vector<double> prev(l, 0.), cur(l);
     double* g = work.p;
     double* ub = work.p + (uint64_t)l * l;
@@ -792,9 +965,18 @@ void full_svd_leading(ae_matrepr& a, uint32_t rank, std::vector<float>& s, DevBu
     for (int it = 0; it < max_outer; it++) {
         for (int inner = 0; inner < 4; inner++) {
             mat_t_mul_panel(a, q.p, z.p, l);
-            orthonormalize_panel(z.p, n, l, work.p);
+            qr(z.p);
             mat_mul_panel(a, z.p, q.p, l);
-            orthonormalize_panel(q.p, n, l, work.p);
+            qr(q.p);
+        }
+        if (!robust && orthonormalize_fast_failed()) {  // rank-deficient panel: restart on the eigen route
+            robust = true;
+            gaussian_fill_device(z.p, n * l, kDefaultSeed, kTagOmega);
+            mat_mul_panel(a, z.p, q.p, l);
+            qr(q.p);
+            std::fill(prev.begin(), prev.end(), 0.);
+            it = -1;
+            continue;
         }
         // Rayleigh-Ritz on B = Q^T A: sigma^2 = eig(B B^T), rotate Q onto the Ritz vectors
         mat_t_mul_panel(a, q.p, z.p, l);
