@@ -501,15 +501,16 @@ class GraphLaplacian(_Handle):
         check(L.load().ae_laplacian_get_vectors(self._h, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), C.byref(ms)))
         return dict(normalizer=out[0], normed_scales=out[1], q_density=out[2], beta_scales=out[3], mean_scale=ms.value)
 
-    def do_svd(self, asked_dim=0):
-        """GraphLaplacian::do_svd, src/graphlaplace.rs:127-134."""
+    def do_svd(self, asked_dim=0, want_u=True):
+        """GraphLaplacian::do_svd, src/graphlaplace.rs:127-134.  want_u=False leaves U on the device (as the embedder's
+        own call does) and returns the spectrum only."""
         _, n, _ = self.info()
         s = np.zeros(20, np.float32)
-        u = np.zeros((n, 20), np.float32)
+        u = np.zeros((n, 20), np.float32) if want_u else None
         r = C.c_uint64()
-        check(L.load().ae_laplacian_do_svd(self._h, ptr(s), ptr(u), C.byref(r)))
+        check(L.load().ae_laplacian_do_svd(self._h, ptr(s), ptr(u) if want_u else None, C.byref(r)))
         r = r.value
-        return SvdResult(s[:r].copy(), np.ascontiguousarray(u.reshape(-1)[: n * r].reshape(n, r)), None)
+        return SvdResult(s[:r].copy(), np.ascontiguousarray(u.reshape(-1)[: n * r].reshape(n, r)) if want_u else None, None)
 
 
 class DiffusionMaps:

@@ -74,28 +74,42 @@ inline int32_t guard(F&& f) {
 hipStream_t stream();
 void require_device();
 
+// stream-ordered allocations (hipMallocAsync on the library stream, default pool kept warm): for the temporaries
+// of the per-call hot functions -- a hipMalloc / hipFree pair costs a device synchronisation
+void* pool_alloc(size_t bytes);
+void pool_free(void* p);
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool pooled = false;
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), pooled(o.pooled) { o.p = nullptr; o.n = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; pooled = o.pooled; o.p = nullptr; o.n = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) { if (pooled) pool_free(p); else (void)hipFree(p); }
         p = nullptr; n = 0;
     }
     void alloc(size_t count) {
         release();
         n = count;
+        pooled = false;
         if (count) AE_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    // scratch that never leaves the library's stream (not for buffers handed to RCCL / other streams)
+    void alloc_pooled(size_t count) {
+        release();
+        n = count;
+        pooled = true;
+        if (count) p = static_cast<T*>(pool_alloc(count * sizeof(T)));
     }
     void upload(const T* host, size_t count) {
         if (count > n) alloc(count);

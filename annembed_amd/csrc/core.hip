@@ -30,6 +30,28 @@ hipStream_t stream() {
     return g_streams[dev];
 }
 
+void* pool_alloc(size_t bytes) {
+    static bool ready[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) fail(AE_ERR_NO_DEVICE, "hipGetDevice failed (no HIP device?)");
+    if (!ready[dev]) {  // keep freed blocks in the pool instead of returning them to the driver at every synchronisation
+        hipMemPool_t pool;
+        AE_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+        uint64_t threshold = ~0ull;
+        AE_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
+        ready[dev] = true;
+    }
+    void* p = nullptr;
+    AE_HIP(hipMallocAsync(&p, bytes, stream()));
+    return p;
+}
+void pool_free(void* p) {
+    try {
+        (void)hipFreeAsync(p, stream());
+    } catch (...) {  // process teardown: the device is gone
+    }
+}
+
 }  // namespace ae
 
 using namespace ae;

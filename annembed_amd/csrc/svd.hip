@@ -715,10 +715,10 @@ static void launch_gram_mfma(const float* d_y, uint64_t rows, uint32_t l, double
 // accumulator of the next Gram.
 __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ g,
                                                          double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero) {
-    __shared__ double R[kMaxL * kMaxL];
-    __shared__ double M[kMaxL * kMaxL];
-    __shared__ float tile[kGramTile * kMaxL];
-    __shared__ double s_d, s_dmax;
+    extern __shared__ double smem[];         // R[l*l] | M[l*l] | tile[kGramTile*l] (floats)
+    double* R = smem;
+    double* M = smem + (size_t)l * l;
+    float* tile = reinterpret_cast<float*>(smem + 2 * (size_t)l * l);
     __shared__ int s_bad;
     const uint32_t tid = threadIdx.x;
     for (uint32_t idx = tid; idx < l * l; idx += 256) { R[idx] = g[idx]; M[idx] = 0.; }
@@ -726,42 +726,48 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
         for (uint32_t idx = tid; idx < l * l; idx += 256) g_zero[idx] = 0.;
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    if (tid == 0) {
-        double dm = 0.;
-        for (uint32_t q = 0; q < l; q++) dm = R[q * l + q] > dm ? R[q * l + q] : dm;
-        s_dmax = dm;
-    }
-    __syncthreads();
-    const double dmax = s_dmax;
-    for (uint32_t j = 0; j < l; j++) {  // upper Cholesky G = R^T R, row j per step; lane i (< l) of wave 0 owns column i
-        double v = 0.;
-        if (tid >= j && tid < l) {
-            v = R[j * l + tid];
-            for (uint32_t k = 0; k < j; k++) v -= R[k * l + j] * R[k * l + tid];
-            if (tid == j) s_d = v;
+    if (tid < 64) {  // wave 0 factorises (lane i owns column i); LDS operations of one wave execute in order
+        const uint32_t i = tid;
+        double dmax = 0.;
+        for (uint32_t q = 0; q < l; q++) dmax = R[q * l + q] > dmax ? R[q * l + q] : dmax;
+        bool bad = false;
+        for (uint32_t j = 0; j < l; j++) {  // upper Cholesky G = R^T R, row j per step
+            double v0 = 0., v1 = 0.;
+            const uint32_t ic = i < l ? i : l - 1;
+            uint32_t k = 0;
+            for (; k + 2 <= j; k += 2) {
+                v0 += R[k * l + j] * R[k * l + ic];
+                v1 += R[(k + 1) * l + j] * R[(k + 1) * l + ic];
+            }
+            if (k < j) v0 += R[k * l + j] * R[k * l + ic];
+            const double v = R[j * l + ic] - (v0 + v1);
+            const double dd = __shfl(v, (int)j);
+            if (!(dd > rel_tol * dmax)) { bad = true; break; }  // wave-uniform
+            const double inv = 1.0 / sqrt(dd);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (i >= j && i < l) R[j * l + i] = (i == j) ? sqrt(dd) : v * inv;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        __syncthreads();
-        const double dd = s_d;
-        if (!(dd > rel_tol * dmax)) { if (tid == 0) s_bad = 1; break; }  // uniform: every thread reads the same s_d
-        const double rjj = sqrt(dd);
-        if (tid >= j && tid < l) R[j * l + tid] = (tid == j) ? rjj : v / rjj;
-        __syncthreads();
+        if (bad) { if (i == 0) s_bad = 1; }
+        else if (i < l) {  // column i of M = R^-1 by back substitution (upper triangular)
+            M[i * l + i] = 1. / R[i * l + i];
+            for (int r = (int)i - 1; r >= 0; r--) {
+                double a0 = 0., a1 = 0.;
+                uint32_t k = (uint32_t)r + 1;
+                for (; k + 2 <= i + 1; k += 2) {
+                    a0 += R[r * l + k] * M[k * l + i];
+                    a1 += R[r * l + k + 1] * M[(k + 1) * l + i];
+                }
+                if (k <= i) a0 += R[r * l + k] * M[k * l + i];
+                M[r * l + i] = -(a0 + a1) / R[r * l + r];
+            }
+        }
     }
     __syncthreads();
     if (s_bad) {
         if (blockIdx.x == 0 && tid == 0) atomicOr(flag, 1);
         return;
     }
-    if (tid < l) {  // column tid of M = R^-1 by back substitution (upper triangular)
-        const uint32_t i = tid;
-        M[i * l + i] = 1. / R[i * l + i];
-        for (int r = (int)i - 1; r >= 0; r--) {
-            double v = 0.;
-            for (uint32_t k = r + 1; k <= i; k++) v -= R[r * l + k] * M[k * l + i];
-            M[r * l + i] = v / R[r * l + r];
-        }
-    }
-    __syncthreads();
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t r0 = t * kGramTile;
@@ -800,8 +806,10 @@ void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) {
     f.k++;
     launch_gram_mfma(d_y, rows, l, g);
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
-    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 2048));
-    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz);
+    // every workgroup pays the factorisation once: a few tiles per workgroup, all workgroups resident at once
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 512));
+    const size_t smem = sizeof(double) * 2 * (size_t)l * l + sizeof(float) * (size_t)kGramTile * l;
+    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), smem, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz);
     check_launch("chol_apply");
 }
 // true when a Cholesky pivot failed since the last call (synchronises the stream)
@@ -859,9 +867,12 @@ static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t
     const uint64_t m = a.nrows, n = a.ncols;
     const uint32_t l = (uint32_t)std::min<uint64_t>(std::min(m, n), rank);  // :294 / :358
     if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "rank %llu unsupported (1..%d)", (unsigned long long)rank, kMaxL);
-    DevBuf<float> omega(n * l), yn(n * l);
-    DevBuf<double> work(3ull * l * l + l);
-    q.alloc(m * l);
+    DevBuf<float> omega, yn;
+    DevBuf<double> work;
+    omega.alloc_pooled(n * l);
+    yn.alloc_pooled(n * l);
+    work.alloc_pooled(3ull * l * l + l);
+    q.alloc_pooled(m * l);
     // do_qr (Householder, :998-1013) is replaced by CholeskyQR on an f64 Gram.  First optimistically (two launches per
     // QR, no host round trip); if any panel was rank deficient (sticky device flag) the whole iteration is redone
     // with the eigen route, which turns the dependent directions into zero columns.
@@ -903,10 +914,12 @@ static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, boo
 static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out) {
     const uint64_t m = a.nrows, n = a.ncols;
     // B = Q^T A (l x n), kept transposed: Bt = A^T Q (n x l)                       :737-743
-    DevBuf<float> bt(n * l);
+    DevBuf<float> bt;
+    bt.alloc_pooled(n * l);
     mat_t_mul_panel(a, q.p, bt.p, l);
     // svd(B) through the l x l Gram B B^T = U_b S^2 U_b^T                          :758
-    DevBuf<double> work(3ull * l * l + l);
+    DevBuf<double> work;
+    work.alloc_pooled(3ull * l * l + l);
     double* g = work.p;
     double* ub = work.p + (uint64_t)l * l;
     double* evals = work.p + 2ull * l * l;
@@ -919,7 +932,7 @@ static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
     out.s.resize(l);
     for (uint32_t i = 0; i < l; i++) out.s[i] = (float)std::sqrt(std::max(hev[i], 0.));
     // U = Q U_b                                                                   :781
-    out.u.alloc(m * l);
+    out.u.alloc_pooled(m * l);
     apply_panel(q.p, m, l, ub, l, out.u.p);
     if (want_vt) {
         // Vt = S^-1 U_b^T B  <=>  V = Bt U_b S^-1 ; null directions get zero rows

@@ -130,10 +130,13 @@ def main():
     lap = A.DiffusionMaps(dp).laplacian_from_kgraph(kg)
     _, _, nnz_a = lap.info()
     L.check(L.load().ae_synchronize())
-    lap.do_svd()  # warm
+    lap.do_svd(want_u=False)  # warm
+    svd_reps = 5
+    L.check(L.load().ae_synchronize())
     t0 = time.perf_counter()
-    lap.do_svd()
-    svd_s = time.perf_counter() - t0
+    for _ in range(svd_reps):
+        lap.do_svd(want_u=False)  # U stays in HBM, as in the embedder's own call; the spectrum comes back
+    svd_s = (time.perf_counter() - t0) / svd_reps
     y0 = A.DiffusionMaps(dp).embed_from_kgraph(kg)
     y0 = A.set_data_box(y0, 10.0)
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
