@@ -11,6 +11,7 @@
 // instead of failing.  The l x n SVD of B (gesdd at :758) is done the same way through B B^T.
 
 #include "linalg.h"
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 // (after <cstring>: rocprim's texture iterator calls the host memset)
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
     __shared__ int order[kMaxL];
     const uint32_t L = (l + 1) & ~1u;  // even
     const uint32_t tid = threadIdx.x;
-    for (uint32_t idx = tid; idx < l * l; idx += 256) {
+    for (uint32_t idx = tid; idx < l * l; idx += blockDim.x) {
         G[idx] = gin[idx];
         V[idx] = (idx / l == idx % l) ? 1. : 0.;
     }
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
             }
             __syncthreads();
             // columns: G <- G J, V <- V J
-            for (uint32_t idx = tid; idx < l * (L / 2); idx += 256) {
+            for (uint32_t idx = tid; idx < l * (L / 2); idx += blockDim.x) {
                 const uint32_t r = idx / (L / 2), pr = idx % (L / 2);
                 const uint32_t a = pp[pr], b = pq[pr];
                 if (b >= l) continue;
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
             }
             __syncthreads();
             // rows: G <- J^T G
-            for (uint32_t idx = tid; idx < l * (L / 2); idx += 256) {
+            for (uint32_t idx = tid; idx < l * (L / 2); idx += blockDim.x) {
                 const uint32_t k = idx / (L / 2), pr = idx % (L / 2);
                 const uint32_t a = pp[pr], b = pq[pr];
                 if (b >= l) continue;
@@ -401,7 +402,7 @@ __global__ void __launch_bounds__(256) jacobi_eigh_kernel(const double* __restri
         }
     }
     __syncthreads();
-    for (uint32_t idx = tid; idx < l * l; idx += 256) {
+    for (uint32_t idx = tid; idx < l * l; idx += blockDim.x) {
         const uint32_t r = idx / l, o = idx % l;
         evecs[idx] = V[r * l + order[o]];
     }
@@ -665,7 +666,8 @@ __global__ void __launch_bounds__(256) gram_mfma_f64_kernel(const float* __restr
 #pragma unroll
         for (int b = 0; b < TB; b++) acc[a][b] = d4_t{0., 0., 0., 0.};
     const uint64_t nsteps = (rows + 3) / 4;
-    for (uint64_t s = blockIdx.x * 4ull + wave; s < nsteps; s += gridDim.x * 4ull) {
+#pragma unroll 4
+    for (uint64_t s = blockIdx.x * 4ull + wave; s < nsteps; s += gridDim.x * 4ull) {  // unrolled: several row loads in flight
         const uint64_t row = s * 4 + kq;
         double v[TB];
 #pragma unroll
@@ -714,73 +716,68 @@ static void launch_gram_mfma(const float* d_y, uint64_t rows, uint32_t l, double
 // caller then repeats its computation through the eigen (SVQB) route.  Workgroup 0 also clears `g_zero`, the
 // accumulator of the next Gram.
 __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ g,
-                                                         double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero) {
-    extern __shared__ double smem[];         // R[l*l] | M[l*l] | tile[kGramTile*l] (floats)
+                                                         double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero, uint32_t rp) {
+    extern __shared__ double smem[];         // R[l*l] | rinv[l] | tile[rp rows * (l + 1)] (f64, one row per thread, rp <= 256)
     double* R = smem;
-    double* M = smem + (size_t)l * l;
-    float* tile = reinterpret_cast<float*>(smem + 2 * (size_t)l * l);
+    double* rinv = smem + (size_t)l * l;
+    double* tile = rinv + l;
     __shared__ int s_bad;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t idx = tid; idx < l * l; idx += 256) { R[idx] = g[idx]; M[idx] = 0.; }
+    for (uint32_t idx = tid; idx < l * l; idx += 256) R[idx] = g[idx];
     if (blockIdx.x == 0 && g_zero)
         for (uint32_t idx = tid; idx < l * l; idx += 256) g_zero[idx] = 0.;
     if (tid == 0) s_bad = 0;
     __syncthreads();
     if (tid < 64) {  // wave 0 factorises (lane i owns column i); LDS operations of one wave execute in order
         const uint32_t i = tid;
+        const uint32_t ic = i < l ? i : l - 1;
         double dmax = 0.;
         for (uint32_t q = 0; q < l; q++) dmax = R[q * l + q] > dmax ? R[q * l + q] : dmax;
         bool bad = false;
         for (uint32_t j = 0; j < l; j++) {  // upper Cholesky G = R^T R, row j per step
-            double v0 = 0., v1 = 0.;
-            const uint32_t ic = i < l ? i : l - 1;
+            double v0 = 0., v1 = 0., v2 = 0., v3 = 0.;
             uint32_t k = 0;
-            for (; k + 2 <= j; k += 2) {
+            for (; k + 4 <= j; k += 4) {
                 v0 += R[k * l + j] * R[k * l + ic];
                 v1 += R[(k + 1) * l + j] * R[(k + 1) * l + ic];
+                v2 += R[(k + 2) * l + j] * R[(k + 2) * l + ic];
+                v3 += R[(k + 3) * l + j] * R[(k + 3) * l + ic];
             }
-            if (k < j) v0 += R[k * l + j] * R[k * l + ic];
-            const double v = R[j * l + ic] - (v0 + v1);
+            for (; k < j; k++) v0 += R[k * l + j] * R[k * l + ic];
+            const double v = R[j * l + ic] - ((v0 + v1) + (v2 + v3));
             const double dd = __shfl(v, (int)j);
             if (!(dd > rel_tol * dmax)) { bad = true; break; }  // wave-uniform
-            const double inv = 1.0 / sqrt(dd);
+            const double inv = rsqrt(dd);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (i >= j && i < l) R[j * l + i] = (i == j) ? sqrt(dd) : v * inv;
+            if (i >= j && i < l) R[j * l + i] = (i == j) ? dd * inv : v * inv;
+            if (i == j) rinv[j] = inv;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        if (bad) { if (i == 0) s_bad = 1; }
-        else if (i < l) {  // column i of M = R^-1 by back substitution (upper triangular)
-            M[i * l + i] = 1. / R[i * l + i];
-            for (int r = (int)i - 1; r >= 0; r--) {
-                double a0 = 0., a1 = 0.;
-                uint32_t k = (uint32_t)r + 1;
-                for (; k + 2 <= i + 1; k += 2) {
-                    a0 += R[r * l + k] * M[k * l + i];
-                    a1 += R[r * l + k + 1] * M[(k + 1) * l + i];
-                }
-                if (k <= i) a0 += R[r * l + k] * M[k * l + i];
-                M[r * l + i] = -(a0 + a1) / R[r * l + r];
-            }
-        }
+        if (bad && i == 0) s_bad = 1;
     }
     __syncthreads();
     if (s_bad) {
         if (blockIdx.x == 0 && tid == 0) atomicOr(flag, 1);
         return;
     }
-    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
+    // Y <- Y R^-1 row by row: x R = y by forward substitution, one thread per row (no explicit inverse)
+    const uint64_t ntiles = (rows + rp - 1) / rp;
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint64_t r0 = t * kGramTile;
-        const uint32_t nr = (uint32_t)(rows - r0 < kGramTile ? rows - r0 : kGramTile);
+        const uint64_t r0 = t * rp;
+        const uint32_t nr = (uint32_t)(rows - r0 < rp ? rows - r0 : rp);
         __syncthreads();
-        for (uint32_t idx = tid; idx < nr * l; idx += 256) tile[idx] = y[r0 * l + idx];
+        for (uint32_t idx = tid; idx < nr * l; idx += 256) tile[(idx / l) * (l + 1) + idx % l] = (double)y[r0 * l + idx];  // coalesced load
         __syncthreads();
-        for (uint32_t idx = tid; idx < nr * l; idx += 256) {
-            const uint32_t r = idx / l, c2 = idx % l;
-            double s2 = 0.;
-            for (uint32_t cc = 0; cc <= c2; cc++) s2 += (double)tile[r * l + cc] * M[cc * l + c2];
-            y[(r0 + r) * l + c2] = (float)s2;
+        if (tid < nr) {
+            double* x = tile + (size_t)tid * (l + 1);  // odd stride in doubles: conflict-free rows
+            for (uint32_t c = 0; c < l; c++) {
+                double acc = x[c];
+                for (uint32_t k = 0; k < c; k++) acc -= x[k] * R[k * l + c];
+                x[c] = acc * rinv[c];
+            }
         }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nr * l; idx += 256) y[r0 * l + idx] = (float)tile[(idx / l) * (l + 1) + idx % l];
     }
 }
 
@@ -805,11 +802,12 @@ void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) {
     double* gz = f.g[(f.k + 1) & 1].p;
     f.k++;
     launch_gram_mfma(d_y, rows, l, g);
-    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
-    // every workgroup pays the factorisation once: a few tiles per workgroup, all workgroups resident at once
-    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 512));
-    const size_t smem = sizeof(double) * 2 * (size_t)l * l + sizeof(float) * (size_t)kGramTile * l;
-    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), smem, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz);
+    // every workgroup pays the factorisation once; rp rows per workgroup and pass, sized to stay under 64 KB of LDS
+    const uint32_t rp = l <= 24 ? 256u : (l <= 40 ? 128u : 32u);
+    const uint64_t ntiles = (rows + rp - 1) / rp;
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024));
+    const size_t smem = sizeof(double) * ((size_t)l * l + l + rp * (size_t)(l + 1));
+    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), smem, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz, rp);
     check_launch("chol_apply");
 }
 // true when a Cholesky pivot failed since the last call (synchronises the stream)
@@ -905,6 +903,53 @@ struct SvdOut {
 
 // SvdApprox::direct_svd (RANK mode), svdapprox.rs:721-799
 static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out);
+
+// Eigendecomposition of the l x l (l <= 64) f64 Gram on the HOST: cyclic Jacobi, eigenvalues descending, eigenvectors
+// in the columns of v (row-major).  The callers need the spectrum on the host anyway (one synchronisation either
+// way); 20 x 20 takes ~50 us here against ~330 us of a single-workgroup device kernel (latency of ~1500 dependent
+// LDS round trips).  This is the l x l tail of the reference's gesdd on B (svdapprox.rs:758), not a data path.
+static void jacobi_eigh_host(const double* g_in, uint32_t l, std::vector<double>& evals, std::vector<double>& v) {
+    std::vector<double> a(g_in, g_in + (size_t)l * l);
+    v.assign((size_t)l * l, 0.);
+    for (uint32_t i = 0; i < l; i++) v[(size_t)i * l + i] = 1.;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0., diag = 0.;
+        for (uint32_t i = 0; i < l; i++)
+            for (uint32_t j = 0; j < l; j++) (i == j ? diag : off) += a[(size_t)i * l + j] * a[(size_t)i * l + j];
+        if (off <= 1e-26 * diag || off == 0.) break;
+        for (uint32_t p = 0; p + 1 < l; p++)
+            for (uint32_t q2 = p + 1; q2 < l; q2++) {
+                const double apq = a[(size_t)p * l + q2];
+                if (apq == 0.) continue;
+                const double tau = (a[(size_t)q2 * l + q2] - a[(size_t)p * l + p]) / (2. * apq);
+                const double t = (tau >= 0. ? 1. : -1.) / (std::fabs(tau) + std::sqrt(1. + tau * tau));
+                const double c = 1. / std::sqrt(1. + t * t), sn = t * c;
+                for (uint32_t r = 0; r < l; r++) {  // A <- A J, V <- V J
+                    const double ap = a[(size_t)r * l + p], aq = a[(size_t)r * l + q2];
+                    a[(size_t)r * l + p] = c * ap - sn * aq;
+                    a[(size_t)r * l + q2] = sn * ap + c * aq;
+                    const double vp = v[(size_t)r * l + p], vq = v[(size_t)r * l + q2];
+                    v[(size_t)r * l + p] = c * vp - sn * vq;
+                    v[(size_t)r * l + q2] = sn * vp + c * vq;
+                }
+                for (uint32_t k = 0; k < l; k++) {  // A <- J^T A
+                    const double ap = a[(size_t)p * l + k], aq = a[(size_t)q2 * l + k];
+                    a[(size_t)p * l + k] = c * ap - sn * aq;
+                    a[(size_t)q2 * l + k] = sn * ap + c * aq;
+                }
+            }
+    }
+    std::vector<uint32_t> order(l);
+    for (uint32_t i = 0; i < l; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y2) { return a[(size_t)x * l + x] > a[(size_t)y2 * l + y2]; });
+    evals.resize(l);
+    std::vector<double> vs((size_t)l * l);
+    for (uint32_t o = 0; o < l; o++) {
+        evals[o] = a[(size_t)order[o] * l + order[o]];
+        for (uint32_t r = 0; r < l; r++) vs[(size_t)r * l + o] = v[(size_t)r * l + order[o]];
+    }
+    v.swap(vs);
+}
 static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, bool want_vt, SvdOut& out) {
     DevBuf<float> q;
     const uint32_t l = subspace_iteration_device(a, rank, nbiter, q);
@@ -924,10 +969,12 @@ static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
     double* ub = work.p + (uint64_t)l * l;
     double* evals = work.p + 2ull * l * l;
     gram_panel(bt.p, n, l, g);
-    jacobi_eigh_device(g, l, evals, ub);
-    std::vector<double> hev(l);
-    AE_HIP(hipMemcpyAsync(hev.data(), evals, sizeof(double) * l, hipMemcpyDeviceToHost, stream()));
+    std::vector<double> hg((size_t)l * l), hev, hub_sorted;
+    AE_HIP(hipMemcpyAsync(hg.data(), g, sizeof(double) * l * l, hipMemcpyDeviceToHost, stream()));
     sync();
+    jacobi_eigh_host(hg.data(), l, hev, hub_sorted);
+    AE_HIP(hipMemcpyAsync(ub, hub_sorted.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, stream()));
+    (void)evals;
     out.l = l;
     out.s.resize(l);
     for (uint32_t i = 0; i < l; i++) out.s[i] = (float)std::sqrt(std::max(hev[i], 0.));
@@ -936,9 +983,8 @@ static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
     apply_panel(q.p, m, l, ub, l, out.u.p);
     if (want_vt) {
         // Vt = S^-1 U_b^T B  <=>  V = Bt U_b S^-1 ; null directions get zero rows
-        std::vector<double> hub(l * l), hm(l * l);
-        AE_HIP(hipMemcpyAsync(hub.data(), ub, sizeof(double) * l * l, hipMemcpyDeviceToHost, stream()));
-        sync();
+        const std::vector<double>& hub = hub_sorted;
+        std::vector<double> hm(l * l);
         for (uint32_t c = 0; c < l; c++)
             for (uint32_t o = 0; o < l; o++) {
                 const double sv = std::sqrt(std::max(hev[o], 0.));
@@ -994,10 +1040,14 @@ void full_svd_leading(ae_matrepr& a, uint32_t rank, std::vector<float>& s, DevBu
         // Rayleigh-Ritz on B = Q^T A: sigma^2 = eig(B B^T), rotate Q onto the Ritz vectors
         mat_t_mul_panel(a, q.p, z.p, l);
         gram_panel(z.p, n, l, g);
-        jacobi_eigh_device(g, l, evals, ub);
-        AE_HIP(hipMemcpyAsync(cur.data(), evals, sizeof(double) * l, hipMemcpyDeviceToHost, stream()));
+        std::vector<double> hg((size_t)l * l), hub;
+        AE_HIP(hipMemcpyAsync(hg.data(), g, sizeof(double) * l * l, hipMemcpyDeviceToHost, stream()));
         sync();
+        jacobi_eigh_host(hg.data(), l, cur, hub);
+        AE_HIP(hipMemcpyAsync(ub, hub.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, stream()));
         apply_panel(q.p, n, l, ub, l, q.p);
+        sync();  // hub leaves scope
+        (void)evals;
         double delta = 0.;
         for (uint32_t i = 0; i < rank; i++) {
             double a1 = std::sqrt(std::max(cur[i], 0.)), a0 = std::sqrt(std::max(prev[i], 0.));
