@@ -137,50 +137,62 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Y[m x l] = A[m x n] * X[n x l].  A is row-major with the contraction index contiguous, so the 32 x KT tile of each
 // wave goes through LDS (coalesced 16-byte row segments in, conflict-free column reads out: row stride KT + 1).
-constexpr int kMfmaKT = 32;
+constexpr int kMfmaKT = 64;
 template <bool VEC4>
 __global__ void __launch_bounds__(256) dense_mul_panel_mfma_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
                                                                    const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
-    __shared__ float sA[128 * (kMfmaKT + 1)];
-    __shared__ float sX[kMfmaKT * 32];
+    constexpr int KT = kMfmaKT, NQ = 128 * KT / 4 / 256, NX = KT * 32 / 256;  // float4 / floats per thread and tile
+    __shared__ float sA[128 * (KT + 1)];
+    __shared__ float sX[KT * 32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t row_base = blockIdx.x * 128ull;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
-    for (uint64_t k0 = 0; k0 < n; k0 += kMfmaKT) {
+    float ra[NQ][4], rx[NX];
+    auto gload = [&](uint64_t k0) {  // tile k0 into registers: 16 consecutive threads read 256 contiguous bytes of a row
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // A tile: 128 rows x 32 k, one 16-byte segment per thread and pass
+        for (int q = 0; q < NQ; q++) {
             const int idx = tid + q * 256;
-            const int r = idx >> 3, kc = (idx & 7) * 4;
+            const int r = idx / (KT / 4), kc = (idx % (KT / 4)) * 4;
             const uint64_t row = row_base + r, kk = k0 + kc;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            ra[q][0] = ra[q][1] = ra[q][2] = ra[q][3] = 0.f;
             if (row < m) {
                 if (VEC4 && kk + 3 < n) {
                     const float4 t = *reinterpret_cast<const float4*>(a + row * n + kk);
-                    v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                    ra[q][0] = t.x; ra[q][1] = t.y; ra[q][2] = t.z; ra[q][3] = t.w;
                 } else {
                     const float* p = a + row * n;
-                    if (kk < n) v0 = p[kk];
-                    if (kk + 1 < n) v1 = p[kk + 1];
-                    if (kk + 2 < n) v2 = p[kk + 2];
-                    if (kk + 3 < n) v3 = p[kk + 3];
+                    if (kk < n) ra[q][0] = p[kk];
+                    if (kk + 1 < n) ra[q][1] = p[kk + 1];
+                    if (kk + 2 < n) ra[q][2] = p[kk + 2];
+                    if (kk + 3 < n) ra[q][3] = p[kk + 3];
                 }
             }
-            float* d = sA + r * (kMfmaKT + 1) + kc;
-            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // X slab: 32 k x 32 j (zero padded beyond l)
+        for (int q = 0; q < NX; q++) {  // X slab: KT k x 32 j (zero padded beyond l)
             const int idx = tid + q * 256;
             const int kk = idx >> 5, j = idx & 31;
-            sX[idx] = (k0 + kk < n && (uint32_t)j < l) ? x[(k0 + kk) * l + j] : 0.f;
+            rx[q] = (k0 + kk < n && (uint32_t)j < l) ? x[(k0 + kk) * l + j] : 0.f;
         }
+    };
+    gload(0);
+    for (uint64_t k0 = 0; k0 < n; k0 += KT) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int idx = tid + q * 256;
+            float* d = sA + (idx / (KT / 4)) * (KT + 1) + (idx % (KT / 4)) * 4;
+            d[0] = ra[q][0]; d[1] = ra[q][1]; d[2] = ra[q][2]; d[3] = ra[q][3];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; q++) sX[tid + q * 256] = rx[q];
         __syncthreads();
-        const float* pa = sA + (w * 32 + (lane & 31)) * (kMfmaKT + 1) + (lane >> 5);
+        if (k0 + KT < n) gload(k0 + KT);  // the next tile is in flight while the matrix cores work on this one
+        const float* pa = sA + (w * 32 + (lane & 31)) * (KT + 1) + (lane >> 5);
         const float* pb = sX + (lane >> 5) * 32 + (lane & 31);
 #pragma unroll
-        for (int kk = 0; kk < kMfmaKT; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk * 32], acc, 0, 0, 0);
+        for (int kk = 0; kk < KT; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk * 32], acc, 0, 0, 0);
         __syncthreads();
     }
     const int j = lane & 31;
@@ -210,7 +222,8 @@ __global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
     // the 4 waves of the workgroup interleave the rows of the chunk; their accumulators are summed through LDS
-    for (uint64_t r = i0 + 2 * w; r < i1; r += 8) {
+#pragma unroll 8
+    for (uint64_t r = i0 + 2 * w; r < i1; r += 8) {  // unrolled: the loads of several steps are in flight together
         const uint64_t rr = r + kh;
         const bool ok = rr < i1;
         const float av = (ok && cok) ? a[rr * n + col] : 0.f;
@@ -234,9 +247,16 @@ __global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float
 __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t chunks, uint64_t count, float* __restrict__ out) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= count) return;
-    float s = 0.f;
-    for (uint64_t r = 0; r < chunks; r++) s += partial[r * count + i];
-    out[i] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed 4-way interleave: deterministic, four loads in flight
+    uint64_t r = 0;
+    for (; r + 4 <= chunks; r += 4) {
+        s0 += partial[r * count + i];
+        s1 += partial[(r + 1) * count + i];
+        s2 += partial[(r + 2) * count + i];
+        s3 += partial[(r + 3) * count + i];
+    }
+    for (; r < chunks; r++) s0 += partial[r * count + i];
+    out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // Gram: partial[block][l*l] = sum over the block's row tiles of y_r^T y_r, f64 accumulation

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--knbn", type=int, default=12)
     ap.add_argument("--asked-dim", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-svd", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +118,23 @@ def main():
         dist.all_gather_into_tensor(dist_all, dist_l)
     else:
         nbr_all, dist_all = nbr_l, dist_l
+    # secondary figure (rank 0, N = 1): the dense range finder of tools::svdapprox on the data matrix itself --
+    # subspace_iteration_full + direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
+    svd_dense = None
+    if world == 1 and not args.no_dense_svd:
+        mat = A.MatRepr.from_array2(x.cpu().numpy())
+        A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))  # warm
+        L.check(L.load().ae_synchronize())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))
+        dt = (time.perf_counter() - t0) / 3
+        m_, n_, l_ = n, args.dim, 20
+        fl = 9 * 2 * m_ * n_ * l_ + 5 * 4 * m_ * l_ * l_ + 4 * 4 * n_ * l_ * l_ + 2 * m_ * n_ * l_  # SURVEY 8d, dense path
+        svd_dense = {"shape": "%dx%d rank 20 nbiter 5" % (m_, n_), "ms": dt * 1e3, "tflops": fl / dt / 1e12,
+                     "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
+                     "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
+        del mat
     del x
     indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
     nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
@@ -227,6 +245,7 @@ def main():
             "svd_init": {
                 "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
             },
+            "svd_dense": svd_dense,
             "samples_per_s": nb_sample * world * args.steps / elapsed,
             "ce_before": ce_before, "ce_after": ce_after,
         }
