@@ -389,7 +389,7 @@ void dmap_laplacian_device(const ae_kgraph* g, const ae_diffusion_params* dp, in
         // kernel0_to_density :855-952
         symmetrise_rowsum();
         scale_vec(q.p, (float)max_nbng);              // :888 / :931
-        scale_vec(q.p, seq_sum_f32(q.p, n) / (float)n);  // :889-891 / :932-933
+        scale_vec(q.p, ndarray_sum_f32(q.p, n) / (float)n);  // :889-891 / :932-933 (q.sum(): ndarray order)
         lap->q_density.alloc(n);
         AE_HIP(hipMemcpyAsync(lap->q_density.p, q.p, sizeof(float) * n, hipMemcpyDeviceToDevice, stream()));
         lap->beta_scales.alloc(n);
@@ -401,7 +401,7 @@ void dmap_laplacian_device(const ae_kgraph* g, const ae_diffusion_params* dp, in
     }
     // ---- compute_laplacian :427-587 ----
     symmetrise_rowsum();                                      // :468 / :538,:543
-    scale_vec(q.p, seq_sum_f32(q.p, n) / (float)max_nbng);    // :469-471 / :546-548  (sic: / max_nbng)
+    scale_vec(q.p, ndarray_sum_f32(q.p, n) / (float)max_nbng);    // :469-471 / :546-548  (sic: / max_nbng; q.sum(): ndarray order)
     DevBuf<float> deg(n);
     lap->normalizer.alloc(n);
     ae_matrepr& k = lap->sym_kernel;

@@ -482,27 +482,67 @@ __global__ void svqb_scale_kernel(const double* __restrict__ evals, const double
 }
 
 __global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
-    // exact left-to-right f32 sum (the reference's iter().sum::<f32>() order): the workgroup stages chunks in LDS
-    // with coalesced loads, lane 0 adds them in order
+    // exact left-to-right f32 sum (the reference's iter().sum::<f32>() / fold order): the workgroup stages chunks in
+    // LDS with coalesced loads, lane 0 adds them in order, always 16 values ahead in registers (the add chain, not
+    // the LDS latency, sets the pace)
     constexpr int CH = 4096;
-    __shared__ float buf[CH];
+    __shared__ float buf[CH + 16];
     float s = 0.f;
     for (uint64_t c0 = 0; c0 < n; c0 += CH) {
         const uint32_t m = (uint32_t)((n - c0) < (uint64_t)CH ? (n - c0) : (uint64_t)CH);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m; i += 256) buf[i] = x[(c0 + i) * stride];
+        for (uint32_t i = threadIdx.x; i < CH + 16; i += 256) buf[i] = i < m ? x[(c0 + i) * stride] : 0.f;
         __syncthreads();
         if (threadIdx.x == 0) {
+            const float4* b4 = reinterpret_cast<const float4*>(buf);
+            float4 a0 = b4[0], a1 = b4[1], a2 = b4[2], a3 = b4[3];
             uint32_t i = 0;
-            for (; i + 8 <= m; i += 8) {
-                const float v0 = buf[i], v1 = buf[i + 1], v2 = buf[i + 2], v3 = buf[i + 3];
-                const float v4 = buf[i + 4], v5 = buf[i + 5], v6 = buf[i + 6], v7 = buf[i + 7];
-                s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+            for (; i + 16 <= m; i += 16) {
+                const float4 n0 = b4[i / 4 + 4], n1 = b4[i / 4 + 5], n2 = b4[i / 4 + 6], n3 = b4[i / 4 + 7];  // next 16 (padding past m)
+                s += a0.x; s += a0.y; s += a0.z; s += a0.w; s += a1.x; s += a1.y; s += a1.z; s += a1.w;
+                s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w;
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3;
             }
             for (; i < m; i++) s += buf[i];
         }
     }
     if (threadIdx.x == 0) *out = s;
+}
+
+// ndarray's Array1::sum() order (numeric_util::unrolled_fold: eight interleaved accumulators, then
+// ((p0+p4) + (p1+p5)) ... and the tail), used by the reference for q.sum() (diffmaps.rs:469, :546, :889, :932).
+// Eight lanes run the eight chains.
+__global__ void __launch_bounds__(256) ndarray_sum_kernel(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    constexpr int CH = 4096;
+    __shared__ float buf[CH];
+    __shared__ float p8[8];
+    float p = 0.f;
+    const uint64_t n8 = n & ~7ull;
+    for (uint64_t c0 = 0; c0 < n8; c0 += CH) {
+        const uint32_t m = (uint32_t)((n8 - c0) < (uint64_t)CH ? (n8 - c0) : (uint64_t)CH);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += 256) buf[i] = x[c0 + i];
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            uint32_t i = threadIdx.x;
+            for (; i + 24 < m; i += 32) {
+                const float v0 = buf[i], v1 = buf[i + 8], v2 = buf[i + 16], v3 = buf[i + 24];
+                p += v0; p += v1; p += v2; p += v3;
+            }
+            for (; i < m; i += 8) p += buf[i];
+        }
+    }
+    if (threadIdx.x < 8) p8[threadIdx.x] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        acc = acc + (p8[0] + p8[4]);
+        acc = acc + (p8[1] + p8[5]);
+        acc = acc + (p8[2] + p8[6]);
+        acc = acc + (p8[3] + p8[7]);
+        for (uint64_t i = n8; i < n; i++) acc = acc + x[i];
+        *out = acc;
+    }
 }
 
 // transpose support ---------------------------------------------------------------------------
@@ -567,10 +607,20 @@ void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t 
 }
 
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
-    DevBuf<float> out(1);
+    static DevBuf<float> out;
+    if (!out.n) out.alloc(1);
     hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(256), 0, stream(), d_x, n, stride, out.p);
     check_launch("seq_sum");
     float h;
+    out.download(&h, 1);
+    return h;
+}
+float ndarray_sum_f32(const float* d_x, uint64_t n) {
+    static DevBuf<float> out;
+    if (!out.n) out.alloc(1);
+    hipLaunchKernelGGL(ndarray_sum_kernel, dim3(1), dim3(256), 0, stream(), d_x, n, out.p);
+    check_launch("ndarray_sum");
+    float h = 0.f;
     out.download(&h, 1);
     return h;
 }

@@ -347,6 +347,25 @@ static int lookup(const orc_trip *t, const uint64_t *rs, uint32_t i, uint32_t j,
     return 0;
 }
 
+/* ndarray's Array1::sum() on a contiguous array (ndarray 0.15/0.16 numeric_util::unrolled_fold, a dependency that is
+ * not vendored under /root/reference: order restated from its published source -- parity unpinned): eight interleaved
+ * accumulators p_k += x[8 t + k], combined as acc = 0 + (p0 + p4) + (p1 + p5) + (p2 + p6) + (p3 + p7), then the
+ * tail elements in order. */
+static float ndarray_sum_f32(const float *x, uint64_t n) {
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint64_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int k = 0; k < 8; k++) p[k] = p[k] + x[i + k];
+    float acc = 0.f;
+    acc = acc + (p[0] + p[4]);
+    acc = acc + (p[1] + p[5]);
+    acc = acc + (p[2] + p[6]);
+    acc = acc + (p[3] + p[7]);
+    for (; i < n; i++) acc = acc + x[i];
+    return acc;
+}
+float orc_ndarray_sum_f32(const float *x, uint64_t n) { return ndarray_sum_f32(x, n); }
+
 /* a4. kernel0_to_density, CSR branch, src/diffmaps.rs:898-942: q[n] (normalised density),
  * beta_scales[n] = q^beta * mean_scale. */
 void orc_dmap_density_csr(uint64_t n, const uint64_t *kindptr, const uint32_t *kcols, const float *kvals,
@@ -361,8 +380,7 @@ void orc_dmap_density_csr(uint64_t n, const uint64_t *kindptr, const uint32_t *k
         q[t[x].j] += sym;
     }
     for (uint64_t i = 0; i < n; i++) q[i] /= (float)max_nbng; /* :931 */
-    float s = 0.f;
-    for (uint64_t i = 0; i < n; i++) s += q[i];
+    float s = ndarray_sum_f32(q, n);                         /* q.sum(): ndarray order */
     float q_mean = s / (float)n;                             /* :932 */
     for (uint64_t i = 0; i < n; i++) q[i] /= q_mean;         /* :933 */
     for (uint64_t i = 0; i < n; i++) beta_scales[i] = powf(q[i], beta) * mean_scale; /* :938-942 */
@@ -387,8 +405,7 @@ void orc_dmap_laplacian_csr(uint64_t n, const uint64_t *kindptr, const uint32_t 
         rows[2 * x] = t[x].i; cols[2 * x] = t[x].j; vals[2 * x] = sym; q[t[x].i] += sym;
         rows[2 * x + 1] = t[x].j; cols[2 * x + 1] = t[x].i; vals[2 * x + 1] = sym; q[t[x].j] += sym;
     }
-    float qs = 0.f;
-    for (uint64_t i = 0; i < n; i++) qs += q[i];
+    float qs = ndarray_sum_f32(q, n);                         /* q.sum(): ndarray order */
     float q_mean = qs / (float)max_nbng;                      /* :546 (sic: / max_nbng) */
     for (uint64_t i = 0; i < n; i++) q[i] /= q_mean;          /* :548 */
     for (uint64_t x = 0; x < nt; x++) vals[x] /= powf(q[rows[x]] * q[cols[x]], alfa); /* :553-557 */
