@@ -625,14 +625,15 @@ class QualityReport:
         self.median_ratio, self.mean_ratio, self.quality = float(rep.median_ratio), float(rep.mean_ratio), float(rep.quality)
         self.ratio_by_node, self.first_dist = ratio_by_node, first_dist
 
-    def __str__(self):  # the reference's text, :695-731
-        fq = lambda q: " , ".join("%.2g : %.2e" % (p, v) for p, v in zip(QUALITY_PROBAS, q))
+    def __str__(self):  # the reference's text, :695-731, numbers in Rust's {:.2e} / {:.3e} form
+        from .io import format_e
+        fq = lambda q: " , ".join("%s : %s" % (p, format_e(v, 2)) for p, v in zip(QUALITY_PROBAS, q))
         return ("\n a guess at quality\n  neighbourhood size used in embedding : %d\n  nb neighbourhoods without a match : %d,  "
-                "mean number of neighbours conserved when match : %.3e\n  embedded radii quantiles at %s\n\n statistics on "
+                "mean number of neighbours conserved when match : %s\n  embedded radii quantiles at %s\n\n statistics on "
                 "conservation of neighborhood (of size nbng)\n  neighbourhood size used in target space : %d\n  quantiles at %s\n"
-                "  neighborhood are conserved in radius multiplied by median  : %.2e, mean %.2e" %
-                (self.kgraph_nbng, self.nb_without_match, self.mean_nbmatch, fq(self.radii_quantiles), self.nbng,
-                 fq(self.ratio_quantiles), self.median_ratio, self.mean_ratio))
+                "  neighborhood are conserved in radius multiplied by median  : %s, mean %s" %
+                (self.kgraph_nbng, self.nb_without_match, format_e(self.mean_nbmatch, 3), fq(self.radii_quantiles), self.nbng,
+                 fq(self.ratio_quantiles), format_e(self.median_ratio, 2), format_e(self.mean_ratio, 2)))
 
 
 def quality_estimate_from_edge_length(kgraph, y, nbng):

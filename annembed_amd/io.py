@@ -23,6 +23,17 @@ import numpy as np
 KGRAPH_MAGIC = b"AEKGRAPH"
 
 
+def format_e(x, prec):
+    """Rust `{:.<prec>e}` of an f64: mantissa with `prec` decimals, bare exponent ("5.07e0", "1.36e-1")"""
+    v = float(x)
+    if math.isnan(v):
+        return "NaN"
+    if math.isinf(v):
+        return "inf" if v > 0 else "-inf"
+    mant, exp = ("%.*e" % (prec, v)).split("e")
+    return "%se%d" % (mant, int(exp))
+
+
 def format_5e(x):
     """Rust `format!("{:.5e}", x as f32)`: 6 significant digits, exponent without sign padding ("1.23457e3", "-1.56250e-2")"""
     v = float(np.float32(x))
