@@ -108,3 +108,16 @@ def emulate_sharded_batch(make_backend, y, n, world, nb_samples, grad_step, it):
     for lo, hi, yr in outs:
         merged[lo:hi] = yr[lo:hi]
     return merged
+
+
+def library_stream():
+    """the library's HIP stream as a torch stream.  Running the per-batch collective under
+    `with torch.cuda.stream(library_stream()):` orders it after the batch's kernels and before the next batch's by
+    stream events (torch's NCCL/RCCL work waits on, and is waited by, the current stream): no host synchronisation
+    in the CE loop (bench.py)."""
+    import ctypes
+    import torch
+    from . import _lib as L
+    sp = ctypes.c_void_p()
+    L.check(L.load().ae_get_stream(ctypes.byref(sp)))
+    return torch.cuda.ExternalStream(sp.value)

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--asked-dim", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-svd", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the collective path with world size 1 (validation)")
     args = ap.parse_args()
 
     import torch
@@ -96,8 +97,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import annembed_amd as A
@@ -167,24 +172,30 @@ def main():
     ce_before = eo.ce_compute_threaded()
 
     y_all = None
-    if world > 1:
+    lib_stream = None
+    if use_dist:
         ptr, nn, dd = eo.device_coords()
 
         class _Arr:  # wraps the library's device buffer as a torch tensor (no copy)
             __cuda_array_interface__ = {"shape": (nn, dd), "typestr": "<f4", "data": (ptr, False), "version": 2}
         y_all = torch.as_tensor(_Arr(), device="cuda")
+        # the library's HIP stream as a torch stream: the collective is ordered after the batch's kernels and before the
+        # next batch's by stream events (torch's NCCL work waits on / is waited by the current stream) -- no host sync
+        import ctypes
+        sp = ctypes.c_void_p()
+        L.check(L.load().ae_get_stream(ctypes.byref(sp)))
+        lib_stream = torch.cuda.ExternalStream(sp.value)
 
     def one_step(it):
         eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / nb_batch), it)
-        if world > 1:
-            L.check(L.load().ae_synchronize())  # library stream -> torch stream hand-off
-            dist.all_gather_into_tensor(y_all, y_all[lo:hi].clone())
-            torch.cuda.current_stream().synchronize()  # the next batch reads the gathered replica
+        if use_dist:
+            with torch.cuda.stream(lib_stream):
+                dist.all_gather_into_tensor(y_all, y_all[lo:hi].clone())
 
     def fence():
         L.check(L.load().ae_synchronize())
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -201,7 +212,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eo.kernel_time()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -252,7 +263,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
