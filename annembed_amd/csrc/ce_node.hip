@@ -600,7 +600,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     static DevBuf<unsigned long long> prof_buf;
     a.prof = nullptr;
     if (getenv("AE_CE_PROF")) {
-        if (!prof_buf.n) { prof_buf.alloc(8); prof_buf.zero(); }
+        if (!prof_buf.n) { prof_buf.alloc(12); prof_buf.zero(); }
         a.prof = prof_buf.p;
     }
     const bool sharded = o->dev.shard_edges != o->dev.nnz;
@@ -628,10 +628,11 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     }
     check_launch("ce_node");
     if (a.prof) {
-        unsigned long long h[8];
-        prof_buf.download(h, 8);
-        if (h[6]) fprintf(stderr, "CEPROF waves=%llu per-wave cycles: [0] %.0f [1] %.0f [2] %.0f [3] %.0f [4] %.0f total %.0f\n", h[6],
-                          (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+        unsigned long long h[12];
+        prof_buf.download(h, 12);
+        if (h[6]) fprintf(stderr, "CEPROF waves=%llu per-wave cycles: A %.0f | B prepare %.0f replay %.0f | C scan %.0f park %.0f count+gather %.0f replay %.0f | total %.0f\n", h[6],
+                          (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[7] / h[6], (double)h[8] / h[6], (double)h[3] / h[6],
+                          (double)h[4] / h[6], (double)h[5] / h[6]);
         prof_buf.zero();
     }
 }

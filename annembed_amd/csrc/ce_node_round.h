@@ -79,6 +79,14 @@ __device__ __forceinline__ float repulse_coeff(float d, float inv_s2, float step
     }
 }
 
+// The workgroup is ONE wave: its LDS operations execute in program order, so making one lane's LDS writes visible to
+// the others needs no s_barrier -- and must not use __syncthreads(), whose workgroup-scope fence drains every
+// outstanding global load (vmcnt(0)) and would serialise the gathers that are deliberately left in flight.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int DIM, bool PAD, bool B1, int KMAX>
 __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     using Cfg = NodeKernelCfg<DIM>;
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     else { ib = c.indptr[v]; k = (uint32_t)(c.indptr[v + 1] - ib); }
     const uint32_t rk = round_hash_key(a.round_key, c.seed);
     const float step2 = 2.0f * a.step;
-    unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_begin = tk0;
 #define AE_TICK(i) if (a.prof) { const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); tk_acc[i] += tk1 - tk0; tk0 = tk1; }
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             if (t0 > 0) {
                 replay(cA);
                 // optional write-through after every chunk (AE_CE_STORE=0, see ce_node.hip)
-                if (a.store_mode != 2 && valid && cA.act) st(v, yv);
+                if (a.store_mode == 0 && valid && cA.act) st(v, yv);
             }
             cA = cB;
             AE_TICK(2)
@@ -302,10 +310,10 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
         for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
             prepare(t0, cA);
             replay(cA);
-            if (a.store_mode != 2 && valid && cA.act) st(v, yv);
+            if (a.store_mode == 0 && valid && cA.act) st(v, yv);
         }
     }
-    if (a.store_mode == 2 && valid && nv) st(v, yv);
+    if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
     // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,
     // gathers of the sources' rows, an exclusive scan of the counts = position of every push in the list of
     // pushes of the pass (zero counts vanish, a count of c takes c slots, a node's pushes are contiguous since
@@ -326,7 +334,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
 #pragma unroll
             for (int q = 0; q < NQ; q++) ld(cn[q] ? recA[q].src : v, yu[q]);
         };
-        if (t_begin + CH < t_end) load_recs(t_begin + CH, recB);
+        load_recs(t_begin + CH, recB);  // (clamped inside when past the end)
         count_and_gather(t_begin);
 #pragma nounroll
         for (uint64_t cb = t_begin; cb < t_end; cb += CH) {
@@ -338,47 +346,53 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); incl += lane >= off ? o : 0u; }
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t pos[NQ];
+            // everything the parking below needs, in registers of its own: the pipeline registers (recA, cn, yu) are
+            // refilled for the NEXT pass right away, unconditionally, so that those loads are in flight during this
+            // pass's parking and replay
+            uint32_t pos[NQ], cnP[NQ];
+            float pa[NQ], pb[NQ], pis2[NQ], yuP[NQ][DIM];
             {
                 uint32_t run = incl - mine_tot;
 #pragma unroll
-                for (int q = 0; q < NQ; q++) { pos[q] = run; s_pos[lane * NQ + q] = run; run += cn[q]; }
+                for (int q = 0; q < NQ; q++) {
+                    pos[q] = run;
+                    s_pos[lane * NQ + q] = run;
+                    run += cn[q];
+                    cnP[q] = cn[q];
+                    pis2[q] = rcp(recA[q].s_src * recA[q].s_src);
+                    pa[q] = B1 ? step2 * pis2[q] * (1.f - recA[q].w) : recA[q].w;
+                    pb[q] = B1 ? step2 * pis2[q] * recA[q].w : 0.f;
+#pragma unroll
+                    for (int t = 0; t < DIM; t++) yuP[q][t] = yu[q][t];
+                }
             }
             if (lane == 0) s_pos[CH] = total;
-            float pa[NQ], pb[NQ], pis2[NQ];
+            AE_TICK(7)
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                pis2[q] = rcp(recA[q].s_src * recA[q].s_src);
-                pa[q] = B1 ? step2 * pis2[q] * (1.f - recA[q].w) : recA[q].w;
-                pb[q] = B1 ? step2 * pis2[q] * recA[q].w : 0.f;
-            }
+            for (int q = 0; q < NQ; q++) recA[q] = recB[q];
+            count_and_gather(cb + CH);
+            load_recs(cb + 2 * CH, recB);
+            AE_TICK(3)
             const uint64_t lo = tb_v > cb ? tb_v : cb;
             const uint64_t hi = te_v < cb + CH ? te_v : cb + CH;
             const bool has_range = hi > lo;
-            const bool more = cb + CH < t_end;
 #pragma nounroll
             for (uint32_t w0 = 0; w0 < total; w0 += EC) {  // one window unless the pass holds more than EC pushes
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    for (uint32_t r = 0; r < cn[q]; r++) {
+                    for (uint32_t r = 0; r < cnP[q]; r++) {
                         const uint32_t e = pos[q] + r - w0;  // wraps below the window
                         if (e < (uint32_t)EC) {
 #pragma unroll
-                            for (int t = 0; t < DIM; t++) s_in_row[e * DIM + t] = yu[q][t];
+                            for (int t = 0; t < DIM; t++) s_in_row[e * DIM + t] = yuP[q][t];
                             s_in_a[e] = pa[q];
                             s_in_b[e] = pb[q];
                             s_in_is2[e] = pis2[q];
                         }
                     }
                 }
-                __syncthreads();
-                if (more && w0 + EC >= total) {  // last window: the next pass's counts and rows are in flight during the replay
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) recA[q] = recB[q];
-                    count_and_gather(cb + CH);
-                    if (cb + 2 * CH < t_end) load_recs(cb + 2 * CH, recB);
-                }
-                AE_TICK(3)
+                wave_lds_sync();
+                AE_TICK(8)
                 uint32_t pbeg = 0, pend = 0;
                 if (has_range) { pbeg = s_pos[(uint32_t)(lo - cb)]; pend = s_pos[(uint32_t)(hi - cb)]; }
                 pbeg = pbeg > w0 ? pbeg : w0;
@@ -423,19 +437,13 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
                     }
                 }
                 any_push |= len != 0u;
-                if (a.store_mode != 2 && valid && len) st(v, yv);
-                __syncthreads();
+                if (a.store_mode == 0 && valid && len) st(v, yv);
+                wave_lds_sync();
                 AE_TICK(4)
-            }
-            if (more && total == 0u) {  // no window ran: advance the pipeline here
-#pragma unroll
-                for (int q = 0; q < NQ; q++) recA[q] = recB[q];
-                count_and_gather(cb + CH);
-                if (cb + 2 * CH < t_end) load_recs(cb + 2 * CH, recB);
             }
         }
     }
-    if (a.store_mode == 2 && any_push && valid) st(v, yv);
+    if (valid && ((a.store_mode == 2 && any_push) || (a.store_mode == 3 && (any_push || nv)))) st(v, yv);
     // samples drawn: one atomic per wave, spread over 1024 counters (a single address serialises at ~12 ns each)
     unsigned long long mine = valid ? (unsigned long long)nv : 0ull;
 #pragma unroll
@@ -446,6 +454,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
         for (int i = 0; i < 5; i++) atomicAdd(&a.prof[i], tk_acc[i]);
         atomicAdd(&a.prof[5], tend - tk_begin);
         atomicAdd(&a.prof[6], 1ull);
+        for (int i = 7; i < 10; i++) atomicAdd(&a.prof[i], tk_acc[i]);  // finer split of the in-edge staging
     }
 #undef AE_TICK
 }
