@@ -263,23 +263,25 @@ def test_hogwild_statistics_match_oracle(A, oracle):
     assert np.quantile(lr, 0.5) > 1.4 * np.quantile(lo, 0.5)
 
 
-@pytest.mark.parametrize("dim,k,hub", [(5, 8, False), (10, 20, True), (20, 28, False), (3, 32, False), (7, 12, True)])
-def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub):
-    """asked_dim without an exact kernel instantiation (run zero-padded to 8 / 16 / 32 columns) and rows of up to 32
-    neighbours: same statistical bar as the 2-D case against the oracle's sequential run."""
+@pytest.mark.parametrize("dim,k,hub,b", [(5, 8, False, 1.0), (10, 20, True, 1.0), (20, 28, False, 1.0), (3, 32, False, 1.0), (7, 12, True, 1.0),
+                                         (2, 10, False, 0.8), (6, 20, True, 1.3)])
+def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub, b):
+    """asked_dim without an exact kernel instantiation (run zero-padded to 8 / 16 / 32 columns), rows of up to 32
+    neighbours, hubness-weighted negatives, exponent b != 1: same statistical bar as the 2-D case against the
+    oracle's sequential run."""
     n = 4000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
     g = A.KGraph(indptr, nbr, dist)
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
     y0 = oracle.set_data_box(np.random.default_rng(dim).normal(size=(n, dim)).astype(np.float32), 10.0)
     hubc = g.hubness() if hub else None
-    par = A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub)
+    par = A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b)
     eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), par, y0, hub_counts=hubc)
     nb_sample = 10 * len(nbr)
     for it in range(1, 6):
         eo.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
     y, ce1 = eo.get_embedded(), eo.ce_compute_threaded()
-    yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc)
+    yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc, b=b)
     assert np.isfinite(y).all() and y.shape == (n, dim)
     assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
     src = np.repeat(np.arange(n), k)
