@@ -259,53 +259,7 @@ __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t
     out[i] = (s0 + s1) + (s2 + s3);
 }
 
-// Gram: partial[block][l*l] = sum over the block's row tiles of y_r^T y_r, f64 accumulation
 constexpr int kGramTile = 64;
-__global__ void __launch_bounds__(256) gram_partial_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,
-                                                           double* __restrict__ partial) {
-    __shared__ float tile[kGramTile * kMaxL];
-    const uint32_t npairs = l * l;
-    double acc[(kMaxL * kMaxL + 255) / 256];
-#pragma unroll
-    for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) acc[p] = 0.;
-    const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint64_t r0 = t * kGramTile;
-        const uint32_t nr = (uint32_t)(rows - r0 < kGramTile ? rows - r0 : kGramTile);
-        __syncthreads();
-        for (uint32_t idx = threadIdx.x; idx < nr * l; idx += 256) tile[idx] = y[r0 * l + idx];
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) {
-            const uint32_t pair = p * 256 + threadIdx.x;
-            if (pair < npairs) {
-                const uint32_t a = pair / l, b = pair % l;
-                double s = 0.;
-                for (uint32_t r = 0; r < nr; r++) s += (double)tile[r * l + a] * (double)tile[r * l + b];
-                acc[p] += s;
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < (kMaxL * kMaxL + 255) / 256; p++) {
-        const uint32_t pair = p * 256 + threadIdx.x;
-        if (pair < npairs) partial[(uint64_t)blockIdx.x * npairs + pair] = acc[p];
-    }
-}
-__global__ void gram_reduce_kernel(const double* __restrict__ partial, uint32_t nblocks, uint32_t npairs, double* __restrict__ g) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npairs) return;
-    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;  // fixed 4-way interleave: deterministic
-    uint32_t b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += partial[(uint64_t)b * npairs + p];
-        s1 += partial[(uint64_t)(b + 1) * npairs + p];
-        s2 += partial[(uint64_t)(b + 2) * npairs + p];
-        s3 += partial[(uint64_t)(b + 3) * npairs + p];
-    }
-    for (; b < nblocks; b++) s0 += partial[(uint64_t)b * npairs + p];
-    g[p] = (s0 + s1) + (s2 + s3);
-}
 
 // out tile = y tile * M ; each workgroup owns kGramTile rows, staged through LDS so that in-place is safe
 __global__ void __launch_bounds__(256) apply_panel_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,

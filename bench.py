@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--asked-dim", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-svd", action="store_true")
+    ap.add_argument("--lattice-graph", action="store_true",
+                    help="scale runs (C3 / C4 shapes): ring-lattice kNN graph with gamma-distributed distances instead of an exact kNN of synthetic points (an 11 M-point exact kNN is out of reach of brute force)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path with world size 1 (validation)")
     args = ap.parse_args()
 
@@ -114,37 +116,47 @@ def main():
     lo, hi = rank * ppg, (rank + 1) * ppg
 
     # ---------------- input preparation (untimed) ----------------
-    x = synth_points(n, args.dim, seed=1)
-    nbr_l, dist_l = knn_rows(x, lo, hi, k)
-    if world > 1:
-        nbr_all = torch.empty((n, k), dtype=torch.int64, device=x.device)
-        dist_all = torch.empty((n, k), dtype=torch.float32, device=x.device)
-        dist.all_gather_into_tensor(nbr_all, nbr_l)
-        dist.all_gather_into_tensor(dist_all, dist_l)
+    if args.lattice_graph:
+        rng = np.random.default_rng(1)
+        base = np.arange(n, dtype=np.int64)
+        offs = np.array([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597][:(k + 1) // 2])
+        cols = [(base + o) % n for o in offs] + [(base - o) % n for o in offs]
+        nbr = np.stack(cols[:k], 1).astype(np.uint32).reshape(-1)
+        dst = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1).reshape(-1)
+        indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+        svd_dense = None
     else:
-        nbr_all, dist_all = nbr_l, dist_l
-    # secondary figure (rank 0, N = 1): the dense range finder of tools::svdapprox on the data matrix itself --
-    # subspace_iteration_full + direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
-    svd_dense = None
-    if world == 1 and not args.no_dense_svd:
-        mat = A.MatRepr.from_array2(x.cpu().numpy())
-        A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))  # warm
-        L.check(L.load().ae_synchronize())
-        t0 = time.perf_counter()
-        for _ in range(3):
-            A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))
-        dt = (time.perf_counter() - t0) / 3
-        m_, n_, l_ = n, args.dim, 20
-        fl = 9 * 2 * m_ * n_ * l_ + 5 * 4 * m_ * l_ * l_ + 4 * 4 * n_ * l_ * l_ + 2 * m_ * n_ * l_  # SURVEY 8d, dense path
-        svd_dense = {"shape": "%dx%d rank 20 nbiter 5" % (m_, n_), "ms": dt * 1e3, "tflops": fl / dt / 1e12,
-                     "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
-                     "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
-        del mat
-    del x
-    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
-    nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
-    dst = dist_all.cpu().numpy().reshape(-1)
-    del nbr_all, dist_all, nbr_l, dist_l
+        x = synth_points(n, args.dim, seed=1)
+        nbr_l, dist_l = knn_rows(x, lo, hi, k)
+        if world > 1:
+            nbr_all = torch.empty((n, k), dtype=torch.int64, device=x.device)
+            dist_all = torch.empty((n, k), dtype=torch.float32, device=x.device)
+            dist.all_gather_into_tensor(nbr_all, nbr_l)
+            dist.all_gather_into_tensor(dist_all, dist_l)
+        else:
+            nbr_all, dist_all = nbr_l, dist_l
+        # secondary figure (rank 0, N = 1): the dense range finder of tools::svdapprox on the data matrix itself --
+        # subspace_iteration_full + direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
+        svd_dense = None
+        if world == 1 and not args.no_dense_svd:
+            mat = A.MatRepr.from_array2(x.cpu().numpy())
+            A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))  # warm
+            L.check(L.load().ae_synchronize())
+            t0 = time.perf_counter()
+            for _ in range(3):
+                A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))
+            dt = (time.perf_counter() - t0) / 3
+            m_, n_, l_ = n, args.dim, 20
+            fl = 9 * 2 * m_ * n_ * l_ + 5 * 4 * m_ * l_ * l_ + 4 * 4 * n_ * l_ * l_ + 2 * m_ * n_ * l_  # SURVEY 8d, dense path
+            svd_dense = {"shape": "%dx%d rank 20 nbiter 5" % (m_, n_), "ms": dt * 1e3, "tflops": fl / dt / 1e12,
+                         "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
+                         "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
+            del mat
+        del x
+        indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+        nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
+        dst = dist_all.cpu().numpy().reshape(-1)
+        del nbr_all, dist_all, nbr_l, dist_l
     torch.cuda.empty_cache()
     kg = A.KGraph(indptr, nbr, dst, k)
 
@@ -228,7 +240,9 @@ def main():
         launch_ms = kernel_ms / rounds if rounds else 0.0
         bytes_per_launch = bytes_per_sample * nb_sample / max(rounds, 1)
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = pmc_traffic()
+        # the committed PMC passes are of the default single-GPU workload only
+        default_workload = (world == 1 and not args.lattice_graph and ppg == 60000 and k == 12 and d == 2 and args.dim == 784)
+        traffic = pmc_traffic() if default_workload else None
         out = {
             "metric": "embedded_points_per_sec_ce_epoch",
             "value": points_per_s,
@@ -243,8 +257,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1]); %d points per GPU"
-                            % (n, args.dim, d, k, ppg),
+                "workload": ("ring-lattice kNN graph %d nodes -> %dD, k=%d, dmap init + CE loop (scale run); %d points per GPU" % (n, d, k, ppg))
+                            if args.lattice_graph else
+                            ("MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1]); %d points per GPU"
+                             % (n, args.dim, d, k, ppg)),
                 "nb_sampling_by_edge": 10, "samples_per_step": int(nb_sample * world), "sampler": "rowcdf", "ce_mode": "hogwild",
             },
             "roofline": {
