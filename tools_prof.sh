@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_sq.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_write.log 2>&1
 cd $OUT
