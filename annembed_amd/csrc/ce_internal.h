@@ -67,6 +67,7 @@ struct ae_entropy_optim {
     DevBuf<InEdge> tin;
     DevBuf<unsigned long long> sample_counter;  // samples actually drawn (Poisson total), for verification
     uint32_t rounds = 1;
+    float in_weight_max = 1.f;                  // largest sum of in-edge probabilities over the nodes (sizes the rounds)
     DevBuf<uint8_t> cnt;     // per-edge sample counts of the current round
     DevBuf<uint32_t> tot;    // per-node planned out-samples
     DevBuf<uint32_t> plan;   // per-node sample plans (cap slots x 6 words)

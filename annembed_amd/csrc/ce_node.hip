@@ -510,6 +510,16 @@ __global__ void in_edge_fill_kernel(uint64_t nnz, const uint64_t* __restrict__ k
     tin[x] = r;
 }
 
+// largest in-weight W_in(v) = sum of p_e over the in-edges of v (as a float bit pattern: weights are positive)
+__global__ void in_weight_max_kernel(uint64_t n, const uint64_t* __restrict__ tptr, const InEdge* __restrict__ tin, unsigned int* __restrict__ out) {
+    const uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    float w = 0.f;
+    if (v < n)
+        for (uint64_t x = tptr[v]; x < tptr[v + 1]; x++) w += tin[x].w;
+    for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(w));
+}
+
 template <int DIM>
 void launch_round_fused(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
     if constexpr (DIM > 0) {
@@ -559,7 +569,14 @@ void ce_node_build_transpose(ae_entropy_optim* o) {
     rowptr_from_sorted_keys(k1.p, g->nnz, g->n, o->tptr.p);
     o->sample_counter.alloc(1024);
     o->sample_counter.zero();
-    sync();
+    DevBuf<unsigned int> wmax(1);
+    wmax.zero();
+    hipLaunchKernelGGL(in_weight_max_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), g->n, (const uint64_t*)o->tptr.p,
+                       (const InEdge*)o->tin.p, wmax.p);
+    check_launch("in_weight_max");
+    unsigned int bits = 0;
+    wmax.download(&bits, 1);
+    memcpy(&o->in_weight_max, &bits, sizeof(float));
 }
 
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
@@ -575,7 +592,11 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     const bool node_kernel = node_kernel_ok(o) && !(force_legacy && legacy_dim(o->dev.dim));
     double per_round_target = node_kernel ? 8.0 : 12.0;
     if (getenv("AE_CE_PER_ROUND")) per_round_target = atof(getenv("AE_CE_PER_ROUND"));
-    const uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / per_round_target));
+    uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / per_round_target));
+    // hubs: a node of in-weight W receives per_node * W / rounds pushes per round, all evaluated against round-start
+    // source rows; keep that below 128 (no effect on graphs whose largest in-weight is below ~16)
+    if (!getenv("AE_CE_PER_ROUND"))
+        rounds = std::max(rounds, (uint32_t)std::min(1000.0, std::ceil(per_node * (double)o->in_weight_max / 128.0)));
     o->rounds = rounds;
     if (iter >= (1u << 20) || rounds >= (1u << 10)) fail(AE_ERR_INVALID_ARG, "iteration / round index too large for the RNG key");
     const double per_round = per_node / (double)rounds;

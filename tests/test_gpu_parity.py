@@ -317,11 +317,11 @@ def test_hogwild_hub_and_ragged_rows(A, oracle):
     y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5), y0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5)
     assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
-    # measured 0.75: a node with 3000 in-edges is where the round structure departs most from the sequential order
-    assert abs(ce1 - oce1) < 0.35 * oce1, (ce1, oce1)
+    # rounds are sized by the largest in-weight too (176 rounds here instead of 8): measured 0.89 (0.75 without)
+    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
     src = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
     lg, lo = np.linalg.norm(y[src] - y[nbr], axis=1), np.linalg.norm(yo[src] - yo[nbr], axis=1)
-    assert abs(np.median(lg) - np.median(lo)) < 0.35 * np.median(lo)  # measured +23 % (same cause)
+    assert abs(np.median(lg) - np.median(lo)) < 0.2 * np.median(lo)  # measured +3 % (+23 % without)
 
 
 def test_hogwild_unsupported_shape_fails_loudly(A, oracle):
