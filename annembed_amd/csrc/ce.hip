@@ -17,9 +17,15 @@
 #include <algorithm>
 
 #include "ce_internal.h"
+#include <chrono>
 #include "philox.h"
 
 using namespace ae;
+
+namespace ae {
+void sort_keys_u64(uint64_t* d_keys_in, uint64_t* d_keys_out, uint64_t count, unsigned end_bit);
+void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrows, uint64_t* d_rowptr);
+}  // namespace ae
 
 #pragma clang fp contract(off)
 
@@ -138,17 +144,14 @@ __device__ __forceinline__ double grad_coeff(double d_scaled, double scale, doub
     return 2. * b * cw / (scale * scale);
 }
 
-// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample
+// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample, on rows held in registers: yi / yj are updated in place
+// (the values the reference stores at :1301 / :1239), yk are the five negatives' rows
 template <int DIM>
-__device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, double grad_step) {
-    float yi[DIM], yj[DIM], grad[DIM];
-    load_row<DIM>(c.y, p.i, yi);  // :1185
-    load_row<DIM>(c.y, p.j, yj);  // :1186
+__device__ __forceinline__ void sample_update(float* yi, float* yj, const float (*yk)[DIM], float w, double scale, double b, double grad_step) {
+    float grad[DIM];
 #pragma unroll
     for (int t = 0; t < DIM; t++) grad[t] = 0.f;  // :1199
-    const double weight = (double)p.w;              // :1202
-    const double scale = (double)c.emb_scale[p.i];  // :1204
-    const double b = c.b;
+    const double weight = (double)w;                // :1202
     float acc = 0.f;
 #pragma unroll
     for (int t = 0; t < DIM; t++) {  // :1207-1211
@@ -170,15 +173,12 @@ __device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, doub
         yi[t] -= grad[t];
         yj[t] += grad[t];
     }
-    store_row<DIM>(c.y, p.j, yj);  // :1239
 #pragma unroll
     for (int g = 0; g < 5; g++) {  // :1244-1299
-        float yk[DIM];
-        load_row<DIM>(c.y, p.k[g], yk);
         float ak = 0.f;
 #pragma unroll
         for (int t = 0; t < DIM; t++) {  // :1267-1271
-            float df = yi[t] - yk[t];
+            float df = yi[t] - yk[g][t];
             ak += df * df;
         }
         const double d_ik = (double)ak;
@@ -189,11 +189,24 @@ __device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, doub
             const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
             const float cf = (float)coeff_ik;
 #pragma unroll
-            for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
+            for (int t = 0; t < DIM; t++) grad[t] = (yk[g][t] - yi[t]) * cf;
         }  // else: `gradient` keeps its previous value, as in the reference
 #pragma unroll
         for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
     }
+}
+
+// in-place form: rows read from / written to the coordinate array (the negatives are never i or j, :1246-1253, so
+// reading them before the stores equals the reference's order)
+template <int DIM>
+__device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, double grad_step) {
+    float yi[DIM], yj[DIM], yk[5][DIM];
+    load_row<DIM>(c.y, p.i, yi);  // :1185
+    load_row<DIM>(c.y, p.j, yj);  // :1186
+#pragma unroll
+    for (int g = 0; g < 5; g++) load_row<DIM>(c.y, p.k[g], yk[g]);
+    sample_update<DIM>(yi, yj, yk, p.w, (double)c.emb_scale[p.i], c.b, grad_step);
+    store_row<DIM>(c.y, p.j, yj);  // :1239
     store_row<DIM>(c.y, p.i, yi);  // :1301
 }
 
@@ -279,6 +292,158 @@ __global__ void __launch_bounds__(256) ce_sgd_planned_kernel(CeDev c, const uint
     p.w = plan_w[s];
     if constexpr (DIM == 0) apply_sample_dyn(c, p, grad_step);
     else apply_sample<DIM>(c, p, grad_step);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// AE_CE_SEQUENTIAL, device-scheduled ("dataflow") form.  Executing samples 0, 1, 2, ... in order is equivalent to:
+// every sample reads, for each of its 7 nodes, the row produced by the LAST EARLIER sample that wrote that node (or the
+// batch's initial row), and publishes its two new rows (y_i, y_j) as new versions.  With versions instead of in-place
+// stores there are no write-after-read or write-after-write hazards, only the true dependencies remain (C2: depth 4 323
+// instead of 7 191 levels).  So:
+//   1. ce_plan_kernel draws the node sets (as before);
+//   2. the 2 S write events (node, sample, slot) are radix-sorted, a CSR over nodes is built, and every sample finds
+//      its 7 predecessors by binary search in its nodes' write lists -- all parallel, nothing on the host;
+//   3. a persistent grid runs the samples in index order: a lane polls the version rows of its predecessors (a row is
+//      published by its own stores, see df_try_load_version), takes each as soon as it exists, applies the sample
+//      (same f64 arithmetic as the in-place form: bit-exact) and publishes its two rows.  Every sample only waits for
+//      smaller sample indices and all lanes are resident (cooperative launch), so the smallest unfinished sample can
+//      always run: no deadlock; a poll budget turns any violation of that argument into an error instead of a hang;
+//   4. the last version of every written node is copied back into the coordinate array.
+constexpr uint32_t kNoPred = 0xFFFFFFFFu;
+
+__global__ void df_write_keys_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, uint64_t* __restrict__ keys) {
+    const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    keys[2 * s] = ((uint64_t)plan_nodes[s * 7] << 32) | (s << 1);
+    keys[2 * s + 1] = ((uint64_t)plan_nodes[s * 7 + 1] << 32) | (s << 1) | 1ull;
+}
+
+// pred[s * 7 + t] = (sample << 1 | slot) of the last write of node plan_nodes[s * 7 + t] by a sample < s, or kNoPred
+__global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint64_t* __restrict__ keys,
+                               const uint64_t* __restrict__ rowptr, uint32_t* __restrict__ pred) {
+    const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (idx >= S * 7) return;
+    const uint64_t s = idx / 7;
+    const uint32_t x = plan_nodes[idx];
+    uint64_t lo = rowptr[x], hi = rowptr[x + 1];  // first key of node x with sample >= s: lower bound on (sample)
+    const uint64_t base = lo;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (((keys[mid] & 0xFFFFFFFFull) >> 1) < s) lo = mid + 1;
+        else hi = mid;
+    }
+    pred[idx] = lo > base ? (uint32_t)(keys[lo - 1] & 0xFFFFFFFFull) : kNoPred;
+}
+
+// A version row is published by its stores alone: the buffer is filled with an all-ones pattern (a NaN no arithmetic
+// produces: hardware NaNs are the canonical 0x7FC00000) before the kernel, a reader polls the row itself and takes it
+// once every part differs from the pattern -- one memory round trip per dependency hop instead of flag + data.
+constexpr uint64_t kUnpublished64 = ~0ull;
+constexpr uint32_t kUnpublished32 = ~0u;
+template <int DIM>
+__device__ __forceinline__ bool df_try_load_version(const float* __restrict__ ver, uint32_t pv, float* out) {
+    const float* p = ver + (uint64_t)pv * DIM;  // version index = sample * 2 + slot
+    bool ok = true;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= bits != kUnpublished64;
+            out[2 * q] = __uint_as_float((uint32_t)bits);
+            out[2 * q + 1] = __uint_as_float((uint32_t)(bits >> 32));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) {
+            const uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= bits != kUnpublished32;
+            out[t] = __uint_as_float(bits);
+        }
+    }
+    return ok;
+}
+template <int DIM>
+__device__ __forceinline__ void df_store_version(float* __restrict__ ver, uint64_t v, const float* in) {
+    float* p = ver + v * DIM;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
+                                                          const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
+                                                          float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t sweeps = (S + nthreads - 1) / nthreads;
+    for (uint64_t k = 0; k < sweeps; k++) {  // wave-uniform trip count; sample indices increase with k
+        const uint64_t s = k * nthreads + tid;
+        bool finished = s >= S;
+        uint32_t node[7], pr[7];
+        float rows[7][DIM];
+        float w = 0.f;
+        uint32_t pending = 0;  // bit t: row t not gathered yet
+        if (!finished) {
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                node[t] = plan_nodes[s * 7 + t];
+                pr[t] = pred[s * 7 + t];
+                if (pr[t] == kNoPred) load_row<DIM>(c.y, node[t], rows[t]);  // the batch's initial row: c.y is read-only here
+                else pending |= 1u << t;
+            }
+            w = plan_w[s];
+        }
+        uint32_t polls = 0;
+        while (!__all(finished)) {
+            if (!finished) {
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    if ((pending >> t) & 1u) {
+                        float tmp[DIM];
+                        if (df_try_load_version<DIM>(ver, pr[t], tmp)) {
+#pragma unroll
+                            for (int q = 0; q < DIM; q++) rows[t][q] = tmp[q];
+                            pending &= ~(1u << t);
+                        }
+                    }
+                }
+                if (pending == 0u) {
+                    sample_update<DIM>(rows[0], rows[1], rows + 2, w, (double)c.emb_scale[node[0]], c.b, grad_step);
+                    df_store_version<DIM>(ver, s * 2, rows[0]);
+                    df_store_version<DIM>(ver, s * 2 + 1, rows[1]);
+                    finished = true;
+                } else if (++polls > (1u << 24)) {  // cannot happen (see above): fail instead of hanging
+                    atomicOr(err, 8u);
+                    float zero[DIM];
+#pragma unroll
+                    for (int q = 0; q < DIM; q++) zero[q] = 0.f;
+                    df_store_version<DIM>(ver, s * 2, zero);  // unblock the successors; the host reports the error
+                    df_store_version<DIM>(ver, s * 2 + 1, zero);
+                    finished = true;
+                }
+            }
+            if (!__all(finished)) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// the last version of every node written in the batch becomes its row in the coordinate array
+template <int DIM>
+__global__ void df_commit_kernel(uint64_t n, const uint64_t* __restrict__ rowptr, const uint64_t* __restrict__ keys,
+                                 const float* __restrict__ ver, float* __restrict__ y) {
+    const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (x >= n || rowptr[x + 1] == rowptr[x]) return;
+    const uint32_t pv = (uint32_t)(keys[rowptr[x + 1] - 1] & 0xFFFFFFFFull);
+#pragma unroll
+    for (int t = 0; t < DIM; t++) y[x * DIM + t] = ver[(uint64_t)pv * DIM + t];
 }
 
 // cauchy_edge_weight (:1322-1345) + ce_compute_threaded (:1127-1163): per-block partial sums in f64
@@ -388,7 +553,85 @@ static void check_err_flag(ae_entropy_optim* o) {
     if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
 }
 
+template <int DIM>
+static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const uint64_t* rowptr, const uint64_t* keys) {
+    if constexpr (DIM > 0) {
+        static int blocks_per_cu = 0, cus = 0;
+        if (!blocks_per_cu) {
+            int dev = 0;
+            AE_HIP(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            AE_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount;
+        }
+        int bpc = 0;
+        AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, 256, 0));
+        blocks_per_cu = std::max(1, std::min(bpc, 2));
+        // few lanes in flight: the run is bound by the dependency chain (one memory round trip + one sample's f64
+        // arithmetic per hop), more pollers only add traffic (measured on MI355X: 128 x 64 lanes 30 ms, 256 x 64 34 ms,
+        // 1024 x 256 67 ms per C2 batch)
+        const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 64u;
+        unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)blocks_per_cu * cus, blocks_for(S, bs));
+        grid = std::min<unsigned>(grid, getenv("AE_DF_GRID") ? (unsigned)atoi(getenv("AE_DF_GRID")) : 128u);
+        CeDev dev = o->dev;
+        const uint32_t* pn = o->plan_nodes.p;
+        const float* pw = o->plan_w.p;
+        const uint32_t* pred = o->df_pred.p;
+        float* ver = o->df_ver.p;
+        unsigned int* err = o->err.p;
+        void* args[] = {&dev, &S, &pn, &pw, &pred, &ver, &step, &err};
+        AE_HIP(hipMemsetAsync(ver, 0xFF, sizeof(float) * S * 2 * DIM, stream()));  // every version "unpublished"
+        // cooperative launch: the runtime refuses a grid that cannot be resident at once (the progress argument needs it)
+        AE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<void*>(ce_dataflow_kernel<DIM>), dim3(grid), dim3(bs), args, 0, stream()));
+        hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
+                           (const float*)ver, o->dev.y);
+    }
+}
+
+// AE_CE_SEQUENTIAL scheduled on the device (see the dataflow kernels above)
+static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter) {
+    if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
+    const uint32_t dim = o->dev.dim;
+    if (o->plan_nodes.n < S * 7) o->plan_nodes.alloc(S * 7);
+    if (o->plan_w.n < S) o->plan_w.alloc(S);
+    if (o->df_pred.n < S * 7) o->df_pred.alloc(S * 7);
+    if (o->df_ver.n < S * 2 * dim) o->df_ver.alloc(S * 2 * dim);
+    if (o->df_keys0.n < 2 * S) { o->df_keys0.alloc(2 * S); o->df_keys1.alloc(2 * S); }
+    if (o->df_rowptr.n < o->dev.n + 1) o->df_rowptr.alloc(o->dev.n + 1);
+    const bool prof = getenv("AE_CE_PROF") != nullptr;
+    auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(S, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset, S, iter, o->plan_nodes.p,
+                       o->plan_w.p, o->err.p);
+    check_launch("ce_plan");
+    const double t1 = now();
+    hipLaunchKernelGGL(df_write_keys_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p, o->df_keys0.p);
+    unsigned node_bits = 1;
+    while (node_bits < 32 && (o->dev.n >> node_bits)) node_bits++;
+    sort_keys_u64(o->df_keys0.p, o->df_keys1.p, 2 * S, 32 + node_bits);
+    rowptr_from_sorted_keys(o->df_keys1.p, 2 * S, o->dev.n, o->df_rowptr.p);
+    hipLaunchKernelGGL(df_pred_kernel, dim3(blocks_for(S * 7, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p,
+                       (const uint64_t*)o->df_keys1.p, (const uint64_t*)o->df_rowptr.p, o->df_pred.p);
+    check_launch("df_pred");
+    const double t2 = now();
+    AE_DISPATCH_DIM(dim, launch_dataflow, o, S, step, (const uint64_t*)o->df_rowptr.p, (const uint64_t*)o->df_keys1.p);
+    check_launch("ce_dataflow");
+    sync();
+    if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan %.2f ms, sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
+                      (unsigned long long)S, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now() - t2) * 1e3);
+    unsigned int h = 0;
+    o->err.download(&h, 1);
+    if (h & 8u) fail(AE_ERR_STATE, "sequential dataflow kernel: poll budget exceeded (scheduling invariant violated)");
+    check_err_flag(o);
+}
+
 static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
+    // device-scheduled form for the instantiated dimensions; AE_CE_SEQ_LEVELS=1 keeps the host level schedule (A/B)
+    const uint32_t d = o->dev.dim;
+    if ((d == 2 || d == 3 || d == 4 || d == 8 || d == 16) && !getenv("AE_CE_SEQ_LEVELS")) {
+        run_sequential_dataflow(o, nb_sample, step, iter);
+        return;
+    }
     if (nb_sample >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^32 samples per batch");
     if (o->plan_nodes.n < nb_sample * 7) o->plan_nodes.alloc(nb_sample * 7);
     if (o->plan_w.n < nb_sample) o->plan_w.alloc(nb_sample);
@@ -396,8 +639,12 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
     hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(nb_sample, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset, nb_sample,
                        iter, o->plan_nodes.p, o->plan_w.p, o->err.p);
     check_launch("ce_plan");
+    const bool prof = getenv("AE_CE_PROF") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     std::vector<uint32_t> nodes(nb_sample * 7);
     o->plan_nodes.download(nodes.data(), nb_sample * 7);
+    const double t1 = now();
     check_err_flag(o);
     // level schedule: sample s runs after every earlier sample that wrote a node it touches and after
     // every earlier sample that read a node it writes  =>  identical to sequential execution.
@@ -415,6 +662,19 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
         for (int g = 0; g < 5; g++) last_r[p[2 + g]] = std::max(last_r[p[2 + g]], l);
         max_level = std::max(max_level, l);
     }
+    uint32_t raw_depth = 0;
+    if (prof) {  // depth of the true (read-after-write) dependencies alone: what a multi-version schedule would need
+        std::vector<uint32_t> lw(n, 0);
+        for (uint64_t s = 0; s < nb_sample; s++) {
+            const uint32_t* p = &nodes[s * 7];
+            uint32_t l = 0;
+            for (int g = 0; g < 7; g++) l = std::max(l, lw[p[g]]);
+            l += 1;
+            lw[p[0]] = l;
+            lw[p[1]] = l;
+            raw_depth = std::max(raw_depth, l);
+        }
+    }
     std::vector<uint64_t> off(max_level + 2, 0);
     for (uint64_t s = 0; s < nb_sample; s++) off[level[s] + 1]++;
     for (uint32_t l = 0; l <= max_level; l++) off[l + 1] += off[l];
@@ -423,6 +683,7 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
         std::vector<uint64_t> cur(off.begin(), off.end() - 1);
         for (uint64_t s = 0; s < nb_sample; s++) order[cur[level[s]]++] = (uint32_t)s;
     }
+    const double t2 = now();
     o->order.upload(order.data(), nb_sample);
     for (uint32_t l = 1; l <= max_level; l++) {
         uint64_t cnt = off[l + 1] - off[l];
@@ -431,6 +692,9 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
     }
     check_launch("ce_sgd_planned");
     sync();
+    if (prof)
+        fprintf(stderr, "CESEQ samples=%llu levels=%u (read-after-write depth %u) plan+download %.1f ms, host schedule %.1f ms, upload+%u launches %.1f ms\n",
+                (unsigned long long)nb_sample, max_level, raw_depth, (t1 - t0) * 1e3, (t2 - t1) * 1e3, max_level, (now() - t2) * 1e3);
 }
 
 

