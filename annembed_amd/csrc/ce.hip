@@ -566,13 +566,15 @@ static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const 
         }
         int bpc = 0;
         AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, 256, 0));
-        blocks_per_cu = std::max(1, std::min(bpc, 2));
+        blocks_per_cu = std::max(1, std::min(bpc, 8));
         // few lanes in flight: the run is bound by the dependency chain (one memory round trip + one sample's f64
         // arithmetic per hop), more pollers only add traffic (measured on MI355X: 128 x 64 lanes 30 ms, 256 x 64 34 ms,
         // 1024 x 256 67 ms per C2 batch)
         const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 64u;
         unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)blocks_per_cu * cus, blocks_for(S, bs));
-        grid = std::min<unsigned>(grid, getenv("AE_DF_GRID") ? (unsigned)atoi(getenv("AE_DF_GRID")) : 128u);
+        // ... so the grid grows with the batch: ~1000 samples per lane, at least 128 workgroups
+        const unsigned want = (unsigned)std::max<uint64_t>(128, S / (1024ull * bs));
+        grid = std::min<unsigned>(grid, getenv("AE_DF_GRID") ? (unsigned)atoi(getenv("AE_DF_GRID")) : want);
         CeDev dev = o->dev;
         const uint32_t* pn = o->plan_nodes.p;
         const float* pw = o->plan_w.p;

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--asked-dim", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-svd", action="store_true")
+    ap.add_argument("--no-exact-mode", action="store_true")
     ap.add_argument("--lattice-graph", action="store_true",
                     help="scale runs (C3 / C4 shapes): ring-lattice kNN graph with gamma-distributed distances instead of an exact kNN of synthetic points (an 11 M-point exact kNN is out of reach of brute force)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path with world size 1 (validation)")
@@ -230,6 +231,25 @@ def main():
         elapsed = float(tt.item())
     ce_after = eo.ce_compute_threaded()
 
+    # secondary figure: the exact mode (AE_CE_SEQUENTIAL, bit-exact against the oracle's sequential loop -- tests),
+    # same graph, same batch size
+    exact_mode = None
+    if world == 1 and not args.no_exact_mode:
+        pe = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0,
+                              ce_mode=A.AE_CE_SEQUENTIAL)
+        ex = A.EntropyOptim(kg, node_params, pe, y0)
+        ex.gradient_iteration_threaded(nb_sample, 0.9, 1)  # warm (allocations)
+        L.check(L.load().ae_synchronize())
+        t0 = time.perf_counter()
+        reps = 3
+        for r in range(reps):
+            ex.gradient_iteration_threaded(nb_sample, 0.9, 2 + r)
+        L.check(L.load().ae_synchronize())
+        dt = (time.perf_counter() - t0) / reps
+        exact_mode = {"ce_mode": "sequential (device-scheduled dataflow, bit-exact vs the oracle)", "ms_per_step": dt * 1e3,
+                      "points_per_s": n / dt, "samples_per_s": nb_sample / dt}
+        del ex
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         points_per_s = n * args.steps / elapsed
@@ -273,6 +293,7 @@ def main():
                 "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
             },
             "svd_dense": svd_dense,
+            "exact_mode": exact_mode,
             "samples_per_s": nb_sample * world * args.steps / elapsed,
             "ce_before": ce_before, "ce_after": ce_after,
         }
