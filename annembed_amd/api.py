@@ -393,7 +393,7 @@ class RangePrecision:
 def adaptative_range_finder_matrep(mat, epsil, r, max_rank):
     """adaptative_range_finder_matrep, src/tools/svdapprox.rs:444-597 -> Q (m, l), l <= max_rank"""
     m, n = mat.shape
-    cap = min(int(max_rank), 64)
+    cap = min(int(max_rank), 4096)
     q = np.zeros((m, cap), np.float32)
     lo = C.c_uint64()
     check(L.load().ae_adaptative_range_finder(mat.handle, float(epsil), int(r), int(max_rank), ptr(q), C.byref(lo)))

@@ -1160,10 +1160,11 @@ uint32_t adaptive_range_finder_device(ae_matrepr& a, double epsil, uint64_t r_ar
     const uint32_t r = (uint32_t)r_arg;
     if (r < 1 || r > (uint32_t)kMaxL) fail(AE_ERR_INVALID_ARG, "range finder: step must be in 1..%d", kMaxL);
     if (max_rank_arg == 0) fail(AE_ERR_INVALID_ARG, "range finder: max_rank must be positive");
-    const uint32_t max_rank = (uint32_t)std::min<uint64_t>(max_rank_arg, std::min<uint64_t>((uint64_t)kMaxL, std::min(m, n) + 1));
+    // the basis may be wider than a panel (kMaxL bounds the QR / SVD panels, not this vector-at-a-time finder)
+    const uint32_t max_rank = (uint32_t)std::min<uint64_t>(max_rank_arg, std::min<uint64_t>(4096ull, std::min(m, n) + 1));
     const unsigned rg = std::min<unsigned>(blocks_for(m, 256), 512);
     DevBuf<float> omega(n * r), yp(m * r), qp(m * (uint64_t)max_rank), wv(n), yv(m);
-    DevBuf<double> coef(kMaxL), norms(kMaxL);
+    DevBuf<double> coef(std::max<uint32_t>(max_rank, kMaxL)), norms(kMaxL);
     std::vector<double> hn(r);
     auto col_norms = [&]() {  // squared norms of the r probes
         norms.zero();
@@ -1325,7 +1326,7 @@ int32_t ae_svd_approx_epsil(const ae_matrepr* m, double epsil, uint64_t step, ui
         if (step <= 1) step = 2;  // RangePrecision::new, svdapprox.rs:167-179
         DevBuf<float> dq;
         ae_matrepr& a = *const_cast<ae_matrepr*>(m);
-        const uint32_t l = adaptive_range_finder_device(a, epsil, step, max_rank, dq);
+        const uint32_t l = adaptive_range_finder_device(a, epsil, step, std::min<uint64_t>(max_rank, (uint64_t)kMaxL), dq);
         if (l == 0) fail(AE_ERR_SVD, "adaptative range finder returned an empty basis");
         SvdOut o;
         direct_svd_from_q(a, dq, l, vt != nullptr, o);

@@ -262,7 +262,7 @@ int32_t ae_svd_approx_rank(const ae_matrepr *m, uint64_t rank, uint64_t nbiter, 
 
 /* adaptative_range_finder_matrep (svdapprox.rs:444-597, Halko-Martinsson-Tropp algorithm 4.2;
    RangeApproxMode::EPSIL of RangeApprox::get_approximator :240-247): orthonormal q[nrows x l]
-   row-major, l <= max_rank (<= 64) written to *l_out; q must hold nrows * min(max_rank, 64) floats.
+   row-major, l <= min(max_rank, 4096) written to *l_out; q must hold nrows * min(max_rank, 4096) floats.
    r probe vectors; stops when the largest probe norm falls below epsil / (10 sqrt(2 pi)) times its
    initial value (:465, :515), at max_rank, or on a vanishing vector (:524-532). */
 int32_t ae_adaptative_range_finder(const ae_matrepr *m, double epsil, uint64_t r, uint64_t max_rank,
@@ -270,7 +270,8 @@ int32_t ae_adaptative_range_finder(const ae_matrepr *m, double epsil, uint64_t r
 
 /* SvdApprox::direct_svd(EPSIL(RangePrecision{epsil, step, max_rank})) (svdapprox.rs:721-799 with the
    range finder above; step <= 1 is reset to 2 as RangePrecision::new :167-179): s[l], u[nrows*l],
-   vt[l*ncols] row-major (u / vt may be NULL, sized for l = min(max_rank, 64)). */
+   vt[l*ncols] row-major (u / vt may be NULL, sized for l = min(max_rank, 64): the SVD panels are at
+   most 64 wide, a larger max_rank is clamped). */
 int32_t ae_svd_approx_epsil(const ae_matrepr *m, double epsil, uint64_t step, uint64_t max_rank,
                             float *s, float *u, float *vt, uint64_t *l_out);
 

@@ -454,6 +454,26 @@ def estimate_first_singular_value(mat):
     return np.sqrt(lam)
 
 
+def estimate_first_singular_value_csmat(mat):
+    """estimate_first_singular_value_csmat, svdapprox.rs:844-887: densify, power iteration on A A^T (or A^T A), stop at
+    |v1 - v2| < 1e-10 or 1000 iterations"""
+    dense = np.zeros(mat.shape, np.float64)
+    rows = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr.astype(np.int64)))
+    dense[rows, mat.indices.astype(np.int64)] = mat.values
+    a2 = dense @ dense.T if dense.shape[0] <= dense.shape[1] else dense.T @ dense
+    v1 = np.full(a2.shape[0], 1.0 / np.sqrt(a2.shape[0]))
+    lam = 0.0
+    for _ in range(1000):
+        v2 = a2 @ v1
+        lam = np.sqrt(v2 @ v2)
+        v2 = v2 * 1.0 / lam
+        w = v1 - v2
+        if np.sqrt(w @ w) < 1e-10:
+            break
+        v1 = v2
+    return np.sqrt(lam)
+
+
 # ------------------------------------------------------------------------------------------------
 # diffusion-map drivers
 # ------------------------------------------------------------------------------------------------

@@ -724,3 +724,21 @@ def test_adaptative_range_finder_vs_oracle(A, oracle):
     sm = sp.random(2000, 1500, density=0.01, random_state=3, dtype=np.float32, format="csr")
     qs = A.adaptative_range_finder_matrep(A.MatRepr.from_csrmat(sm.indptr, sm.indices, sm.data, sm.shape), 0.1, 5, 30)
     assert qs.shape == (2000, 30) and np.allclose(qs.T @ qs, np.eye(30), atol=2e-5)  # full-rank input: stops at max_rank
+
+
+def test_range_approx_epsil_stops_at_the_rank(A, oracle):
+    """svdapprox.rs:1191 test_range_approx_epsil (there 3003 x 3003 of rank 200, asked 500, f64, residual < 1e-5): the
+    finder must stop at the rank of the matrix.  f32 here: 1200 x 1200 of rank 100, asked 300, relative residual 1e-4."""
+    rng = np.random.default_rng(5)
+    m = n = 1200
+    rank, asked = 100, 300
+    u, v = rng.standard_normal((m, m)), rng.standard_normal((n, n))
+    p = np.zeros((m, n))
+    p[np.arange(rank), np.arange(rank)] = 1.0
+    a = (u @ (p @ v)).astype(np.float32)
+    q = A.RangeApprox(A.MatRepr.from_array2(a), A.RangePrecision(0.05, 8, asked)).get_approximator()
+    assert rank <= q.shape[1] < rank + 2 * 8, q.shape
+    assert np.allclose(q.T @ q, np.eye(q.shape[1]), atol=5e-5)
+    a64 = a.astype(np.float64)
+    q64 = q.astype(np.float64)
+    assert np.linalg.norm(a64 - q64 @ (q64.T @ a64)) < 1e-4 * np.linalg.norm(a64)

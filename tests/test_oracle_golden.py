@@ -38,6 +38,14 @@ def test_singular_value_full(oracle):  # :1034 test_singular_value_full
     assert abs(oracle.estimate_first_singular_value(GOLD["spectral_mat"]) - 10.6811457) < 1e-4
 
 
+def test_singular_value_csmat(oracle):  # :1046 test_singular_value_csmat: CSR and dense estimates agree to 1e-4 relative
+    import scipy.sparse as sp
+    m = sp.csr_matrix(GOLD["spectral_mat"].astype(np.float64))
+    full = oracle.estimate_first_singular_value(GOLD["spectral_mat"])
+    csr = oracle.estimate_first_singular_value_csmat(oracle.CsrMat(m.indptr, m.indices, m.data, m.shape))
+    assert abs(full - csr) < 1e-4 * full
+
+
 def test_svd_wiki_rank_full(oracle):  # :1310 test_svd_wiki_rank_full
     s, u, vt = oracle.direct_svd(GOLD["wiki"], 3, 8)
     assert 3 <= len(s) <= 4
@@ -68,12 +76,21 @@ def test_svd_wiki_full_epsil(oracle):  # :1530 test_svd_wiki_full_epsil (f64 den
     _check_sigma(s, GOLD["wiki_sigma"], float(np.finfo(np.float32).eps))
 
 
-def test_range_approx_epsil(oracle):  # :1200 test_range_approx_epsil shape (50 x 500, rank-limited): residual small
+def test_range_approx_epsil(oracle):
+    """:1191 test_range_approx_epsil: a rank-deficient u p v (the reference: 3003 x 3003 of rank 200, asked 500, epsil
+    0.05, step 8, f64, residual < 1e-5; here 900 x 900 of rank 60, asked 150 -- same construction, same assertion, sized
+    for the CPU suite).  The finder must stop at the rank of the matrix, not at the asked rank."""
     rng = np.random.default_rng(5)
-    a = (rng.standard_normal((50, 12)) @ rng.standard_normal((12, 500))).astype(np.float64)
-    q = oracle.adaptative_range_finder(a, 0.05, 5, 40)
-    assert 12 <= q.shape[1] <= 40 and np.allclose(q.T @ q, np.eye(q.shape[1]), atol=1e-10)
-    assert np.linalg.norm(a - q @ (q.T @ a)) < 1e-8 * np.linalg.norm(a)
+    m = n = 900
+    rank, asked = 60, 150
+    u, v = rng.standard_normal((m, m)), rng.standard_normal((n, n))
+    p = np.zeros((m, n))
+    p[np.arange(rank), np.arange(rank)] = 1.0
+    a = u @ (p @ v)
+    q = oracle.adaptative_range_finder(a, 0.05, 8, asked)
+    assert rank <= q.shape[1] < rank + 2 * 8 and np.allclose(q.T @ q, np.eye(q.shape[1]), atol=1e-10)
+    residue = np.linalg.norm(a - q @ (q.T @ a))  # check_range_approx, :600-611: Frobenius norm of the residual
+    assert residue < 1e-5
 
 
 def test_svd_f32_wiki(oracle):  # src/graphlaplace.rs:362 test_svd_wiki_rank_svd_f32
