@@ -24,9 +24,9 @@ namespace ae {
 template <int DIM>
 struct NodeKernelCfg {
     static constexpr int S = DIM <= 2 ? 4 : (DIM <= 4 ? 2 : 1);  // samples whose rows are gathered together
-    static constexpr int NQ = 4;                                  // in-edge records per lane and pass of stage C
+    static constexpr int NQ = DIM <= 4 ? 8 : 4;                   // in-edge records per lane and pass of stage C
     static constexpr int CH = 64 * NQ;
-    static constexpr int EC = DIM <= 4 ? 512 : (DIM <= 8 ? 256 : 128);  // pushes parked in LDS per window
+    static constexpr int EC = DIM <= 4 ? 1024 : (DIM <= 8 ? 256 : 128);  // pushes parked in LDS per window
 };
 
 // N independent Poisson inversions advanced together, branch-free (same operations, same order per variate as
