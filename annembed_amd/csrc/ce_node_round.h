@@ -226,7 +226,6 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             for (uint32_t attempt = 0; attempt < 16u; attempt++) {  // embedder.rs:1241-1253; one pass unless a draw is rejected
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    const uint32_t j = idx[s][0];
 #pragma unroll
                     for (int g = 1; g <= 5; g++) {
                         const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
@@ -238,8 +237,8 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
                         } else {
                             cand = __umulhi(w0, (uint32_t)c.n);  // :1121
                         }
-                        // reject k in {i, j} or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85): min over xors is 0
-                        uint32_t acc = (cand ^ v) < (cand ^ j) ? (cand ^ v) : (cand ^ j);
+                        // reject k = i or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85; the sampled j is in N(i)): min over xors is 0
+                        uint32_t acc = cand ^ v;
 #pragma unroll
                         for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
                         const uint32_t bit = 1u << (8 * s + g);
@@ -301,7 +300,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
                 // optional write-through after every chunk (AE_CE_STORE=0, see ce_node.hip)
                 if (a.store_mode == 0 && valid && cA.act) st(v, yv);
             }
-            cA = cB;
+            cA = cB;  // (alternating the roles of the two chunks instead of copying was measured: no gain, larger code)
             AE_TICK(2)
         }
     } else {  // 32 padded columns: one chunk in registers at a time
