@@ -198,12 +198,16 @@ def main():
         sp = ctypes.c_void_p()
         L.check(L.load().ae_get_stream(ctypes.byref(sp)))
         lib_stream = torch.cuda.ExternalStream(sp.value)
+        y_gather = torch.empty((nn, dd), dtype=torch.float32, device="cuda")
 
     def one_step(it):
         eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / nb_batch), it)
         if use_dist:
             with torch.cuda.stream(lib_stream):
-                dist.all_gather_into_tensor(y_all, y_all[lo:hi].clone())
+                # the collective works on torch-owned buffers (no assumption about RCCL and memory it did not see
+                # allocated); the gathered replica is copied into the library's coordinate array on the same stream
+                dist.all_gather_into_tensor(y_gather, y_all[lo:hi].clone())
+                y_all.copy_(y_gather)
 
     def fence():
         L.check(L.load().ae_synchronize())
