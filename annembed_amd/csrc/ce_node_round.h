@@ -200,10 +200,44 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
         float ws[S];
         uint32_t act;
     };
-    auto prepare = [&](uint32_t t0, Chunk& ck) {
+    struct ChunkPlan {  // node sets of S samples: idx[s][0] = sampled neighbour j, idx[s][1..5] = negatives
         uint32_t idx[S][6];
-        uint32_t need = 0;  // bit s * 8 + g: draw (s, g) still has to be (re)drawn
-        ck.act = 0;
+        float ws[S];
+        uint32_t act;
+    };
+    // one attempt of all 5 S draws (embedder.rs:1241-1253), branch-free: `need` has bit 8 s + g set while draw (s, g) is
+    // still wanted; reject k = i or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85; the sampled j is in N(i)):
+    // min over xors is 0
+    auto draw_pass = [&](auto hub_tag, uint32_t t0, uint32_t attempt, ChunkPlan& pl, uint32_t& need) {
+        constexpr bool HUB = decltype(hub_tag)::value;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+#pragma unroll
+            for (int g = 1; g <= 5; g++) {
+                const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
+                uint32_t cand;
+                if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
+                    const uint32_t x = __umulhi(w0, (uint32_t)c.n);
+                    const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                    cand = (uu < c.hub_odds[x]) ? x : c.hub_alias[x];
+                } else {
+                    cand = __umulhi(w0, (uint32_t)c.n);  // :1121
+                }
+                uint32_t acc = cand ^ v;
+#pragma unroll
+                for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
+                const uint32_t bit = 1u << (8 * s + g);
+                const bool mine = (need & bit) != 0u;
+                pl.idx[s][g] = (mine || attempt == 0u) ? cand : pl.idx[s][g];
+                need = (mine && acc != 0u) ? (need & ~bit) : need;
+            }
+        }
+    };
+    // plan of chunk t0; `overlap` (the replay of an earlier chunk) sits in the same basic block as the first attempt so
+    // that the scheduler can fill the stalls of its dependent chain with the independent hash / compare streams
+    auto plan_chunk = [&](auto hub_tag, uint32_t t0, ChunkPlan& pl, auto&& overlap) {
+        uint32_t need = 0;
+        pl.act = 0;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const uint32_t t = t0 + (uint32_t)s;  // wave-uniform
@@ -216,47 +250,24 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             for (int q = 0; q < KP; q++) above += (uint32_t)__builtin_popcount((cumP[q] + bias) & 0x80808080u);
             uint32_t m_s = (uint32_t)KMAX - above;
             m_s = m_s < (uint32_t)KMAX ? m_s : (uint32_t)KMAX - 1u;
-            idx[s][0] = s_nbr[m_s * LS + lane];
-            ck.ws[s] = s_w[m_s * LS + lane];
-            if (act) { ck.act |= 1u << s; need |= 0x3Eu << (8 * s); }
+            pl.idx[s][0] = s_nbr[m_s * LS + lane];
+            pl.ws[s] = s_w[m_s * LS + lane];
+            pl.act |= act ? 1u << s : 0u;
+            need |= act ? 0x3Eu << (8 * s) : 0u;
         }
-        auto draw = [&](auto hub_tag) {
-            constexpr bool HUB = decltype(hub_tag)::value;
+        draw_pass(hub_tag, t0, 0u, pl, need);
+        overlap();
 #pragma nounroll
-            for (uint32_t attempt = 0; attempt < 16u; attempt++) {  // embedder.rs:1241-1253; one pass unless a draw is rejected
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-#pragma unroll
-                    for (int g = 1; g <= 5; g++) {
-                        const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
-                        uint32_t cand;
-                        if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
-                            const uint32_t x = __umulhi(w0, (uint32_t)c.n);
-                            const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                            cand = (uu < c.hub_odds[x]) ? x : c.hub_alias[x];
-                        } else {
-                            cand = __umulhi(w0, (uint32_t)c.n);  // :1121
-                        }
-                        // reject k = i or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85; the sampled j is in N(i)): min over xors is 0
-                        uint32_t acc = cand ^ v;
-#pragma unroll
-                        for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
-                        const uint32_t bit = 1u << (8 * s + g);
-                        const bool mine = (need & bit) != 0u;
-                        idx[s][g] = (mine || attempt == 0u) ? cand : idx[s][g];
-                        need = (mine && acc != 0u) ? (need & ~bit) : need;
-                    }
-                }
-                if (!__any(need != 0u)) break;
-            }
-        };
-        if (hub) draw(std::true_type{});
-        else draw(std::false_type{});
+        for (uint32_t attempt = 1; attempt < 16u && __any(need != 0u); attempt++) draw_pass(hub_tag, t0, attempt, pl, need);  // rare
+    };
+    auto issue = [&](const ChunkPlan& pl, Chunk& ck) {  // the 6 S gathers of a planned chunk
+        ck.act = pl.act;
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const bool act = (ck.act >> s) & 1u;
+            const bool act = (pl.act >> s) & 1u;
+            ck.ws[s] = pl.ws[s];
 #pragma unroll
-            for (int g = 0; g < 6; g++) ld(act ? idx[s][g] : v, ck.rows[s][g]);
+            for (int g = 0; g < 6; g++) ld(act ? pl.idx[s][g] : v, ck.rows[s][g]);
         }
     };
     auto replay = [&](const Chunk& ck) {
@@ -289,29 +300,40 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
         }
     };
-    if constexpr (DIM <= 16) {
-        Chunk cA, cB;
-#pragma nounroll
-        for (uint32_t t0 = 0; t0 < nmax + S; t0 += S) {  // iteration i prepares chunk i and replays chunk i - 1
-            if (t0 < nmax) prepare(t0, cB);
+    // Software pipeline over chunks: the rows of chunk i + 1 are gathered while chunk i + 2 is planned and chunk i replayed.
+    auto stage_b = [&](auto hub_tag) {
+        ChunkPlan pl;
+        if constexpr (DIM <= 16) {
+            Chunk cA, cB;
+            if (nmax) {
+                plan_chunk(hub_tag, 0u, pl, [] {});
+                issue(pl, cA);
+                if ((uint32_t)S < nmax) plan_chunk(hub_tag, (uint32_t)S, pl, [] {});
+            }
             AE_TICK(1)
-            if (t0 > 0) {
+#pragma nounroll
+            for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
+                const bool has1 = t0 + S < nmax, has2 = t0 + 2 * S < nmax;
+                if (has1) issue(pl, cB);
+                if (has2) plan_chunk(hub_tag, t0 + 2 * S, pl, [&] { replay(cA); });
+                else replay(cA);
+                if (a.store_mode == 0 && valid && cA.act) st(v, yv);  // optional write-through after every chunk (AE_CE_STORE=0)
+                if (has1) cA = cB;
+                AE_TICK(2)
+            }
+        } else {  // 32 padded columns: one chunk in registers at a time
+            Chunk cA;
+#pragma nounroll
+            for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
+                plan_chunk(hub_tag, t0, pl, [] {});
+                issue(pl, cA);
                 replay(cA);
-                // optional write-through after every chunk (AE_CE_STORE=0, see ce_node.hip)
                 if (a.store_mode == 0 && valid && cA.act) st(v, yv);
             }
-            cA = cB;  // (alternating the roles of the two chunks instead of copying was measured: no gain, larger code)
-            AE_TICK(2)
         }
-    } else {  // 32 padded columns: one chunk in registers at a time
-        Chunk cA;
-#pragma nounroll
-        for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
-            prepare(t0, cA);
-            replay(cA);
-            if (a.store_mode == 0 && valid && cA.act) st(v, yv);
-        }
-    }
+    };
+    if (hub) stage_b(std::true_type{});
+    else stage_b(std::false_type{});
     if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
     // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,
     // gathers of the sources' rows, an exclusive scan of the counts = position of every push in the list of
