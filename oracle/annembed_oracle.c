@@ -9,8 +9,8 @@
  * PARITY PINNING (see DESIGN.md "Oracle"):
  *   - pinned by the reference's own known-answer tests: the randomized-SVD path (done in
  *     oracle/oracle.py with LAPACK gesdd/geqrf/orgqr through scipy -- the very routines the
- *     reference calls through `lax`), src/tools/svdapprox.rs tests :1034,:1160,:1231,:1270,:1310,
- *     :1497,:1575 and src/graphlaplace.rs:362.
+ *     reference calls through `lax`), src/tools/svdapprox.rs tests :1034,:1046,:1160,:1191,:1231,:1270,
+ *     :1310,:1459,:1497,:1530,:1575 and src/graphlaplace.rs:362 (tests/test_oracle_golden.py).
  *   - PARITY UNPINNED (the reference holds no numeric test, cannot be built here -- no cargo/rustc --
  *     and is not reproducible run to run): to_proba_edges, the dmap kernel/density/laplacian, the CE
  *     SGD sample and the CE value.  For these the check is two independent restatements of the same
@@ -21,6 +21,9 @@
  *     are not under /root/reference (rand 0.9, rand_distr 0.5, rand_xoshiro 0.7; no Cargo.lock):
  *     PARITY UNPINNED.  The build defines its own counter-based stream (Philox4x32-10, below) and the
  *     device code reproduces exactly that.
+ *   - the summation order of ndarray's Array1::sum() (q.sum(), src/diffmaps.rs:469,:546,:889,:932) lives in the
+ *     ndarray crate (0.15 / 0.16, not vendored): restated from its published numeric_util::unrolled_fold --
+ *     PARITY UNPINNED (ndarray_sum_f32 below); it moves q_mean by ~1 ulp.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared).
  */
