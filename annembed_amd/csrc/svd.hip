@@ -152,21 +152,23 @@ __global__ void __launch_bounds__(256) dense_mul_panel_mfma_kernel(const float* 
     float ra[NQ][4], rx[NX];
     auto gload = [&](uint64_t k0) {  // tile k0 into registers: 16 consecutive threads read 256 contiguous bytes of a row
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
+        for (int q = 0; q < NQ; q++) {  // unconditional loads from clamped addresses (all in flight together), then masked
             const int idx = tid + q * 256;
             const int r = idx / (KT / 4), kc = (idx % (KT / 4)) * 4;
             const uint64_t row = row_base + r, kk = k0 + kc;
-            ra[q][0] = ra[q][1] = ra[q][2] = ra[q][3] = 0.f;
-            if (row < m) {
-                if (VEC4 && kk + 3 < n) {
-                    const float4 t = *reinterpret_cast<const float4*>(a + row * n + kk);
-                    ra[q][0] = t.x; ra[q][1] = t.y; ra[q][2] = t.z; ra[q][3] = t.w;
-                } else {
-                    const float* p = a + row * n;
-                    if (kk < n) ra[q][0] = p[kk];
-                    if (kk + 1 < n) ra[q][1] = p[kk + 1];
-                    if (kk + 2 < n) ra[q][2] = p[kk + 2];
-                    if (kk + 3 < n) ra[q][3] = p[kk + 3];
+            const bool rin = row < m;
+            const float* p = a + (rin ? row : 0) * n;
+            if (VEC4) {  // n % 4 == 0: a float4 is entirely inside or outside the row
+                const bool kin = kk < n;
+                const float4 t = *reinterpret_cast<const float4*>(p + (kin ? kk : 0));
+                const bool use = rin && kin;
+                ra[q][0] = use ? t.x : 0.f; ra[q][1] = use ? t.y : 0.f; ra[q][2] = use ? t.z : 0.f; ra[q][3] = use ? t.w : 0.f;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool kin = kk + t < n;
+                    const float vv = p[kin ? kk + t : 0];
+                    ra[q][t] = (rin && kin) ? vv : 0.f;
                 }
             }
         }
@@ -174,7 +176,9 @@ __global__ void __launch_bounds__(256) dense_mul_panel_mfma_kernel(const float* 
         for (int q = 0; q < NX; q++) {  // X slab: KT k x 32 j (zero padded beyond l)
             const int idx = tid + q * 256;
             const int kk = idx >> 5, j = idx & 31;
-            rx[q] = (k0 + kk < n && (uint32_t)j < l) ? x[(k0 + kk) * l + j] : 0.f;
+            const bool in = k0 + kk < n && (uint32_t)j < l;
+            const float vv = x[in ? (k0 + kk) * l + j : 0];
+            rx[q] = in ? vv : 0.f;
         }
     };
     gload(0);
@@ -205,41 +209,73 @@ __global__ void __launch_bounds__(256) dense_mul_panel_mfma_kernel(const float* 
     }
 }
 
-// partial[chunk][n x l] = A[rows of chunk]^T * X[rows of chunk]: for a fixed row of A the 32 columns of the tile are
-// contiguous, so both operands are read straight from global memory in fragment order (no LDS).
+// partial[chunk][n x l] = A[rows of chunk]^T * X[rows of chunk].  A workgroup owns a strip of 128 columns of A and a
+// chunk of rows.  Lane (h = lane / 32, i = lane % 32) loads the float4 A[row + h][c0 + 4 i .. 4 i + 3] -- 512 contiguous
+// bytes per row, one 1 KB load instruction per 2 rows -- and feeds FOUR MFMAs: MFMA q multiplies the strided column set
+// {c0 + 4 i + q} (its 32 "rows" of the A^T operand) with the X rows, so no cross-lane movement is needed; only the
+// output rows are strided.  The X operand (2 rows x 32 padded columns) comes straight from L2.
+template <bool VEC4>
 __global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
                                                                      const float* __restrict__ x, float* __restrict__ partial,
                                                                      uint32_t l, uint64_t rows_per_chunk) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t c0 = blockIdx.x * 32ull;
+    const uint64_t c0 = blockIdx.x * 128ull;
     const uint64_t chunk = blockIdx.y;
     const uint64_t i0 = chunk * rows_per_chunk;
     const uint64_t i1 = i0 + rows_per_chunk < m ? i0 + rows_per_chunk : m;
-    const uint64_t col = c0 + (lane & 31);
+    const uint64_t col = c0 + 4ull * (lane & 31);
     const int kh = lane >> 5;
-    const bool cok = col < n, jok = (uint32_t)(lane & 31) < l;
-    f32x16 acc;
+    const bool jok = (uint32_t)(lane & 31) < l;
+    f32x16 acc[4];
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
     // the 4 waves of the workgroup interleave the rows of the chunk; their accumulators are summed through LDS
-#pragma unroll 8
-    for (uint64_t r = i0 + 2 * w; r < i1; r += 8) {  // unrolled: the loads of several steps are in flight together
+    // U steps per trip, straight-line (loads clamped and masked instead of branched): 2 U row pairs in flight per wave
+    constexpr int U = 8;
+    const uint64_t rbeg = i0 + 2 * (uint64_t)__builtin_amdgcn_readfirstlane(w);
+    for (uint64_t r0 = rbeg; r0 < i1; r0 += 8 * U)
+#pragma unroll
+    for (int uu = 0; uu < U; uu++) {
+        const uint64_t r = r0 + 8 * (uint64_t)uu;
         const uint64_t rr = r + kh;
         const bool ok = rr < i1;
-        const float av = (ok && cok) ? a[rr * n + col] : 0.f;
-        const float bv = (ok && jok) ? x[rr * l + (lane & 31)] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        const uint64_t rc = ok ? rr : i0;  // clamped: the loads below are unconditional, so the unrolled steps keep them all in flight
+        float av[4];
+        if constexpr (VEC4) {  // n % 4 == 0: a float4 is entirely inside or entirely outside the row
+            const bool cin = col < n;
+            const float4 t4 = *reinterpret_cast<const float4*>(a + rc * n + (cin ? col : 0));
+            const bool use = ok && cin;
+            av[0] = use ? t4.x : 0.f; av[1] = use ? t4.y : 0.f; av[2] = use ? t4.z : 0.f; av[3] = use ? t4.w : 0.f;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const bool cin = col + t < n;
+                const float vv = a[rc * n + (cin ? col + t : 0)];
+                av[t] = (ok && cin) ? vv : 0.f;
+            }
+        }
+        const float bx = x[rc * l + (jok ? (lane & 31) : 0)];
+        const float bv = (ok && jok) ? bx : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
     }
     __shared__ float red[4 * 64 * 16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) red[(w * 16 + q) * 64 + lane] = acc[q];
-    __syncthreads();
-    if (w == 0 && jok) {
+    for (int t = 0; t < 4; t++) {  // one strided column set at a time through the reduction buffer
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const float v = (red[q * 64 + lane] + red[(16 + q) * 64 + lane]) + (red[(32 + q) * 64 + lane] + red[(48 + q) * 64 + lane]);
-            const uint64_t crow = c0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);  // row of the output = column of A
-            if (crow < n) partial[(chunk * n + crow) * l + (lane & 31)] = v;
+        for (int q = 0; q < 16; q++) red[(w * 16 + q) * 64 + lane] = acc[t][q];
+        __syncthreads();
+        if (w == 0 && jok) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float v = (red[q * 64 + lane] + red[(16 + q) * 64 + lane]) + (red[(32 + q) * 64 + lane] + red[(48 + q) * 64 + lane]);
+                const uint64_t irow = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);  // row of the MFMA output tile
+                const uint64_t crow = c0 + 4 * irow + t;                          // = column of A (strided set t)
+                if (crow < n) partial[(chunk * n + crow) * l + (lane & 31)] = v;
+            }
         }
     }
 }
@@ -656,14 +692,18 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     }
     const uint64_t m = a.nrows, n = a.ncols;
     if (l <= 32 && !getenv("AE_NO_MFMA")) {  // matrix-core path: 32-column tiles x row chunks, then a deterministic reduce
-        const uint64_t ctiles = (n + 31) / 32;
+        const uint64_t ctiles = (n + 127) / 128;  // strips of 128 columns
         uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, std::max<uint64_t>(1, 2048 / ctiles)));
         const uint64_t rpc = ((m + chunks - 1) / chunks + 7) & ~7ull;
         chunks = (m + rpc - 1) / rpc;
         static DevBuf<float> part;
         if (part.n < chunks * n * l) { sync(); part.alloc(chunks * n * l); }
-        hipLaunchKernelGGL(dense_t_mul_panel_mfma_kernel, dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m, n, d_x,
-                           part.p, l, rpc);
+        if (n % 4 == 0)
+            hipLaunchKernelGGL((dense_t_mul_panel_mfma_kernel<true>), dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m,
+                               n, d_x, part.p, l, rpc);
+        else
+            hipLaunchKernelGGL((dense_t_mul_panel_mfma_kernel<false>), dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m,
+                               n, d_x, part.p, l, rpc);
         check_launch("dense_t_mul_panel_mfma");
         hipLaunchKernelGGL(reduce_chunks_kernel, dim3(blocks_for(n * l, 256)), dim3(256), 0, stream(), part.p, chunks, n * l, d_y);
         check_launch("reduce_chunks");
