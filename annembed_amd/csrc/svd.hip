@@ -232,34 +232,41 @@ __global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
     // the 4 waves of the workgroup interleave the rows of the chunk; their accumulators are summed through LDS
-    // U steps per trip, straight-line (loads clamped and masked instead of branched): 2 U row pairs in flight per wave
+    // U steps per trip: first ALL the loads of the trip (clamped addresses, no branches), then the masking and the
+    // MFMAs -- 2 U row pairs (U KB of A) in flight per wave; the scheduling barrier keeps the compiler from pairing each
+    // load with its use again (double-buffering the trips on top of this was measured slower)
     constexpr int U = 8;
     const uint64_t rbeg = i0 + 2 * (uint64_t)__builtin_amdgcn_readfirstlane(w);
-    for (uint64_t r0 = rbeg; r0 < i1; r0 += 8 * U)
+    const bool cin = col < n;           // VEC4: n % 4 == 0, a float4 is entirely inside or outside the row
+    const uint64_t colc = cin ? col : 0;
+    const uint32_t jc = jok ? (uint32_t)(lane & 31) : 0u;
+    for (uint64_t r0 = rbeg; r0 < i1; r0 += 8 * U) {
+        float av[U][4], bx[U];
+        bool ok[U];
 #pragma unroll
-    for (int uu = 0; uu < U; uu++) {
-        const uint64_t r = r0 + 8 * (uint64_t)uu;
-        const uint64_t rr = r + kh;
-        const bool ok = rr < i1;
-        const uint64_t rc = ok ? rr : i0;  // clamped: the loads below are unconditional, so the unrolled steps keep them all in flight
-        float av[4];
-        if constexpr (VEC4) {  // n % 4 == 0: a float4 is entirely inside or entirely outside the row
-            const bool cin = col < n;
-            const float4 t4 = *reinterpret_cast<const float4*>(a + rc * n + (cin ? col : 0));
-            const bool use = ok && cin;
-            av[0] = use ? t4.x : 0.f; av[1] = use ? t4.y : 0.f; av[2] = use ? t4.z : 0.f; av[3] = use ? t4.w : 0.f;
-        } else {
+        for (int uu = 0; uu < U; uu++) {
+            const uint64_t rr = r0 + 8 * (uint64_t)uu + kh;
+            ok[uu] = rr < i1;
+            const uint64_t rc = ok[uu] ? rr : i0;
+            if constexpr (VEC4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(a + rc * n + colc);
+                av[uu][0] = t4.x; av[uu][1] = t4.y; av[uu][2] = t4.z; av[uu][3] = t4.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) av[uu][t] = a[rc * n + (col + t < n ? col + t : 0)];
+            }
+            bx[uu] = x[rc * l + jc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int uu = 0; uu < U; uu++) {
+            const float bv = (ok[uu] && jok) ? bx[uu] : 0.f;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const bool cin = col + t < n;
-                const float vv = a[rc * n + (cin ? col + t : 0)];
-                av[t] = (ok && cin) ? vv : 0.f;
+                const bool use = ok[uu] && (VEC4 ? cin : col + t < n);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? av[uu][t] : 0.f, bv, acc[t], 0, 0, 0);
             }
         }
-        const float bx = x[rc * l + (jok ? (lane & 31) : 0)];
-        const float bv = (ok && jok) ? bx : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
     }
     __shared__ float red[4 * 64 * 16];
 #pragma unroll
