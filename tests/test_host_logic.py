@@ -105,3 +105,31 @@ def test_shard_ranges():
         assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
         assert max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
     assert sample_offset(0) == 0 and sample_offset(5) == 5 << 24
+
+
+def test_committed_bench_evidence_is_well_formed():
+    """the bench lines kept under profiles/ carry every field of the bench contract (the GPU box regenerates them;
+    this only guards the schema and the arithmetic of the committed evidence)"""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_r*_v*.json")))
+    assert files, "no committed bench line"
+    with open(files[-1]) as f:
+        j = json.loads(f.read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["config"]["workload"] and j["higher_is_better"] is True and j["vs_baseline"] is None and j["scaling"] == "weak"
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # achieved = algorithmic bytes per launch / average launch duration
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"]
+    pmc = os.path.join(os.path.dirname(files[-1]), "pmc_ce_round.json")
+    with open(pmc) as f:
+        assert abs(json.load(f)["hbm_bytes_per_launch"] - r["traffic"]) < 0.05 * r["traffic"]
