@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [bench args...]   (runs on the GPU box via gpurun)
+# usage: tools/prof_bench.sh <tag> [bench args...]   (runs on the GPU box via gpurun)
 set -u
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools_svdprof.sh <tag> -- kernel trace of the SVD init (bench without CE steps)
+# usage: tools/prof_svd.sh <tag> -- kernel trace of the SVD init (bench without CE steps)
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/svdprof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/${SVDSCRIPT:-scratch_svdonly.py} > $OUT/run.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/${SVDSCRIPT:-tools/run_svd_init.py} > $OUT/run.log 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/t_kernel_stats.csv")))

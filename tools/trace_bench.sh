@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_trace.sh <tag> [bench args]  -- kernel trace + stats only
+# usage: tools/trace_bench.sh <tag> [bench args]  -- kernel trace + stats only
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
