@@ -311,7 +311,7 @@ def main():
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>/pmc_ce_round.json, written by tools_prof.sh: FETCH_SIZE and WRITE_SIZE collected in separate
+    (profiles/<round>/pmc_ce_round.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate
     passes, KiB -> bytes); None when no profile of the current kernel is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_ce_round.json")))
