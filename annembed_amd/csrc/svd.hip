@@ -798,6 +798,47 @@ static void launch_gram_mfma(const float* d_y, uint64_t rows, uint32_t l, double
 // that is not safely positive (rank-deficient / ill-conditioned panel) sets the sticky flag and leaves Y alone: the
 // caller then repeats its computation through the eigen (SVQB) route.  Workgroup 0 also clears `g_zero`, the
 // accumulator of the next Gram.
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, srclane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), srclane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Upper Cholesky G = R^T R of an l x l matrix (l <= LT <= 64) by ONE wave with the matrix in registers: lane i owns
+// column i (col[k] = R[k][i]); step j needs row j of the factor so far, i.e. lane j's registers, which the scalar
+// broadcast v_readlane supplies at a few cycles each -- ~5 us for l = 20 against ~20 us through LDS round trips.
+// Returns false when a pivot is not safely positive.
+template <int LT>
+__device__ __forceinline__ bool chol_wave_registers(const double* R_in /*LDS, l x l*/, uint32_t l, double rel_tol, int lane, double* col,
+                                                    double* rinv_out /*LDS, l*/) {
+    const uint32_t ic = (uint32_t)lane < l ? (uint32_t)lane : l - 1;
+    double dmax = 0.;
+    for (uint32_t q = 0; q < l; q++) dmax = R_in[q * l + q] > dmax ? R_in[q * l + q] : dmax;
+#pragma unroll
+    for (int k = 0; k < LT; k++) col[k] = (uint32_t)k < l ? R_in[k * l + ic] : 0.;  // column of G (lanes >= l: a copy, unused)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < LT; j++) {
+        if ((uint32_t)j < l && ok) {  // wave-uniform
+            double s0 = 0., s1 = 0.;
+#pragma unroll
+            for (int k = 0; k < j; k++) {
+                const double rkj = readlane_f64(col[k], j);
+                if (k & 1) s1 += rkj * col[k]; else s0 += rkj * col[k];
+            }
+            const double v = col[j] - (s0 + s1);
+            const double dd = readlane_f64(v, j);
+            if (!(dd > rel_tol * dmax)) ok = false;
+            else {
+                const double inv = rsqrt(dd);
+                col[j] = (lane == j) ? dd * inv : ((lane > j) ? v * inv : 0.);
+                if (lane == j) rinv_out[j] = inv;
+            }
+        }
+    }
+    return ok;
+}
+
 __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ g,
                                                          double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero, uint32_t rp) {
     extern __shared__ double smem[];         // R[l*l] | rinv[l] | tile[rp rows * (l + 1)] (f64, one row per thread, rp <= 256)
@@ -811,7 +852,17 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
         for (uint32_t idx = tid; idx < l * l; idx += 256) g_zero[idx] = 0.;
     if (tid == 0) s_bad = 0;
     __syncthreads();
-    if (tid < 64) {  // wave 0 factorises (lane i owns column i); LDS operations of one wave execute in order
+    if (tid < 64 && l <= 32) {  // wave 0 factorises in registers and writes the factor back for the row solves
+        double col[32];
+        const bool okc = chol_wave_registers<32>(R, l, rel_tol, (int)tid, col, rinv);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (!okc) { if (tid == 0) s_bad = 1; }
+        else if (tid < l) {
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                if ((uint32_t)k < l) R[k * l + tid] = col[k];
+        }
+    } else if (tid < 64) {  // wider panels: wave 0 factorises through LDS (lane i owns column i)
         const uint32_t i = tid;
         const uint32_t ic = i < l ? i : l - 1;
         double dmax = 0.;
@@ -853,10 +904,30 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
         __syncthreads();
         if (tid < nr) {
             double* x = tile + (size_t)tid * (l + 1);  // odd stride in doubles: conflict-free rows
-            for (uint32_t c = 0; c < l; c++) {
-                double acc = x[c];
-                for (uint32_t k = 0; k < c; k++) acc -= x[k] * R[k * l + c];
-                x[c] = acc * rinv[c];
+            if (l <= 32) {  // the row in registers, the factor by LDS broadcast reads (every thread reads the same R[k][c])
+                double xr[32];
+#pragma unroll
+                for (int c = 0; c < 32; c++) xr[c] = (uint32_t)c < l ? x[c] : 0.;
+#pragma unroll
+                for (int c = 0; c < 32; c++) {
+                    if ((uint32_t)c < l) {  // uniform
+                        double a0 = xr[c], a1 = 0.;
+#pragma unroll
+                        for (int k = 0; k < c; k++) {
+                            if (k & 1) a1 -= xr[k] * R[k * l + c]; else a0 -= xr[k] * R[k * l + c];
+                        }
+                        xr[c] = (a0 + a1) * rinv[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 32; c++)
+                    if ((uint32_t)c < l) x[c] = xr[c];
+            } else {
+                for (uint32_t c = 0; c < l; c++) {
+                    double acc = x[c];
+                    for (uint32_t k = 0; k < c; k++) acc -= x[k] * R[k * l + c];
+                    x[c] = acc * rinv[c];
+                }
             }
         }
         __syncthreads();
