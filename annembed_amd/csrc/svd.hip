@@ -633,8 +633,46 @@ float ndarray_sum_f32(const float* d_x, uint64_t n) {
     return h;
 }
 
+// l % 4 == 0, l <= 32: eight lanes per edge, each gathering one float4 of the X row (8 edges x 80 bytes per wave
+// instruction for l = 20 instead of 2 edges), partial rows summed across the 8 edge slots by three xor-shuffle steps.
+__global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ ind,
+                                                            const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ y,
+                                                            uint32_t l) {
+    const int lane = threadIdx.x & 63;
+    const int sl = lane >> 3, q = lane & 7;
+    const bool active = (uint32_t)(4 * q) < l;
+    const uint32_t qo = active ? 4u * (uint32_t)q : 0u;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t row = wave; row < m; row += nwaves) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const uint64_t e0 = indptr[row], e1 = indptr[row + 1];
+        for (uint64_t eb = e0; eb < e1; eb += 16) {  // two edges per lane in flight (clamped, masked: no branches)
+            const uint64_t ea = eb + sl, ec = eb + 8 + sl;
+            const bool ina = ea < e1, inc = ec < e1;
+            const float va = val[ina ? ea : e0], vc = val[inc ? ec : e0];
+            const uint64_t ca = ind[ina ? ea : e0], cc = ind[inc ? ec : e0];
+            const float4 xa = *reinterpret_cast<const float4*>(x + ca * l + qo);
+            const float4 xc = *reinterpret_cast<const float4*>(x + cc * l + qo);
+            const float wa = (ina && active) ? va : 0.f, wc = (inc && active) ? vc : 0.f;
+            a0 = fmaf(wa, xa.x, a0); a1 = fmaf(wa, xa.y, a1); a2 = fmaf(wa, xa.z, a2); a3 = fmaf(wa, xa.w, a3);
+            a0 = fmaf(wc, xc.x, a0); a1 = fmaf(wc, xc.y, a1); a2 = fmaf(wc, xc.z, a2); a3 = fmaf(wc, xc.w, a3);
+        }
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+        }
+        if (sl == 0 && active) *reinterpret_cast<float4*>(y + row * l + qo) = make_float4(a0, a1, a2, a3);
+    }
+}
+
 static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     const unsigned grid = grid_cap(a.nrows * 64, 256);
+    if (l % 4 == 0 && l <= 32 && !getenv("AE_SPMM_SCALAR")) {
+        hipLaunchKernelGGL(spmm_csr_vec4_kernel, dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
+        check_launch("spmm_csr_vec4");
+        return;
+    }
     if (l <= 16)
         hipLaunchKernelGGL((spmm_csr_kernel<16>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
     else if (l <= 32)
