@@ -787,19 +787,32 @@ __global__ void __launch_bounds__(256) gram_mfma_f64_kernel(const float* __restr
 #pragma unroll
         for (int b = 0; b < TB; b++) acc[a][b] = d4_t{0., 0., 0., 0.};
     const uint64_t nsteps = (rows + 3) / 4;
-#pragma unroll 4
-    for (uint64_t s = blockIdx.x * 4ull + wave; s < nsteps; s += gridDim.x * 4ull) {  // unrolled: several row loads in flight
-        const uint64_t row = s * 4 + kq;
-        double v[TB];
+    const uint64_t sstride = gridDim.x * 4ull;
+    constexpr int U = 4;  // steps whose loads are issued together (clamped addresses, masked values: no branches)
+    for (uint64_t s0 = blockIdx.x * 4ull + (uint64_t)__builtin_amdgcn_readfirstlane(wave); s0 < nsteps; s0 += U * sstride) {
+        float raw[U][TB];
 #pragma unroll
-        for (int a = 0; a < TB; a++) {
-            const uint32_t col = 16u * a + c;
-            v[a] = (row < rows && col < l) ? (double)y[row * l + col] : 0.;
+        for (int uu = 0; uu < U; uu++) {
+            const uint64_t row = (s0 + uu * sstride) * 4 + kq;
+            const uint64_t rc = row < rows ? row : 0;
+#pragma unroll
+            for (int a = 0; a < TB; a++) {
+                const uint32_t colx = 16u * a + c;
+                raw[uu][a] = y[rc * l + (colx < l ? colx : 0u)];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < TB; a++)
+        for (int uu = 0; uu < U; uu++) {
+            const uint64_t row = (s0 + uu * sstride) * 4 + kq;
+            double v[TB];
 #pragma unroll
-            for (int b = 0; b < TB; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[a], v[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < TB; a++) v[a] = (row < rows && 16u * a + c < l) ? (double)raw[uu][a] : 0.;
+#pragma unroll
+            for (int a = 0; a < TB; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[a], v[b], acc[a][b], 0, 0, 0);
+        }
     }
     constexpr int W = TB * 16;
     for (int idx = threadIdx.x; idx < W * W; idx += 256) sg[idx] = 0.;
