@@ -951,7 +951,23 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
         const uint64_t r0 = t * rp;
         const uint32_t nr = (uint32_t)(rows - r0 < rp ? rows - r0 : rp);
         __syncthreads();
-        for (uint32_t idx = tid; idx < nr * l; idx += 256) tile[(idx / l) * (l + 1) + idx % l] = (double)y[r0 * l + idx];  // coalesced load
+        if (l <= 32) {  // rp * l / 256 <= 32 elements per thread: all loads first (clamped), then the LDS stores
+            float tmp[32];
+            const uint32_t tot = nr * l;
+#pragma unroll
+            for (int it = 0; it < 32; it++) {
+                const uint32_t idx = tid + (uint32_t)it * 256u;
+                tmp[it] = y[r0 * l + (idx < tot ? idx : 0u)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 32; it++) {
+                const uint32_t idx = tid + (uint32_t)it * 256u;
+                if (idx < tot) tile[(idx / l) * (l + 1) + idx % l] = (double)tmp[it];
+            }
+        } else {
+            for (uint32_t idx = tid; idx < nr * l; idx += 256) tile[(idx / l) * (l + 1) + idx % l] = (double)y[r0 * l + idx];  // coalesced load
+        }
         __syncthreads();
         if (tid < nr) {
             double* x = tile + (size_t)tid * (l + 1);  // odd stride in doubles: conflict-free rows
