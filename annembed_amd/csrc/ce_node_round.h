@@ -210,19 +210,38 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     // min over xors is 0
     auto draw_pass = [&](auto hub_tag, uint32_t t0, uint32_t attempt, ChunkPlan& pl, uint32_t& need) {
         constexpr bool HUB = decltype(hub_tag)::value;
+        uint32_t cands[S][6];
+        if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930: the 10 S table look-ups are issued together
+            uint32_t xs[S][6], al[S][6];
+            float od[S][6], uu[S][6];
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+#pragma unroll
+                for (int g = 1; g <= 5; g++) {
+                    const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
+                    xs[s][g] = __umulhi(w0, (uint32_t)c.n);
+                    uu[s][g] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                    od[s][g] = c.hub_odds[xs[s][g]];
+                    al[s][g] = c.hub_alias[xs[s][g]];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int g = 1; g <= 5; g++) cands[s][g] = (uu[s][g] < od[s][g]) ? xs[s][g] : al[s][g];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int g = 1; g <= 5; g++)
+                    cands[s][g] = __umulhi(pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt), (uint32_t)c.n);  // :1121
+        }
 #pragma unroll
         for (int s = 0; s < S; s++) {
 #pragma unroll
             for (int g = 1; g <= 5; g++) {
-                const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
-                uint32_t cand;
-                if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
-                    const uint32_t x = __umulhi(w0, (uint32_t)c.n);
-                    const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                    cand = (uu < c.hub_odds[x]) ? x : c.hub_alias[x];
-                } else {
-                    cand = __umulhi(w0, (uint32_t)c.n);  // :1121
-                }
+                const uint32_t cand = cands[s][g];
                 uint32_t acc = cand ^ v;
 #pragma unroll
                 for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
