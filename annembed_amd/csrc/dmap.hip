@@ -272,7 +272,12 @@ namespace ae {
 
 void set_data_box_device(float* d_y, uint64_t n, uint64_t dim, float box_size) {
     std::vector<float> means(dim);
-    for (uint64_t j = 0; j < dim; j++) means[j] = seq_sum_f32(d_y + j, n, dim) / (float)n;  // :1391-1394
+    if (dim <= 256) {  // :1391-1394, the dim column sums in one pass
+        seq_sum_cols_f32(d_y, n, (uint32_t)dim, means.data());
+        for (uint64_t j = 0; j < dim; j++) means[j] /= (float)n;
+    } else {
+        for (uint64_t j = 0; j < dim; j++) means[j] = seq_sum_f32(d_y + j, n, dim) / (float)n;
+    }
     DevBuf<float> dm(dim);
     dm.upload(means.data(), dim);
     DevBuf<unsigned int> mb(1);

@@ -39,6 +39,8 @@ void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* 
 
 // exact sequential f32 sum (the reference's iter().sum::<f32>() order) of d_x[0..n) with stride
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride = 1);
+// the dim column sums of a row-major n x dim array, each in row order (dim sequential chains in one pass)
+void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_out);
 // f32 sum in the order of ndarray's Array1::sum() (eight interleaved accumulators, see svd.hip)
 float ndarray_sum_f32(const float* d_x, uint64_t n);
 

@@ -623,6 +623,38 @@ float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
     out.download(&h, 1);
     return h;
 }
+// column sums of a row-major n x dim array, each column added in row order (the reference's `for i { means[j] += data[[i, j]] }`,
+// embedder.rs:1391-1394): dim independent sequential chains, one lane each, over LDS-staged row blocks
+__global__ void __launch_bounds__(256) seq_sum_cols_kernel(const float* __restrict__ x, uint64_t n, uint32_t dim, float* __restrict__ out) {
+    extern __shared__ float cbuf[];  // rows_per_chunk x dim
+    const uint32_t rpc = 4096u / dim;
+    float s = 0.f;
+    for (uint64_t r0 = 0; r0 < n; r0 += rpc) {
+        const uint32_t nr = (uint32_t)((n - r0) < (uint64_t)rpc ? (n - r0) : (uint64_t)rpc);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nr * dim; i += 256) cbuf[i] = x[r0 * dim + i];
+        __syncthreads();
+        if (threadIdx.x < dim) {
+            uint32_t r = 0;
+            for (; r + 4 <= nr; r += 4) {
+                const float v0 = cbuf[r * dim + threadIdx.x], v1 = cbuf[(r + 1) * dim + threadIdx.x];
+                const float v2 = cbuf[(r + 2) * dim + threadIdx.x], v3 = cbuf[(r + 3) * dim + threadIdx.x];
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; r < nr; r++) s += cbuf[r * dim + threadIdx.x];
+        }
+    }
+    if (threadIdx.x < dim) out[threadIdx.x] = s;
+}
+void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_out) {
+    if (dim == 0 || dim > 256) fail(AE_ERR_INVALID_ARG, "seq_sum_cols: dimension %u unsupported", dim);
+    DevBuf<float> out;
+    out.alloc_pooled(dim);
+    hipLaunchKernelGGL(seq_sum_cols_kernel, dim3(1), dim3(256), sizeof(float) * (4096u / dim) * dim, stream(), d_x, n, dim, out.p);
+    check_launch("seq_sum_cols");
+    out.download(host_out, dim);
+}
+
 float ndarray_sum_f32(const float* d_x, uint64_t n) {
     static DevBuf<float> out;
     if (!out.n) out.alloc(1);
