@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,9 +53,17 @@ void set_last_error(const std::string& s);
                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
 
+// The library keeps per-process scratch (the stream, pooled buffers, the alternating Gram accumulators ...): entry points
+// are serialised by one recursive lock, so handles may be used from several host threads (one at a time runs).
+inline std::recursive_mutex& api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 // every C-ABI entry point body is wrapped in this: exceptions never cross the ABI
 template <class F>
 inline int32_t guard(F&& f) {
+    std::lock_guard<std::recursive_mutex> lock(api_mutex());
     try {
         f();
         return AE_OK;

@@ -17,8 +17,9 @@
  *    and are released with the matching `ae_*_destroy`.
  *  - node indices are u32 (reference: `NodeIdx = usize`, src/tools/nodeparam.rs:18), row pointers
  *    u64, distances / probabilities / coordinates f32 (the reference examples instantiate F = f32).
- *  - one handle = one HIP device + one HIP stream; calls on one handle must be serialised by the
- *    caller, different handles are independent.
+ *  - one process drives one HIP device through one library stream; entry points are thread-safe (a
+ *    process-wide recursive lock serialises them: the reference's objects are Send + Sync and driven
+ *    from one thread that fans out on rayon -- here the fan-out is the GPU).
  *  - the library is GPU-only: there is no CPU fallback.  Without a HIP device every compute entry
  *    point fails with AE_ERR_NO_DEVICE.
  */
