@@ -23,7 +23,7 @@ namespace ae {
 //            each lane replays the slice that targets its node.
 template <int DIM>
 struct NodeKernelCfg {
-    static constexpr int S = DIM <= 2 ? 4 : (DIM <= 4 ? 2 : 1);  // samples whose rows are gathered together
+    static constexpr int S = DIM <= 4 ? 2 : 1;  // samples whose rows are gathered together (measured on C2: S = 2 0.73 ms, 3 0.77, 4 0.78, 1 0.79)
     static constexpr int NQ = DIM <= 4 ? 8 : 4;                   // in-edge records per lane and pass of stage C
     static constexpr int CH = 64 * NQ;
     static constexpr int EC = DIM <= 4 ? 1024 : (DIM <= 8 ? 256 : 128);  // pushes parked in LDS per window
