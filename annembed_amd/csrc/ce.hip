@@ -23,7 +23,7 @@
 using namespace ae;
 
 namespace ae {
-void sort_keys_u64(uint64_t* d_keys_in, uint64_t* d_keys_out, uint64_t count, unsigned end_bit);
+void sort_pairs_u32_u32(uint32_t* d_keys_in, uint32_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, uint64_t count, unsigned end_bit);
 void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrows, uint64_t* d_rowptr);
 }  // namespace ae
 
@@ -97,6 +97,68 @@ __device__ __forceinline__ bool make_plan(const CeDev& c, uint64_t s, uint32_t i
     return true;
 }
 
+// The same draws with the neighbour row of i held in registers (rows of at most KMAX entries): the row scan of the
+// CDF sampler and the five rejection scans become branch-free passes over registers, their loads are issued together
+// instead of one dependent load per loop trip.  Results are those of make_plan: the cumulative sums are formed in the
+// same order, and "first t with u < acc_t" = "number of t with !(u < acc_t)" because acc is non-decreasing.
+template <int KMAX>
+__device__ __forceinline__ bool make_plan_rows(const CeDev& c, uint64_t s, uint32_t iter, Plan& p) {
+    PhiloxStream st(c.seed, s, iter);
+    uint64_t e, ib, x = 0;
+    uint32_t ilen;
+    const bool rowcdf = c.sampler == AE_SAMPLER_ROWCDF;
+    if (rowcdf) p.i = (uint32_t)(c.node_lo + st.index(c.node_hi - c.node_lo));
+    else x = st.index(c.shard_edges);
+    const float u = st.f32();
+    if (!rowcdf) {
+        if (!(u < c.edge_odds[x])) x = c.edge_alias[x];
+        p.i = c.edge_src[x];
+    }
+    row_bounds(c, p.i, ib, ilen);
+    uint32_t nb[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; t++) nb[t] = (uint32_t)t < ilen ? c.nbr[ib + t] : 0xFFFFFFFFu;  // node ids are < n < 2^32 - 1
+    if (rowcdf) {
+        float pr[KMAX];
+#pragma unroll
+        for (int t = 0; t < KMAX; t++) pr[t] = (uint32_t)t < ilen ? c.proba[ib + t] : 0.f;
+        float acc = 0.f;
+        uint32_t m = 0;
+#pragma unroll
+        for (int t = 0; t < KMAX; t++) {
+            acc += pr[t];
+            m += ((uint32_t)t < ilen && !(u < acc)) ? 1u : 0u;
+        }
+        e = ib + min(m, ilen - 1);
+    } else {
+        e = c.edge_lo + x;
+    }
+    p.j = c.nbr[e];
+    p.w = c.proba[e];
+    int got = 0;
+    uint32_t attempts = 0;
+    while (got < 5) {
+        uint32_t k;
+        if (c.hub_odds) {
+            uint64_t xx = st.index(c.n);
+            float uu = st.f32();
+            k = (uu < c.hub_odds[xx]) ? (uint32_t)xx : c.hub_alias[xx];
+        } else {
+            k = (uint32_t)st.index(c.n);
+        }
+        if (++attempts > (1u << 20)) return false;
+        bool reject = (k == p.i) || (k == p.j);
+#pragma unroll
+        for (int t = 0; t < KMAX; t++) reject |= nb[t] == k;
+        if (reject) continue;
+        // static indexing keeps p.k in registers
+#pragma unroll
+        for (int g = 0; g < 5; g++) p.k[g] = got == g ? k : p.k[g];
+        got++;
+    }
+    return true;
+}
+
 template <int DIM>
 struct Row {
     float v[DIM];
@@ -144,11 +206,10 @@ __device__ __forceinline__ double grad_coeff(double d_scaled, double scale, doub
     return 2. * b * cw / (scale * scale);
 }
 
-// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample, on rows held in registers: yi / yj are updated in place
-// (the values the reference stores at :1301 / :1239), yk are the five negatives' rows
+// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample, on rows held in registers, in its two kinds of steps:
+// the attraction along the sampled edge (updates y_i and y_j, :1207-1238) ...
 template <int DIM>
-__device__ __forceinline__ void sample_update(float* yi, float* yj, const float (*yk)[DIM], float w, double scale, double b, double grad_step) {
-    float grad[DIM];
+__device__ __forceinline__ void sample_attract(float* yi, float* yj, float* grad, float w, double scale, double b, double grad_step) {
 #pragma unroll
     for (int t = 0; t < DIM; t++) grad[t] = 0.f;  // :1199
     const double weight = (double)w;                // :1202
@@ -173,27 +234,36 @@ __device__ __forceinline__ void sample_update(float* yi, float* yj, const float 
         yi[t] -= grad[t];
         yj[t] += grad[t];
     }
+}
+// ... and one repulsion from a negative sample (updates y_i only, :1267-1297; `grad` carries over, see the quirk below)
+template <int DIM>
+__device__ __forceinline__ void sample_repulse(float* yi, const float* yk, float* grad, double scale, double b, double grad_step) {
+    float ak = 0.f;
 #pragma unroll
-    for (int g = 0; g < 5; g++) {  // :1244-1299
-        float ak = 0.f;
-#pragma unroll
-        for (int t = 0; t < DIM; t++) {  // :1267-1271
-            float df = yi[t] - yk[g][t];
-            ak += df * df;
-        }
-        const double d_ik = (double)ak;
-        const double d_ik_scaled = d_ik / (scale * scale);  // :1274
-        const double cf2 = grad_coeff(d_ik_scaled, scale, b);
-        if (d_ik > 0.) {  // :1286-1295
-            const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
-            const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
-            const float cf = (float)coeff_ik;
-#pragma unroll
-            for (int t = 0; t < DIM; t++) grad[t] = (yk[g][t] - yi[t]) * cf;
-        }  // else: `gradient` keeps its previous value, as in the reference
-#pragma unroll
-        for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
+    for (int t = 0; t < DIM; t++) {  // :1267-1271
+        float df = yi[t] - yk[t];
+        ak += df * df;
     }
+    const double d_ik = (double)ak;
+    const double d_ik_scaled = d_ik / (scale * scale);  // :1274
+    const double cf2 = grad_coeff(d_ik_scaled, scale, b);
+    if (d_ik > 0.) {  // :1286-1295
+        const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
+        const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
+        const float cf = (float)coeff_ik;
+#pragma unroll
+        for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
+    }  // else: `gradient` keeps its previous value, as in the reference
+#pragma unroll
+    for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
+}
+// the whole sample: yi / yj are updated in place (the values the reference stores at :1301 / :1239)
+template <int DIM>
+__device__ __forceinline__ void sample_update(float* yi, float* yj, const float (*yk)[DIM], float w, double scale, double b, double grad_step) {
+    float grad[DIM];
+    sample_attract<DIM>(yi, yj, grad, w, scale, b, grad_step);
+#pragma unroll
+    for (int g = 0; g < 5; g++) sample_repulse<DIM>(yi, yk[g], grad, scale, b, grad_step);  // :1244-1299
 }
 
 // in-place form: rows read from / written to the coordinate array (the negatives are never i or j, :1246-1253, so
@@ -264,18 +334,32 @@ __global__ void __launch_bounds__(256) ce_sgd_hogwild_kernel(CeDev c, uint64_t s
     }
 }
 
+template <int KMAX>  // 0: rows of any length (make_plan)
 __global__ void __launch_bounds__(256) ce_plan_kernel(CeDev c, uint64_t s_begin, uint64_t nb_sample, uint32_t iter,
                                                       uint32_t* __restrict__ plan_nodes, float* __restrict__ plan_w,
                                                       unsigned int* err) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nb_sample; s += stride) {
         Plan p;
-        if (!make_plan(c, s_begin + s, iter, p)) { atomicOr(err, 1u); p.i = p.j = 0; for (int g = 0; g < 5; g++) p.k[g] = 0; p.w = 0.f; }
+        bool ok;
+        if constexpr (KMAX == 0) ok = make_plan(c, s_begin + s, iter, p);
+        else ok = make_plan_rows<KMAX>(c, s_begin + s, iter, p);
+        if (!ok) { atomicOr(err, 1u); p.i = p.j = 0; for (int g = 0; g < 5; g++) p.k[g] = 0; p.w = 0.f; }
         uint32_t* o = plan_nodes + s * 7;
         o[0] = p.i; o[1] = p.j;
         for (int g = 0; g < 5; g++) o[2 + g] = p.k[g];
         plan_w[s] = p.w;
     }
+}
+static void launch_plan(const ae_entropy_optim* o, uint64_t s_first, uint64_t S, uint32_t iter, uint32_t* nodes, float* w) {
+    const uint32_t kmax = o->g->max_nbng;
+    const dim3 grid(grid_cap(S, 256)), block(256);
+#define AE_PLAN(K) hipLaunchKernelGGL(ce_plan_kernel<K>, grid, block, 0, stream(), o->dev, s_first, S, iter, nodes, w, o->err.p)
+    if (kmax <= 16) AE_PLAN(16);
+    else if (kmax <= 32) AE_PLAN(32);
+    else AE_PLAN(0);
+#undef AE_PLAN
+    check_launch("ce_plan");
 }
 
 template <int DIM>
@@ -311,28 +395,67 @@ __global__ void __launch_bounds__(256) ce_sgd_planned_kernel(CeDev c, const uint
 //   4. the last version of every written node is copied back into the coordinate array.
 constexpr uint32_t kNoPred = 0xFFFFFFFFu;
 
-__global__ void df_write_keys_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, uint64_t* __restrict__ keys) {
+// write events in sample order: key = node, value = version id (sample << 1 | slot).  A stable sort on the node bits
+// alone then lists every node's versions in increasing order (3 radix passes instead of the 7 a 52-bit key needs).
+__global__ void df_write_keys_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, uint32_t* __restrict__ keys,
+                                     uint32_t* __restrict__ vals) {
     const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (s >= S) return;
-    keys[2 * s] = ((uint64_t)plan_nodes[s * 7] << 32) | (s << 1);
-    keys[2 * s + 1] = ((uint64_t)plan_nodes[s * 7 + 1] << 32) | (s << 1) | 1ull;
+    *reinterpret_cast<uint2*>(keys + 2 * s) = make_uint2(plan_nodes[s * 7], plan_nodes[s * 7 + 1]);
+    *reinterpret_cast<uint2*>(vals + 2 * s) = make_uint2((uint32_t)(s << 1), (uint32_t)(s << 1) | 1u);
+}
+// rowptr[x] = first sorted position whose node >= x
+__global__ void df_rowptr_kernel(const uint32_t* __restrict__ keys, uint64_t nnz, uint64_t n, uint64_t* __restrict__ rowptr) {
+    const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (x > n) return;
+    uint64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    rowptr[x] = lo;
 }
 
-// pred[s * 7 + t] = (sample << 1 | slot) of the last write of node plan_nodes[s * 7 + t] by a sample < s, or kNoPred
-__global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint64_t* __restrict__ keys,
+// pred[s * 7 + t] = (sample << 1 | slot) of the last write of node plan_nodes[s * 7 + t] by a sample < s, or kNoPred.
+// A node's writers are spread evenly over the batch (i.i.d. samples), so the answer lies within a few entries of the
+// interpolated position: probe there, gallop to a bracket, finish by bisection -- the probes share one or two cache
+// lines instead of the ~log2(len) lines of a bisection from the ends (C3 shape: 56 ms -> see DESIGN.md).
+__global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint32_t* __restrict__ vals,
                                const uint64_t* __restrict__ rowptr, uint32_t* __restrict__ pred) {
     const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (idx >= S * 7) return;
-    const uint64_t s = idx / 7;
+    const uint32_t s = (uint32_t)(idx / 7);
     const uint32_t x = plan_nodes[idx];
-    uint64_t lo = rowptr[x], hi = rowptr[x + 1];  // first key of node x with sample >= s: lower bound on (sample)
-    const uint64_t base = lo;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (((keys[mid] & 0xFFFFFFFFull) >> 1) < s) lo = mid + 1;
-        else hi = mid;
+    const uint64_t lo = rowptr[x], hi = rowptr[x + 1];
+    if (lo == hi) { pred[idx] = kNoPred; return; }
+    const uint32_t key = s << 1;  // first version with sample >= s: vals < key  <=>  its sample < s
+    uint64_t g = lo + (uint64_t)((float)(hi - lo) * ((float)s / (float)S));
+    g = min(g, hi - 1);
+    uint64_t L, H;  // every index < L holds a value < key, every index >= H a value >= key
+    if (vals[g] < key) {
+        L = g + 1;
+        H = hi;
+        for (uint64_t step = 4; L + step < hi; step *= 2) {
+            const uint64_t q = L + step;
+            if (vals[q] < key) L = q + 1;
+            else { H = q; break; }
+        }
+    } else {
+        H = g;
+        L = lo;
+        for (uint64_t step = 4; H >= lo + step; step *= 2) {
+            const uint64_t q = H - step;
+            if (vals[q] < key) { L = q + 1; break; }
+            H = q;
+        }
     }
-    pred[idx] = lo > base ? (uint32_t)(keys[lo - 1] & 0xFFFFFFFFull) : kNoPred;
+    while (L < H) {
+        const uint64_t mid = (L + H) >> 1;
+        if (vals[mid] < key) L = mid + 1;
+        else H = mid;
+    }
+    pred[idx] = L > lo ? vals[L - 1] : kNoPred;
 }
 
 // A version row is published by its stores alone: the buffer is filled with an all-ones pattern (a NaN no arithmetic
@@ -401,7 +524,14 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
             }
             w = plan_w[s];
         }
+        // The sample advances step by step as its rows arrive: the attraction needs rows 0 and 1 and publishes y_j at once
+        // (a successor that only reads y_j does not wait for the five repulsions), repulsion g needs row 1 + g; y_i is
+        // published after the last one.  A dependency therefore delays only the steps that really use it.
         uint32_t polls = 0;
+        int stage = 0;  // 0: attraction pending; 1..5: repulsion `stage` pending; 6: done
+        float grad[DIM];
+        double scale = 1.;
+        if (!finished) scale = (double)c.emb_scale[node[0]];
         while (!__all(finished)) {
             if (!finished) {
 #pragma unroll
@@ -415,10 +545,26 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                         }
                     }
                 }
-                if (pending == 0u) {
-                    sample_update<DIM>(rows[0], rows[1], rows + 2, w, (double)c.emb_scale[node[0]], c.b, grad_step);
-                    df_store_version<DIM>(ver, s * 2, rows[0]);
+                if (stage == 0 && (pending & 3u) == 0u) {
+                    sample_attract<DIM>(rows[0], rows[1], grad, w, scale, c.b, grad_step);
                     df_store_version<DIM>(ver, s * 2 + 1, rows[1]);
+                    stage = 1;
+                }
+                // one code path for the five repulsions: the row is selected by the stage, lanes leave when they block
+                while (stage >= 1 && stage <= 5 && ((pending >> (1 + stage)) & 1u) == 0u) {
+                    float yk[DIM];
+#pragma unroll
+                    for (int q = 0; q < DIM; q++) {
+                        float v = rows[2][q];
+#pragma unroll
+                        for (int g = 2; g <= 5; g++) v = stage == g ? rows[1 + g][q] : v;
+                        yk[q] = v;
+                    }
+                    sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
+                    stage++;
+                }
+                if (stage == 6) {
+                    df_store_version<DIM>(ver, s * 2, rows[0]);
                     finished = true;
                 } else if (++polls > (1u << 24)) {  // cannot happen (see above): fail instead of hanging
                     atomicOr(err, 8u);
@@ -437,11 +583,11 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
 
 // the last version of every node written in the batch becomes its row in the coordinate array
 template <int DIM>
-__global__ void df_commit_kernel(uint64_t n, const uint64_t* __restrict__ rowptr, const uint64_t* __restrict__ keys,
+__global__ void df_commit_kernel(uint64_t n, const uint64_t* __restrict__ rowptr, const uint32_t* __restrict__ vals,
                                  const float* __restrict__ ver, float* __restrict__ y) {
     const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (x >= n || rowptr[x + 1] == rowptr[x]) return;
-    const uint32_t pv = (uint32_t)(keys[rowptr[x + 1] - 1] & 0xFFFFFFFFull);
+    const uint32_t pv = vals[rowptr[x + 1] - 1];
 #pragma unroll
     for (int t = 0; t < DIM; t++) y[x * DIM + t] = ver[(uint64_t)pv * DIM + t];
 }
@@ -554,7 +700,7 @@ static void check_err_flag(ae_entropy_optim* o) {
 }
 
 template <int DIM>
-static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const uint64_t* rowptr, const uint64_t* keys) {
+static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
     if constexpr (DIM > 0) {
         static int blocks_per_cu = 0, cus = 0;
         if (!blocks_per_cu) {
@@ -567,13 +713,13 @@ static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const 
         int bpc = 0;
         AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, 256, 0));
         blocks_per_cu = std::max(1, std::min(bpc, 8));
-        // few lanes in flight: the run is bound by the dependency chain (one memory round trip + one sample's f64
-        // arithmetic per hop), more pollers only add traffic (measured on MI355X: 128 x 64 lanes 30 ms, 256 x 64 34 ms,
-        // 1024 x 256 67 ms per C2 batch)
-        const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 64u;
+        // the run is bound by the dependency chain (one memory round trip + the f64 arithmetic of the steps that use the
+        // row, per hop): enough lanes to keep every chain moving, not more -- pollers add traffic (measured on MI355X,
+        // C2 batch: 64 x 64 lanes 22 ms, 128 x 64 14 ms, 256 x 64 10.2 ms, 256 x 128 10.0 ms, 512 x 128 10.5 ms)
+        const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 128u;
         unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)blocks_per_cu * cus, blocks_for(S, bs));
-        // ... so the grid grows with the batch: ~1000 samples per lane, at least 128 workgroups
-        const unsigned want = (unsigned)std::max<uint64_t>(128, S / (1024ull * bs));
+        // ... so the grid grows with the batch: ~256 samples per lane, at least 256 workgroups
+        const unsigned want = (unsigned)std::max<uint64_t>(256, S / (256ull * bs));
         grid = std::min<unsigned>(grid, getenv("AE_DF_GRID") ? (unsigned)atoi(getenv("AE_DF_GRID")) : want);
         CeDev dev = o->dev;
         const uint32_t* pn = o->plan_nodes.p;
@@ -603,20 +749,23 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
     const bool prof = getenv("AE_CE_PROF") != nullptr;
     auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(S, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset, S, iter, o->plan_nodes.p,
-                       o->plan_w.p, o->err.p);
-    check_launch("ce_plan");
+    launch_plan(o, o->sample_offset, S, iter, o->plan_nodes.p, o->plan_w.p);
     const double t1 = now();
-    hipLaunchKernelGGL(df_write_keys_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p, o->df_keys0.p);
+    // each key buffer holds 2 S node keys followed by 2 S version ids
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(o->df_keys0.p);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(o->df_keys1.p);
+    uint32_t *v0 = k0 + 2 * S, *v1 = k1 + 2 * S;
+    hipLaunchKernelGGL(df_write_keys_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p, k0, v0);
     unsigned node_bits = 1;
     while (node_bits < 32 && (o->dev.n >> node_bits)) node_bits++;
-    sort_keys_u64(o->df_keys0.p, o->df_keys1.p, 2 * S, 32 + node_bits);
-    rowptr_from_sorted_keys(o->df_keys1.p, 2 * S, o->dev.n, o->df_rowptr.p);
+    sort_pairs_u32_u32(k0, k1, v0, v1, 2 * S, node_bits);
+    hipLaunchKernelGGL(df_rowptr_kernel, dim3(blocks_for(o->dev.n + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)k1, 2 * S,
+                       (uint64_t)o->dev.n, o->df_rowptr.p);
     hipLaunchKernelGGL(df_pred_kernel, dim3(blocks_for(S * 7, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p,
-                       (const uint64_t*)o->df_keys1.p, (const uint64_t*)o->df_rowptr.p, o->df_pred.p);
+                       (const uint32_t*)v1, (const uint64_t*)o->df_rowptr.p, o->df_pred.p);
     check_launch("df_pred");
     const double t2 = now();
-    AE_DISPATCH_DIM(dim, launch_dataflow, o, S, step, (const uint64_t*)o->df_rowptr.p, (const uint64_t*)o->df_keys1.p);
+    AE_DISPATCH_DIM(dim, launch_dataflow, o, S, step, (const uint64_t*)o->df_rowptr.p, (const uint32_t*)v1);
     check_launch("ce_dataflow");
     sync();
     if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan %.2f ms, sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
@@ -638,9 +787,7 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
     if (o->plan_nodes.n < nb_sample * 7) o->plan_nodes.alloc(nb_sample * 7);
     if (o->plan_w.n < nb_sample) o->plan_w.alloc(nb_sample);
     if (o->order.n < nb_sample) o->order.alloc(nb_sample);
-    hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(nb_sample, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset, nb_sample,
-                       iter, o->plan_nodes.p, o->plan_w.p, o->err.p);
-    check_launch("ce_plan");
+    launch_plan(o, o->sample_offset, nb_sample, iter, o->plan_nodes.p, o->plan_w.p);
     const bool prof = getenv("AE_CE_PROF") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -862,9 +1009,7 @@ int32_t ae_entropy_optim_plan(ae_entropy_optim* o, uint64_t s_begin, uint64_t co
         if (!o || !nodes7 || count == 0) fail(AE_ERR_INVALID_ARG, "bad argument");
         DevBuf<uint32_t> dn(count * 7);
         DevBuf<float> dw(count);
-        hipLaunchKernelGGL(ce_plan_kernel, dim3(grid_cap(count, 256)), dim3(256), 0, stream(), o->dev, o->sample_offset + s_begin, count,
-                           (uint32_t)iter, dn.p, dw.p, o->err.p);
-        check_launch("ce_plan");
+        launch_plan(o, o->sample_offset + s_begin, count, (uint32_t)iter, dn.p, dw.p);
         dn.download(nodes7, count * 7);
         if (w) dw.download(w, count);
         check_err_flag(o);

@@ -603,6 +603,17 @@ void sort_keys_u64(uint64_t* d_keys_in, uint64_t* d_keys_out, uint64_t count, un
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_keys failed");
 }
 
+// stable (LSD radix) sort of (key, value) pairs on the key bits [0, end_bit)
+void sort_pairs_u32_u32(uint32_t* d_keys_in, uint32_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, uint64_t count, unsigned end_bit) {
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, count, 0, end_bit, stream()) != hipSuccess)
+        fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
+    DevBuf<char> tmp;
+    tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
+    if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, count, 0, end_bit, stream()) != hipSuccess)
+        fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs failed");
+}
+
 void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrows, uint64_t* d_rowptr) {
     hipLaunchKernelGGL(rowptr_from_sorted_keys_kernel, dim3(blocks_for(nrows + 1, 256)), dim3(256), 0, stream(), d_keys, nnz, nrows,
                        d_rowptr);
