@@ -4,6 +4,7 @@
 #include <unordered_map>
 
 #include "objects.h"
+#include "linalg.h"
 
 namespace ae {
 
@@ -160,52 +161,58 @@ __global__ void row_sort_kernel(uint64_t n, const uint64_t* __restrict__ indptr,
     }
 }
 
-// exact kNN by brute force: one thread per query, candidates staged through LDS in tiles.
-// Input producer for benchmarks (stand-in for hnsw_rs), not on the embedding hot path.
+// exact kNN by brute force: one thread per query, candidates staged through LDS in tiles.  Defines the result of the
+// kNN producer (knn.hip reaches the same rows on the matrix cores and uses this kernel for the rows it cannot certify).
+// `rows` (optional) lists the queries; blockIdx.y selects a chunk of the points, the per-chunk lists are merged by
+// knn_merge_chunks_kernel (chunks ascending + strict comparisons: among equal distances the smaller index wins).
 template <int TILE>
 __global__ void __launch_bounds__(256) bruteforce_knn_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim, uint32_t k,
+                                                             const uint32_t* __restrict__ rows, uint64_t nrows, uint64_t chunk_len,
                                                              uint32_t* __restrict__ out_nbr, float* __restrict__ out_d2) {
     extern __shared__ float tile[];  // TILE x dimchunk
     constexpr int DC = 32;           // coordinates per chunk
-    uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    float* best_d = out_d2 + q * k;  // kept sorted ascending in global (L2 resident), k small
-    uint32_t* best_i = out_nbr + q * k;
-    if (q < n)
-        for (uint32_t t = 0; t < k; t++) { best_d[t] = INFINITY; best_i[t] = 0xFFFFFFFFu; }
-    for (uint64_t c0 = 0; c0 < n; c0 += TILE) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const bool active = t < nrows;
+    const uint64_t q = active ? (rows ? rows[t] : t) : 0;
+    const uint64_t c_begin = blockIdx.y * chunk_len, c_end = c_begin + chunk_len < n ? c_begin + chunk_len : n;
+    float* best_d = out_d2 + (t * gridDim.y + blockIdx.y) * k;  // kept sorted ascending in global (L2 resident), k small
+    uint32_t* best_i = out_nbr + (t * gridDim.y + blockIdx.y) * k;
+    if (active)
+        for (uint32_t s = 0; s < k; s++) { best_d[s] = INFINITY; best_i[s] = 0xFFFFFFFFu; }
+    for (uint64_t c0 = c_begin; c0 < c_end; c0 += TILE) {
         float acc[TILE];
 #pragma unroll
-        for (int t = 0; t < TILE; t++) acc[t] = 0.f;
+        for (int s = 0; s < TILE; s++) acc[s] = 0.f;
         for (uint64_t d0 = 0; d0 < dim; d0 += DC) {
             __syncthreads();
             for (int idx = threadIdx.x; idx < TILE * DC; idx += blockDim.x) {
-                int t = idx / DC, d = idx % DC;
-                uint64_t c = c0 + t;
-                tile[idx] = (c < n && d0 + d < dim) ? x[c * dim + d0 + d] : 0.f;
+                int s = idx / DC, d = idx % DC;
+                uint64_t c = c0 + s;
+                tile[idx] = (c < c_end && d0 + d < dim) ? x[c * dim + d0 + d] : 0.f;
             }
             __syncthreads();
-            if (q < n) {
+            if (active) {
                 float xq[DC];
 #pragma unroll
                 for (int d = 0; d < DC; d++) xq[d] = (d0 + d < dim) ? x[q * dim + d0 + d] : 0.f;
 #pragma unroll
-                for (int t = 0; t < TILE; t++) {
-                    float a = acc[t];
+                for (int s = 0; s < TILE; s++) {
+                    float a = acc[s];
 #pragma unroll
                     for (int d = 0; d < DC; d++) {
-                        float df = xq[d] - tile[t * DC + d];
+                        float df = xq[d] - tile[s * DC + d];
                         a += df * df;
                     }
-                    acc[t] = a;
+                    acc[s] = a;
                 }
             }
         }
-        if (q < n) {
+        if (active) {
 #pragma unroll
-            for (int t = 0; t < TILE; t++) {
-                uint64_t c = c0 + t;
-                if (c >= n || c == q) continue;
-                float d = acc[t];
+            for (int s = 0; s < TILE; s++) {
+                uint64_t c = c0 + s;
+                if (c >= c_end || c == q) continue;
+                float d = acc[s];
                 if (!(d < best_d[k - 1])) continue;
                 uint32_t pos = k - 1;
                 while (pos > 0 && d < best_d[pos - 1]) {
@@ -218,8 +225,30 @@ __global__ void __launch_bounds__(256) bruteforce_knn_kernel(const float* __rest
             }
         }
     }
-    if (q < n)
-        for (uint32_t t = 0; t < k; t++) best_d[t] = sqrtf(best_d[t]);
+}
+// thread per query: the k smallest (d2, index) of its per-chunk lists, written as row `q` of the graph (sqrt applied)
+__global__ void knn_merge_chunks_kernel(const uint32_t* __restrict__ rows, uint64_t nrows, uint32_t chunks, uint32_t k,
+                                        const uint32_t* __restrict__ part_i, const float* __restrict__ part_d,
+                                        uint32_t* __restrict__ nbr, float* __restrict__ dist) {
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= nrows) return;
+    const uint64_t q = rows ? rows[t] : t;
+    float* bd = dist + q * k;
+    uint32_t* bi = nbr + q * k;
+    for (uint32_t s = 0; s < k; s++) { bd[s] = INFINITY; bi[s] = 0xFFFFFFFFu; }
+    for (uint64_t e = t * chunks * k; e < (t + 1) * chunks * k; e++) {
+        const float d = part_d[e];
+        if (!(d < bd[k - 1])) continue;
+        uint32_t pos = k - 1;
+        while (pos > 0 && d < bd[pos - 1]) {
+            bd[pos] = bd[pos - 1];
+            bi[pos] = bi[pos - 1];
+            pos--;
+        }
+        bd[pos] = d;
+        bi[pos] = part_i[e];
+    }
+    for (uint32_t s = 0; s < k; s++) bd[s] = sqrtf(bd[s]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -251,6 +280,29 @@ static void finish_kgraph(ae_kgraph* g) {
     }
     g->uniform_k = (hnon == 0 && g->n && g->nnz == (uint64_t)k0 * g->n) ? k0 : 0;
 }
+
+namespace ae {
+// exact brute force for the listed rows (nullptr: rows 0..nrows-1); few rows are spread over many point chunks
+void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint32_t* d_rows, uint64_t nrows,
+                         uint32_t* d_nbr, float* d_dist) {
+    if (nrows == 0) return;
+    constexpr int TILE = 32;
+    const uint64_t row_blocks = blocks_for(nrows, 256);
+    uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / row_blocks), std::max<uint64_t>(1, n / 128));
+    chunks = std::min<uint32_t>(chunks, 1024);
+    const uint64_t chunk_len = (n + chunks - 1) / chunks;
+    DevBuf<uint32_t> part_i;
+    DevBuf<float> part_d;
+    part_i.alloc_pooled(nrows * chunks * k);
+    part_d.alloc_pooled(nrows * chunks * k);
+    hipLaunchKernelGGL((bruteforce_knn_kernel<TILE>), dim3((unsigned)row_blocks, chunks), dim3(256), TILE * 32 * sizeof(float), stream(), d_x,
+                       n, dim, k, d_rows, nrows, chunk_len, part_i.p, part_d.p);
+    check_launch("bruteforce_knn");
+    hipLaunchKernelGGL(knn_merge_chunks_kernel, dim3((unsigned)row_blocks), dim3(256), 0, stream(), d_rows, nrows, chunks, k,
+                       (const uint32_t*)part_i.p, (const float*)part_d.p, d_nbr, d_dist);
+    check_launch("knn_merge_chunks");
+}
+}  // namespace ae
 
 extern "C" {
 
@@ -504,10 +556,14 @@ int32_t ae_kgraph_bruteforce_l2(const float* x, uint64_t n, uint64_t dim, uint32
         g->indptr.upload(indptr.data(), n + 1);
         g->nbr.alloc(g->nnz);
         g->dist.alloc(g->nnz);
-        constexpr int TILE = 32;
-        hipLaunchKernelGGL((bruteforce_knn_kernel<TILE>), dim3(blocks_for(n, 256)), dim3(256), TILE * 32 * sizeof(float), stream(),
-                           dx.p, n, dim, nbng, g->nbr.p, g->dist.p);
-        check_launch("bruteforce_knn");
+        // matrix-core path (knn.hip) for the usual neighbourhood sizes; AE_KNN_LEGACY=1 keeps the plain kernel (A/B)
+        if (nbng + 8 <= 32 && !getenv("AE_KNN_LEGACY")) {
+            const uint64_t fell_back = knn_mfma(dx.p, n, dim, nbng, g->nbr.p, g->dist.p);
+            if (getenv("AE_CE_PROF")) fprintf(stderr, "KNN rows recomputed by the brute-force fallback: %llu of %llu\n",
+                                              (unsigned long long)fell_back, (unsigned long long)n);
+        } else {
+            bruteforce_knn_rows(dx.p, n, dim, nbng, nullptr, n, g->nbr.p, g->dist.p);
+        }
         finish_kgraph(g.get());
         *out = g.release();
     });

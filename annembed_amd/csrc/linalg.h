@@ -44,4 +44,8 @@ void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_ou
 // f32 sum in the order of ndarray's Array1::sum() (eight interleaved accumulators, see svd.hip)
 float ndarray_sum_f32(const float* d_x, uint64_t n);
 
+// exact L2 kNN rows (n x k) on the matrix cores, knn.hip; returns the number of rows recomputed by the brute-force fallback
+uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32_t* d_nbr, float* d_dist);
+void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint32_t* d_rows, uint64_t nrows,
+                         uint32_t* d_nbr, float* d_dist);
 }  // namespace ae

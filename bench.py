@@ -126,6 +126,7 @@ def main():
         dst = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1).reshape(-1)
         indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
         svd_dense = None
+        knn_producer = None
     else:
         x = synth_points(n, args.dim, seed=1)
         nbr_l, dist_l = knn_rows(x, lo, hi, k)
@@ -153,6 +154,18 @@ def main():
                          "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
                          "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
             del mat
+        # secondary figure (rank 0, N = 1): the exact kNN-graph producer on the matrix cores, host matrix in,
+        # KGraph out (includes the PCIe upload of the points)
+        knn_producer = None
+        if world == 1 and not args.no_dense_svd:
+            xh = x.cpu().numpy()
+            A.KGraph.bruteforce_l2(xh, k)  # warm
+            t0 = time.perf_counter()
+            A.KGraph.bruteforce_l2(xh, k)
+            dt = time.perf_counter() - t0
+            knn_producer = {"shape": "%dx%d k=%d" % (n, args.dim, k), "ms": dt * 1e3, "tflops": 2.0 * n * n * args.dim / dt / 1e12,
+                            "mfma_f32_peak_tflops": 157.3, "note": "exact (certified candidates + brute-force fallback), upload included"}
+            del xh
         del x
         indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
         nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
@@ -297,6 +310,7 @@ def main():
                 "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
             },
             "svd_dense": svd_dense,
+            "knn_producer": knn_producer,
             "exact_mode": exact_mode,
             "samples_per_s": nb_sample * world * args.steps / elapsed,
             "ce_before": ce_before, "ce_after": ce_after,

@@ -96,6 +96,30 @@ def kgraph_from_ragged(point_id, row_ptr, nbr_data_id, nbr_dist, nbng):
     return 0, (indptr, nbr[:nnz].copy(), dist[:nnz].copy(), ids)
 
 
+def knn_bruteforce_l2(x, k):
+    """Exact L2 kNN graph as the build's producer defines it (no reference counterpart: the reference takes its graph
+    from hnsw_rs, kgraph.rs:496-546): F(i, j) = f32 sum over the coordinates IN ORDER of (x_i[t] - x_j[t])^2,
+    row i = the k points j != i with the smallest (F, j), ascending, distance sqrt(F) in f32.
+    Returns CSR (indptr u64, nbr u32, dist f32)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, dim = x.shape
+    nbr = np.zeros((n, k), np.uint32)
+    dist = np.zeros((n, k), np.float32)
+    bs = max(1, min(n, (1 << 24) // max(n, 1)))
+    for b in range(0, n, bs):
+        e = min(n, b + bs)
+        f = np.zeros((e - b, n), np.float32)
+        for t in range(dim):  # sequential f32 accumulation over the coordinates
+            df = x[b:e, t][:, None] - x[None, :, t]
+            f += df * df
+        f[np.arange(e - b), np.arange(b, e)] = np.inf
+        order = np.argsort(f, axis=1, kind="stable")[:, :k]  # stable: the smaller index wins among equal F
+        nbr[b:e] = order
+        dist[b:e] = np.sqrt(np.take_along_axis(f, order, 1))
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    return indptr, nbr.reshape(-1), dist.reshape(-1)
+
+
 def hubness(indptr, nbr):
     n = len(indptr) - 1
     counts = np.zeros(n, np.uint32)

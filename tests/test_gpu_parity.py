@@ -120,6 +120,34 @@ def test_distance_batching_and_bruteforce(A):
     assert (nb == nbr).mean() > 0.999  # ties may be ordered differently
 
 
+@pytest.mark.parametrize("n,dim,k", [(1200, 24, 7), (1000, 33, 12), (257, 130, 24), (130, 7, 5), (40, 5, 12), (20, 5, 5)])
+def test_knn_producer_bit_exact(A, oracle, n, dim, k):
+    """the matrix-core kNN producer returns exactly the rows of its definition (oracle.knn_bruteforce_l2:
+    sequential f32 sums of squares, ties by index) -- index sets AND distances bit for bit; n and dim off the tile sizes,
+    dim not a multiple of 4, fewer points than the candidate list."""
+    x, _ = gaussian_mixture(n, dim, 3, seed=n + dim)
+    x = (x * 50.0 + 120.0).astype(np.float32)  # image-like offsets: large norms, small neighbour distances
+    ip, nb, ds = A.KGraph.bruteforce_l2(x, k).get_neighbours()
+    oi, on, od = oracle.knn_bruteforce_l2(x, k)
+    assert np.array_equal(ip, oi) and np.array_equal(nb, on) and np.array_equal(ds, od)
+
+
+def test_knn_producer_duplicates_and_ties(A, oracle, monkeypatch):
+    """40 copies of the same point (more than the 32 candidates a row keeps) and lattice points with many equal
+    distances: the certificate must fail for such rows and the brute-force fallback must produce the defined order;
+    the plain kernel (AE_KNN_LEGACY) gives the same graph."""
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 4, size=(900, 6)).astype(np.float32)  # lattice: massive ties
+    x[100:140] = x[100]
+    k = 10
+    ip, nb, ds = A.KGraph.bruteforce_l2(x, k).get_neighbours()
+    oi, on, od = oracle.knn_bruteforce_l2(x, k)
+    assert np.array_equal(nb, on) and np.array_equal(ds, od)
+    monkeypatch.setenv("AE_KNN_LEGACY", "1")
+    ip2, nb2, ds2 = A.KGraph.bruteforce_l2(x, k).get_neighbours()
+    assert np.array_equal(nb2, nb) and np.array_equal(ds2, ds)
+
+
 # ------------------------------------------------------------------------------------------------
 # a2 to_proba_edges
 # ------------------------------------------------------------------------------------------------

@@ -133,3 +133,17 @@ def test_committed_bench_evidence_is_well_formed():
     pmc = os.path.join(os.path.dirname(files[-1]), "pmc_ce_round.json")
     with open(pmc) as f:
         assert abs(json.load(f)["hbm_bytes_per_launch"] - r["traffic"]) < 0.05 * r["traffic"]
+
+
+def test_oracle_knn_definition_matches_f64_bruteforce():
+    """oracle.knn_bruteforce_l2 (the definition the device producer is held to) against an independent f64 brute force:
+    same neighbours on well-separated data, distances within f32 rounding; ties resolved by index."""
+    from oracle import oracle as O
+    from tests.util import gaussian_mixture, knn_graph
+    x, _ = gaussian_mixture(400, 12, 3, seed=9)
+    ip, nb, ds = O.knn_bruteforce_l2(x, 6)
+    ip2, nb2, ds2 = knn_graph(x, 6)
+    assert np.array_equal(ip, ip2) and np.array_equal(nb, nb2) and np.allclose(ds, ds2, rtol=2e-6, atol=1e-6)
+    xt = np.zeros((6, 2), np.float32)  # all points identical: every row lists the other indices in increasing order
+    _, nbt, dst = O.knn_bruteforce_l2(xt, 3)
+    assert np.array_equal(nbt.reshape(6, 3)[0], [1, 2, 3]) and np.array_equal(nbt.reshape(6, 3)[5], [0, 1, 2]) and not dst.any()
