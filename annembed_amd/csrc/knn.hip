@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256) knn_norms_kernel(const float* __restrict_
 // candidate pass.  MFMA operand layout (svd.hip): A lane -> A[i = lane & 31][k = lane >> 5], B lane -> B[k = lane >> 5][j = lane & 31],
 // C: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Wave w owns query rows [32 w, 32 w + 32) of
 // the workgroup's 128 and all four 32-column blocks of the point tile: one A fragment feeds four MFMAs.
+template <bool VEC4>  // dim % 4 == 0: 16-byte loads
 __global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim,
                                                              const float* __restrict__ pn, uint32_t* __restrict__ cand_i,
                                                              float* __restrict__ cand_a) {
@@ -68,8 +69,10 @@ __global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __r
     const uint64_t q0 = blockIdx.x * (uint64_t)kBQ;
     for (int idx = tid; idx < kM * kBQ; idx += 256) { ld[idx] = INFINITY; li[idx] = 0xFFFFFFFFu; }
     float thr = INFINITY;  // threads < kBQ: value of the last slot of their row
-    const bool vec4 = (dim % 4) == 0;
     // staging: (128 + 128) rows x 32 coordinates = 2048 float4, 8 per thread (4 of the query tile, 4 of the point tile)
+    // The loads keep their raw values in registers; the masking (coordinates beyond dim -> 0) happens when the stage is
+    // written to LDS, one K-step later -- masking at the load site would put the wait for the loads in front of the MFMAs.
+    // Rows beyond n are clamped to row 0: their results are never used (query side) or overwritten by +inf (point side).
     float ra[4][4], rb[4][4];
     auto gload = [&](uint64_t p0, uint64_t k0) {
 #pragma unroll
@@ -78,23 +81,20 @@ __global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __r
             const int r = idx >> 3, kc = (idx & 7) * 4;
             const uint64_t kk = k0 + kc;
             const uint64_t qa = q0 + r, qb = p0 + r;
-            const bool ain = qa < n, bin = qb < n;
-            const float* pa = x + (ain ? qa : 0) * dim;
-            const float* pb = x + (bin ? qb : 0) * dim;
-            if (vec4) {
-                const bool kin = kk < dim;
-                const float4 ta = *reinterpret_cast<const float4*>(pa + (kin ? kk : 0));
-                const float4 tb = *reinterpret_cast<const float4*>(pb + (kin ? kk : 0));
-                const bool ua = ain && kin, ub = bin && kin;
-                ra[q][0] = ua ? ta.x : 0.f; ra[q][1] = ua ? ta.y : 0.f; ra[q][2] = ua ? ta.z : 0.f; ra[q][3] = ua ? ta.w : 0.f;
-                rb[q][0] = ub ? tb.x : 0.f; rb[q][1] = ub ? tb.y : 0.f; rb[q][2] = ub ? tb.z : 0.f; rb[q][3] = ub ? tb.w : 0.f;
+            const float* pa = x + (qa < n ? qa : 0) * dim;
+            const float* pb = x + (qb < n ? qb : 0) * dim;
+            if constexpr (VEC4) {
+                const uint64_t ko = kk < dim ? kk : 0;
+                const float4 ta = *reinterpret_cast<const float4*>(pa + ko);
+                const float4 tb = *reinterpret_cast<const float4*>(pb + ko);
+                ra[q][0] = ta.x; ra[q][1] = ta.y; ra[q][2] = ta.z; ra[q][3] = ta.w;
+                rb[q][0] = tb.x; rb[q][1] = tb.y; rb[q][2] = tb.z; rb[q][3] = tb.w;
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const bool kin = kk + t < dim;
-                    const float va = pa[kin ? kk + t : 0], vb = pb[kin ? kk + t : 0];
-                    ra[q][t] = (ain && kin) ? va : 0.f;
-                    rb[q][t] = (bin && kin) ? vb : 0.f;
+                    const uint64_t ko = kk + t < dim ? kk + t : 0;
+                    ra[q][t] = pa[ko];
+                    rb[q][t] = pb[ko];
                 }
             }
         }
@@ -111,13 +111,19 @@ __global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __r
             for (int q = 0; q < 4; q++) {
                 const int idx = tid + q * 256;
                 const int off = (idx >> 3) * LDK + (idx & 7) * 4;
-                sA[off] = ra[q][0]; sA[off + 1] = ra[q][1]; sA[off + 2] = ra[q][2]; sA[off + 3] = ra[q][3];
-                sB[off] = rb[q][0]; sB[off + 1] = rb[q][1]; sB[off + 2] = rb[q][2]; sB[off + 3] = rb[q][3];
+                const uint64_t kk = k0 + (idx & 7) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool kin = kk + t < dim;
+                    sA[off + t] = kin ? ra[q][t] : 0.f;
+                    sB[off + t] = kin ? rb[q][t] : 0.f;
+                }
             }
             __syncthreads();
             // next stage (or the first stage of the next tile) in flight under the MFMAs and the epilogue
             if (k0 + kKT < dim) gload(p0, k0 + kKT);
             else if (p0 + kBP < n) gload(p0 + kBP, 0);
+            __builtin_amdgcn_sched_barrier(0);  // the loads are issued here, not sunk below the MFMAs to their first use
             const float* pa = sA + (w * 32 + (lane & 31)) * LDK + (lane >> 5);
             const float* pb = sB + (lane & 31) * LDK + (lane >> 5);
 #pragma unroll
@@ -243,11 +249,16 @@ uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32
     const size_t lds = sizeof(float) * ((size_t)(kBQ + kBP) * (kKT + 1) + 2 * (size_t)kM * kBQ);
     static bool attr_set = false;
     if (!attr_set) {
-        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(knn_candidates_kernel, dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p, cand_i.p,
-                       cand_a.p);
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(knn_candidates_kernel<true>, dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
+                           cand_i.p, cand_a.p);
+    else
+        hipLaunchKernelGGL(knn_candidates_kernel<false>, dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
+                           cand_i.p, cand_a.p);
     check_launch("knn_candidates");
     hipLaunchKernelGGL(knn_refine_kernel, dim3(blocks_for(n * kM, 256)), dim3(256), 0, stream(), d_x, n, dim, k, (const uint32_t*)cand_i.p,
                        (const float*)cand_a.p, (const double*)pn64.p, (const unsigned int*)counters.p, d_nbr, d_dist, flagged.p, counters.p + 1);
