@@ -503,13 +503,17 @@ __device__ __forceinline__ void df_store_version(float* __restrict__ ver, uint64
 template <int DIM>
 __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
                                                           const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
-                                                          float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+                                                          float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err, uint32_t lane_stride) {
+    // only every lane_stride-th lane carries samples: a wave's trip through the loop below costs the poll round trip plus
+    // the arithmetic of whichever lanes advance, and a blocked lane moves once per trip -- fewer passengers, shorter trips
+    const uint64_t gtid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const bool carrier = gtid % lane_stride == 0;
+    const uint64_t nthreads = ((uint64_t)gridDim.x * blockDim.x) / lane_stride;
+    const uint64_t tid = gtid / lane_stride;
     const uint64_t sweeps = (S + nthreads - 1) / nthreads;
     for (uint64_t k = 0; k < sweeps; k++) {  // wave-uniform trip count; sample indices increase with k
         const uint64_t s = k * nthreads + tid;
-        bool finished = s >= S;
+        bool finished = !carrier || s >= S;
         uint32_t node[7], pr[7];
         float rows[7][DIM];
         float w = 0.f;
@@ -710,24 +714,31 @@ static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const 
             AE_HIP(hipGetDeviceProperties(&prop, dev));
             cus = prop.multiProcessorCount;
         }
-        int bpc = 0;
-        AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, 256, 0));
-        blocks_per_cu = std::max(1, std::min(bpc, 8));
-        // the run is bound by the dependency chain (one memory round trip + the f64 arithmetic of the steps that use the
-        // row, per hop): enough lanes to keep every chain moving, not more -- pollers add traffic (measured on MI355X,
-        // C2 batch: 64 x 64 lanes 22 ms, 128 x 64 14 ms, 256 x 64 10.2 ms, 256 x 128 10.0 ms, 512 x 128 10.5 ms)
         const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 128u;
-        unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)blocks_per_cu * cus, blocks_for(S, bs));
-        // ... so the grid grows with the batch: ~256 samples per lane, at least 256 workgroups
-        const unsigned want = (unsigned)std::max<uint64_t>(256, S / (256ull * bs));
-        grid = std::min<unsigned>(grid, getenv("AE_DF_GRID") ? (unsigned)atoi(getenv("AE_DF_GRID")) : want);
+        int bpc = 0;
+        AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, (int)bs, 0));
+        blocks_per_cu = std::max(1, std::min(bpc, 8));
+        const uint64_t blocks_cap = (uint64_t)blocks_per_cu * cus;
+        // The run is bound by the dependency chain: per hop one trip of the carrying wave through its loop (poll round
+        // trip + the f64 arithmetic of the lanes that advance).  Enough carrier lanes to keep every chain moving
+        // (~512 samples per carrier, at least 16 K carriers), spread thinly over the waves (every 8th lane) while the
+        // resident grid allows it; big batches are throughput-bound and use every lane.  Measured on MI355X, C2 batch:
+        // 256 x 128 lanes all carrying 10.0 ms; 1024 x 128 with every 4th 8.8 ms, every 8th 8.2 ms, every 16th 10.1 ms;
+        // C3 shape (100 M samples, full grid): all lanes 17 ms, every 2nd 22 ms, every 8th 53 ms.
+        const uint64_t carriers_want = std::min<uint64_t>(S, std::max<uint64_t>(16384, S / 512));
+        uint32_t lane_stride = 8;
+        while (lane_stride > 1 && blocks_cap * bs / lane_stride < carriers_want) lane_stride /= 2;
+        if (getenv("AE_DF_LANE_STRIDE")) lane_stride = (uint32_t)atoi(getenv("AE_DF_LANE_STRIDE"));
+        if (lane_stride == 0 || (bs % lane_stride) != 0) lane_stride = 1;
+        unsigned grid = (unsigned)std::min<uint64_t>(blocks_cap, std::max<uint64_t>(1, (carriers_want * lane_stride + bs - 1) / bs));
+        if (getenv("AE_DF_GRID")) grid = (unsigned)std::min<uint64_t>(blocks_cap, std::max(1, atoi(getenv("AE_DF_GRID"))));
         CeDev dev = o->dev;
         const uint32_t* pn = o->plan_nodes.p;
         const float* pw = o->plan_w.p;
         const uint32_t* pred = o->df_pred.p;
         float* ver = o->df_ver.p;
         unsigned int* err = o->err.p;
-        void* args[] = {&dev, &S, &pn, &pw, &pred, &ver, &step, &err};
+        void* args[] = {&dev, &S, &pn, &pw, &pred, &ver, &step, &err, &lane_stride};
         AE_HIP(hipMemsetAsync(ver, 0xFF, sizeof(float) * S * 2 * DIM, stream()));  // every version "unpublished"
         // cooperative launch: the runtime refuses a grid that cannot be resident at once (the progress argument needs it)
         AE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<void*>(ce_dataflow_kernel<DIM>), dim3(grid), dim3(bs), args, 0, stream()));
