@@ -27,7 +27,6 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kM = 32;    // candidates kept per row
 constexpr int kBQ = 128;  // query rows per workgroup
 constexpr int kBP = 128;  // points per tile
 constexpr int kKT = 32;   // coordinates per LDS stage
@@ -54,8 +53,8 @@ __global__ void __launch_bounds__(256) knn_norms_kernel(const float* __restrict_
 // candidate pass.  MFMA operand layout (svd.hip): A lane -> A[i = lane & 31][k = lane >> 5], B lane -> B[k = lane >> 5][j = lane & 31],
 // C: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Wave w owns query rows [32 w, 32 w + 32) of
 // the workgroup's 128 and all four 32-column blocks of the point tile: one A fragment feeds four MFMAs.
-template <bool VEC4>  // dim % 4 == 0: 16-byte loads
-__global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim,
+template <bool VEC4, int kM>  // dim % 4 == 0: 16-byte loads; kM candidates kept per row (32: two workgroups per CU, 64: one)
+__global__ void __launch_bounds__(256, kM == 32 ? 2 : 1) knn_candidates_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim,
                                                              const float* __restrict__ pn, uint32_t* __restrict__ cand_i,
                                                              float* __restrict__ cand_a) {
     constexpr int LDK = kKT + 1;
@@ -181,7 +180,8 @@ __global__ void __launch_bounds__(256, 2) knn_candidates_kernel(const float* __r
     }
 }
 
-// refine + certificate: 32 lanes per row, lane s owns candidate s
+// refine + certificate: kM lanes per row, lane s owns candidate s
+template <int kM>
 __global__ void __launch_bounds__(256) knn_refine_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim, uint32_t k,
                                                          const uint32_t* __restrict__ cand_i, const float* __restrict__ cand_a,
                                                          const double* __restrict__ pn64,
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(const float* __restrict
     const uint64_t gid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t i = gid / kM;
     const int s = (int)(gid % kM);
-    if (i >= n) return;  // whole half-waves leave together (kM = 32 lanes per row)
+    if (i >= n) return;  // the kM lanes of a row leave together
     const uint32_t j = cand_i[i * kM + s];
     const bool valid = j != 0xFFFFFFFFu;
     const float* xi = x + i * dim;
@@ -227,19 +227,14 @@ __global__ void __launch_bounds__(256) knn_refine_kernel(const float* __restrict
     }
 }
 
-}  // namespace
-
-namespace ae {
-
-// exact kNN rows of all n points into d_nbr / d_dist (n x k); returns the number of rows that needed the fallback
-uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32_t* d_nbr, float* d_dist) {
-    if (k + 8 > (uint32_t)kM) fail(AE_ERR_INVALID_ARG, "knn_mfma: nbng + 8 exceeds the candidate list");
+template <int kM>
+static uint64_t knn_mfma_m(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32_t* d_nbr, float* d_dist) {
     DevBuf<float> pn, cand_a;
     DevBuf<double> pn64;
-    pn64.alloc_pooled(n);
     DevBuf<uint32_t> cand_i, flagged;
     DevBuf<unsigned int> counters(2);
     pn.alloc_pooled(n);
+    pn64.alloc_pooled(n);
     cand_a.alloc_pooled(n * kM);
     cand_i.alloc_pooled(n * kM);
     flagged.alloc_pooled(n);
@@ -249,24 +244,36 @@ uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32
     const size_t lds = sizeof(float) * ((size_t)(kBQ + kBP) * (kKT + 1) + 2 * (size_t)kM * kBQ);
     static bool attr_set = false;
     if (!attr_set) {
-        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<true, kM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_candidates_kernel<false, kM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (dim % 4 == 0)
-        hipLaunchKernelGGL(knn_candidates_kernel<true>, dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
+        hipLaunchKernelGGL((knn_candidates_kernel<true, kM>), dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
                            cand_i.p, cand_a.p);
     else
-        hipLaunchKernelGGL(knn_candidates_kernel<false>, dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
+        hipLaunchKernelGGL((knn_candidates_kernel<false, kM>), dim3(blocks_for(n, kBQ)), dim3(256), lds, stream(), d_x, n, dim, (const float*)pn.p,
                            cand_i.p, cand_a.p);
     check_launch("knn_candidates");
-    hipLaunchKernelGGL(knn_refine_kernel, dim3(blocks_for(n * kM, 256)), dim3(256), 0, stream(), d_x, n, dim, k, (const uint32_t*)cand_i.p,
+    hipLaunchKernelGGL(knn_refine_kernel<kM>, dim3(blocks_for(n * kM, 256)), dim3(256), 0, stream(), d_x, n, dim, k, (const uint32_t*)cand_i.p,
                        (const float*)cand_a.p, (const double*)pn64.p, (const unsigned int*)counters.p, d_nbr, d_dist, flagged.p, counters.p + 1);
     check_launch("knn_refine");
     unsigned int h[2];
     counters.download(h, 2);
     if (h[1]) bruteforce_knn_rows(d_x, n, dim, k, flagged.p, h[1], d_nbr, d_dist);
     return h[1];
+}
+
+}  // namespace
+
+namespace ae {
+
+// exact kNN rows of all n points into d_nbr / d_dist (n x k); returns the number of rows that needed the fallback
+uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32_t* d_nbr, float* d_dist) {
+    if (k + 8 <= 32) return knn_mfma_m<32>(d_x, n, dim, k, d_nbr, d_dist);
+    if (k + 8 <= 64) return knn_mfma_m<64>(d_x, n, dim, k, d_nbr, d_dist);
+    fail(AE_ERR_INVALID_ARG, "knn_mfma: nbng + 8 exceeds the candidate list");
+    return 0;
 }
 
 }  // namespace ae

@@ -172,7 +172,7 @@ int32_t ae_kgraph_fill_l2_distances(ae_kgraph *g, const float *x, uint64_t dim);
    the hnsw_rs producer in benchmarks.  Self matches are excluded (kgraph.rs:502
    asserts index != neighbour).  Definition: F(i, j) = f32 sum, coordinates in order, of
    (x_i[t] - x_j[t])^2; row i = the nbng points with the smallest (F, j); dist = sqrtf(F).
-   For nbng <= 24 the candidates come from an MFMA pass (|p|^2 - 2 <x, p>), are re-evaluated with
+   For nbng <= 56 the candidates come from an MFMA pass (|p|^2 - 2 <x, p>), are re-evaluated with
    the definition and certified by an error bound; uncertified rows take the plain kernel, so the
    rows are exact for any input (knn.hip).  AE_KNN_LEGACY=1 forces the plain kernel. */
 int32_t ae_kgraph_bruteforce_l2(const float *x, uint64_t n, uint64_t dim, uint32_t nbng,

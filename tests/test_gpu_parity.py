@@ -120,7 +120,7 @@ def test_distance_batching_and_bruteforce(A):
     assert (nb == nbr).mean() > 0.999  # ties may be ordered differently
 
 
-@pytest.mark.parametrize("n,dim,k", [(1200, 24, 7), (1000, 33, 12), (257, 130, 24), (130, 7, 5), (40, 5, 12), (20, 5, 5)])
+@pytest.mark.parametrize("n,dim,k", [(1200, 24, 7), (1000, 33, 12), (257, 130, 24), (130, 7, 5), (40, 5, 12), (20, 5, 5), (600, 10, 40), (300, 3, 56), (2000, 2, 50)])
 def test_knn_producer_bit_exact(A, oracle, n, dim, k):
     """the matrix-core kNN producer returns exactly the rows of its definition (oracle.knn_bruteforce_l2:
     sequential f32 sums of squares, ties by index) -- index sets AND distances bit for bit; n and dim off the tile sizes,
