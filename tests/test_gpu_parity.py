@@ -148,6 +148,26 @@ def test_knn_producer_duplicates_and_ties(A, oracle, monkeypatch):
     assert np.array_equal(nb2, nb) and np.array_equal(ds2, ds)
 
 
+def test_embed_cli_end_to_end(A, tmp_path):
+    """The `embed` command line (src/bin/embed.rs) on the library: CSV in (first record dropped, io.rs:170-186), exact
+    kNN graph, embed, CSV out in the reference's `{:.5e}` format with one row per kept record."""
+    from annembed_amd import embed_cli, io
+    x, _ = gaussian_mixture(601, 8, 3, seed=2)
+    src = tmp_path / "in.csv"
+    io.write_csv_array2(str(src), x)
+    out = tmp_path / "out.csv"
+    assert embed_cli.main(["--csv", str(src), "--out", str(out), "--batch", "8", "--dim", "2", "hnsw", "--dist", "DistL2", "--nbconn", "16",
+                           "--ef", "100", "--knbn", "8"]) == 0
+    lines = out.read_text().strip().split("\n")
+    assert len(lines) == 600
+    import re
+    assert all(re.fullmatch(r"-?\d\.\d{5}e-?\d+,-?\d\.\d{5}e-?\d+", ln) for ln in lines)
+    y = np.array([[float(v) for v in ln.split(",")] for ln in lines], np.float32)
+    assert np.isfinite(y).all() and np.abs(y).max() > 0.1
+    with pytest.raises(SystemExit):
+        embed_cli.main(["--csv", str(src), "--layer", "1"])
+
+
 # ------------------------------------------------------------------------------------------------
 # a2 to_proba_edges
 # ------------------------------------------------------------------------------------------------

@@ -73,3 +73,20 @@ def test_kgraph_file_roundtrip_and_validation(tmp_path):
         aio.read_kgraph(tmp_path / "x.kgraph")
     with pytest.raises(ValueError):
         aio.write_kgraph(tmp_path / "bad.kgraph", indptr, nbr[:-1], dist)
+
+
+def test_embed_cli_flags_mirror_reference_defaults():
+    """src/bin/embed.rs:224-321: flag names and defaults (batch 20, stepg 2., nbsample 10, layer 0, scale 1.0, dim 2, no
+    quality; HnswParams::my_default :66-74 without the hnsw subcommand)."""
+    from annembed_amd import embed_cli as E
+    ns, h = E.parse(["--csv", "x.csv"])
+    assert (ns.batch, ns.stepg, ns.nbsample, ns.hierarchy, ns.scale, ns.dimension, ns.quality, ns.outfile) == (20, 2.0, 10, 0, 1.0, 2, None, None)
+    assert h == {"max_conn": 64, "ef_c": 512, "knbn": 10, "distance": "DistL2", "scale_modification": 1.0}
+    ns, h = E.parse(["--csv", "x.csv", "-o", "y.csv", "--batch", "5", "--dim", "3", "--layer", "1", "-q", "0.5", "hnsw", "--dist", "DistCosine",
+                     "--nbconn", "48", "--ef", "400", "--knbn", "6", "--scale_modify_f", "0.5"])
+    assert (ns.outfile, ns.batch, ns.dimension, ns.hierarchy, ns.quality) == ("y.csv", 5, 3, 1, 0.5)
+    assert h == {"max_conn": 48, "ef_c": 400, "knbn": 6, "distance": "DistCosine", "scale_modification": 0.5}
+    with pytest.raises(SystemExit):
+        E.parse(["--csv", "x.csv", "hnsw", "--dist", "DistFoo", "--nbconn", "4", "--ef", "4", "--knbn", "4"])
+    with pytest.raises(SystemExit):
+        E.parse(["--batch", "5"])  # --csv is required
