@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--lattice-graph", action="store_true",
                     help="scale runs (C3 / C4 shapes): ring-lattice kNN graph with gamma-distributed distances instead of an exact kNN of synthetic points (an 11 M-point exact kNN is out of reach of brute force)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the collective path with world size 1 (validation)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="validation only: gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices), so the whole "
+                         "N > 1 code path -- sharded node ranges, gathered kNN rows, per-batch all-gather, max-over-ranks timing -- "
+                         "can be run end to end on a single-GPU box; the figure it prints is not a benchmark result")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +103,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # ranks share the device(s) that exist
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -106,7 +112,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import annembed_amd as A
     from annembed_amd import _lib as L
@@ -292,7 +301,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.backend == "nccl" else "synthetic (VALIDATION RUN over gloo, ranks sharing a GPU: not a result)",
             "config": {
                 "workload": ("ring-lattice kNN graph %d nodes -> %dD, k=%d, dmap init + CE loop (scale run); %d points per GPU" % (n, d, k, ppg))
                             if args.lattice_graph else

@@ -790,3 +790,29 @@ def test_range_approx_epsil_stops_at_the_rank(A, oracle):
     a64 = a.astype(np.float64)
     q64 = q.astype(np.float64)
     assert np.linalg.norm(a64 - q64 @ (q64.T @ a64)) < 1e-4 * np.linalg.norm(a64)
+
+
+def test_bench_sharded_path_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end -- two processes, sharded node ranges, gathered kNN rows, the per-batch
+    all-gather on the library's stream, max-over-ranks timing, one JSON line from rank 0 -- with the two ranks sharing
+    this box's single GPU over gloo (RCCL refuses duplicate devices; the collective is the only difference to the
+    8-GPU launch of the driver)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--points-per-gpu", "6000", "--dim", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["config"]["samples_per_step"] == 2 * 6000 * 12 * 10
+    assert j["value"] > 0 and np.isfinite(j["ce_after"]) and j["roofline"]["rounds"] >= 1
