@@ -79,6 +79,30 @@ __device__ __forceinline__ float repulse_coeff(float d, float inv_s2, float step
     }
 }
 
+// Wide rows (d = 8 / 16: 32 / 64 bytes).  With the row held by one lane, a gather instruction puts every lane on a cache
+// line of its own and a row costs 2 / 4 requests; out of a footprint beyond the Infinity Cache the memory system then
+// delivers 40 / 24 G rows/s, against 55 G rows/s when each row is ONE request (tools/ubench_rowgather.hip: the bound is
+// requests, not bytes).  So the rows of a lane group (G = d/4 lanes) are fetched cooperatively -- in step j every lane of
+// the group loads its 16-byte quarter of the row wanted by the group's lane j -- and handed to their owners through LDS
+// when they are consumed (`untangle`).
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true);
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t x, int j) {  // value of the group's lane j (j is a constant after unrolling)
+    if constexpr (G == 4) {
+        switch (j) {
+            case 0: return quad_perm<0x00>(x);
+            case 1: return quad_perm<0x55>(x);
+            case 2: return quad_perm<0xAA>(x);
+            default: return quad_perm<0xFF>(x);
+        }
+    } else {
+        return j == 0 ? quad_perm<0xA0>(x) : quad_perm<0xF5>(x);
+    }
+}
+
 // The workgroup is ONE wave: its LDS operations execute in program order, so making one lane's LDS writes visible to
 // the others needs no s_barrier -- and must not use __syncthreads(), whose workgroup-scope fence drains every
 // outstanding global load (vmcnt(0)) and would serialise the gathers that are deliberately left in flight.
@@ -98,6 +122,10 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     __shared__ float s_in_b[EC];      // b == 1: 2 step / s_u^2 * w
     __shared__ float s_in_is2[EC];
     __shared__ uint32_t s_pos[CH + 1];
+    constexpr bool COOP = !PAD && (DIM == 8 || DIM == 16);  // rows gathered by lane groups (see group_bcast above)
+    constexpr int G = COOP ? DIM / 4 : 1, RS = DIM + 4;     // LDS row stride of the hand-over buffer: 16-byte aligned, spreads the banks
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ __attribute__((aligned(16))) float s_tr[COOP ? 64 * RS : 4];
     const CeDev c = a.c;
     const int lane = threadIdx.x;
     // row access: exact dimension = vector loads of the whole row; PAD = asked_dim < DIM, the registers beyond
@@ -108,6 +136,37 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             const float* p = c.y + (uint64_t)node * c.dim;
 #pragma unroll
             for (int t = 0; t < DIM; t++) out[t] = (uint32_t)t < c.dim ? __builtin_nontemporal_load(p + t) : 0.f;
+        }
+    };
+    // gather of a partner row.  COOP: `out` receives the group's rows in quarters (out[4 j ..] = this lane's quarter of the
+    // row wanted by the group's lane j) until untangle() swaps them into place; every lane takes part (no divergence here)
+    auto ldg = [&](uint32_t node, float* out) {
+        if constexpr (!COOP) ld(node, out);
+        else {
+            const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const uint32_t rj = group_bcast<G>(node, j);
+                const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)rj * DIM) + sub);
+                out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
+            }
+        }
+    };
+    auto untangle = [&](float* r) {
+        if constexpr (COOP) {
+            const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1), base = (uint32_t)lane & ~(uint32_t)(G - 1);
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                f4 t; t.x = r[4 * j]; t.y = r[4 * j + 1]; t.z = r[4 * j + 2]; t.w = r[4 * j + 3];
+                *reinterpret_cast<f4*>(&s_tr[(base + (uint32_t)j) * RS + sub * 4u]) = t;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+                const f4 t = *reinterpret_cast<const f4*>(&s_tr[(uint32_t)lane * RS + (uint32_t)q * 4u]);
+                r[4 * q] = t.x; r[4 * q + 1] = t.y; r[4 * q + 2] = t.z; r[4 * q + 3] = t.w;
+            }
+            wave_lds_sync();
         }
     };
     auto st = [&](uint32_t node, const float* in) {
@@ -286,15 +345,16 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             const bool act = (pl.act >> s) & 1u;
             ck.ws[s] = pl.ws[s];
 #pragma unroll
-            for (int g = 0; g < 6; g++) ld(act ? pl.idx[s][g] : v, ck.rows[s][g]);
+            for (int g = 0; g < 6; g++) ldg(act ? pl.idx[s][g] : v, ck.rows[s][g]);
         }
     };
-    auto replay = [&](const Chunk& ck) {
+    auto replay = [&](Chunk& ck) {
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool act = (ck.act >> s) & 1u;
             float grad[DIM];
             {   // attraction, the y_i half of embedder.rs:1207-1237
+                untangle(ck.rows[s][0]);
                 float d = 0.f;
 #pragma unroll
                 for (int q = 0; q < DIM; q++) { const float df = yv[q] - ck.rows[s][0][q]; d += df * df; }
@@ -305,6 +365,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
 #pragma unroll
             for (int g = 1; g <= 5; g++) {  // 5 repulsions, :1267-1297
+                untangle(ck.rows[s][g]);
                 float dk = 0.f;
 #pragma unroll
                 for (int q = 0; q < DIM; q++) { const float df = yv[q] - ck.rows[s][g][q]; dk += df * df; }
@@ -372,7 +433,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
             poisson_batch<NQ>(u, mu, cn);
 #pragma unroll
-            for (int q = 0; q < NQ; q++) ld(cn[q] ? recA[q].src : v, yu[q]);
+            for (int q = 0; q < NQ; q++) ldg(cn[q] ? recA[q].src : v, yu[q]);
         };
         load_recs(t_begin + CH, recB);  // (clamped inside when past the end)
         count_and_gather(t_begin);
@@ -404,6 +465,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
                     pb[q] = B1 ? step2 * pis2[q] * recA[q].w : 0.f;
 #pragma unroll
                     for (int t = 0; t < DIM; t++) yuP[q][t] = yu[q][t];
+                    untangle(yuP[q]);
                 }
             }
             if (lane == 0) s_pos[CH] = total;

@@ -340,11 +340,12 @@ def test_hogwild_statistics_match_oracle(A, oracle):
 
 
 @pytest.mark.parametrize("dim,k,hub,b", [(5, 8, False, 1.0), (10, 20, True, 1.0), (20, 28, False, 1.0), (3, 32, False, 1.0), (7, 12, True, 1.0),
-                                         (2, 10, False, 0.8), (6, 20, True, 1.3)])
+                                         (2, 10, False, 0.8), (6, 20, True, 1.3), (8, 12, False, 1.0), (16, 10, True, 1.0), (8, 30, True, 1.0),
+                                         (16, 16, False, 0.9)])
 def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     """asked_dim without an exact kernel instantiation (run zero-padded to 8 / 16 / 32 columns), rows of up to 32
     neighbours, hubness-weighted negatives, exponent b != 1: same statistical bar as the 2-D case against the
-    oracle's sequential run."""
+    oracle's sequential run.  d = 8 and 16 are the kernels whose partner rows are gathered by lane groups."""
     n = 4000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
     g = A.KGraph(indptr, nbr, dist)
