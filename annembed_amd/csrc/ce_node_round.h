@@ -193,6 +193,19 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_begin = tk0;
 #define AE_TICK(i) if (a.prof) { const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); tk_acc[i] += tk1 - tk0; tk0 = tk1; }
+    // ---- loads of stage A first: they depend on v only.  The in-edge records below need tptr (a dependent hop); were
+    // they requested first, stage A would wait behind them (loads complete in order) -- two round trips, ~36 k cycles each
+    // when the memory system is saturated by the other waves' gathers (C4 / C5 shapes)
+    uint32_t nbr_reg[KMAX];
+    float pr_raw[KMAX], yv[DIM];
+#pragma unroll
+    for (int m = 0; m < KMAX; m++) {  // unconditional loads (clamped index): all in flight together
+        const uint32_t mm = (uint32_t)m < k ? (uint32_t)m : k - 1u;
+        nbr_reg[m] = c.nbr[ib + mm];
+        pr_raw[m] = c.proba[ib + mm];
+    }
+    ld(v, yv);
+    const float s_v = c.emb_scale[v];
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
     // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
     const uint32_t v0 = (uint32_t)(c.node_lo + local0);
@@ -207,25 +220,26 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             rec[q] = a.tin[x < t_end ? x : t_begin];
         }
     };
-    if (t_begin < t_end) load_recs(t_begin, recA);
+    // d >= 8: the kernel is at the register limit and the compiler parks the records in AGPRs as soon as they arrive, i.e.
+    // it waits for them on the spot -- a second exposed round trip in front of stage A.  There the first records are
+    // requested together with the gathers of the first chunk of stage B (one wait for both).
+    constexpr bool LATE_RECS = DIM >= 8;
+    auto late_recs = [&] {
+        if constexpr (LATE_RECS) { if (t_begin < t_end) load_recs(t_begin, recA); }
+    };
+    if constexpr (!LATE_RECS) { if (t_begin < t_end) load_recs(t_begin, recA); }
     // ---- stage A: the node's row in registers (rejection test) and in an LDS column private to the lane
     // (dynamic index, no barrier needed), cumulative Poisson counts of the out-edges packed 4 per register
-    uint32_t nbr_reg[KMAX], cumP[KP];
+    uint32_t cumP[KP];
     uint32_t nv;
     {
         float pr[KMAX], mu[KMAX], u[KMAX];
         uint32_t cnt[KMAX];
 #pragma unroll
-        for (int m = 0; m < KMAX; m++) {  // unconditional loads (clamped index): all in flight together
-            const uint32_t mm = (uint32_t)m < k ? (uint32_t)m : k - 1u;
-            nbr_reg[m] = c.nbr[ib + mm];
-            pr[m] = c.proba[ib + mm];
-        }
-#pragma unroll
         for (int m = 0; m < KMAX; m++) {
             const bool has = (uint32_t)m < k;
             nbr_reg[m] = has ? nbr_reg[m] : 0xFFFFFFFFu;  // the pad never equals a candidate
-            pr[m] = has ? pr[m] : 0.f;
+            pr[m] = has ? pr_raw[m] : 0.f;
             s_nbr[m * LS + lane] = nbr_reg[m];
             s_w[m * LS + lane] = pr[m];
             mu[m] = (has && valid) ? a.unit * pr[m] : 0.f;
@@ -246,9 +260,6 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-    float yv[DIM];
-    ld(v, yv);
-    const float s_v = c.emb_scale[v];
     const float inv_s2 = rcp(s_v * s_v);
     const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
     AE_TICK(0)
@@ -388,8 +399,9 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             if (nmax) {
                 plan_chunk(hub_tag, 0u, pl, [] {});
                 issue(pl, cA);
+                late_recs();
                 if ((uint32_t)S < nmax) plan_chunk(hub_tag, (uint32_t)S, pl, [] {});
-            }
+            } else late_recs();
             AE_TICK(1)
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
@@ -403,6 +415,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
         } else {  // 32 padded columns: one chunk in registers at a time
             Chunk cA;
+            late_recs();
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
                 plan_chunk(hub_tag, t0, pl, [] {});

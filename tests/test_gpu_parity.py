@@ -808,9 +808,9 @@ def test_bench_sharded_path_two_ranks_on_one_gpu():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--points-per-gpu", "6000", "--dim", "32"]
+           "--backend", "gloo", "--points-per-gpu", "6000", "--dim", "64", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
