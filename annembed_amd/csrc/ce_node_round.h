@@ -138,20 +138,6 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             for (int t = 0; t < DIM; t++) out[t] = (uint32_t)t < c.dim ? __builtin_nontemporal_load(p + t) : 0.f;
         }
     };
-    // gather of a partner row.  COOP: `out` receives the group's rows in quarters (out[4 j ..] = this lane's quarter of the
-    // row wanted by the group's lane j) until untangle() swaps them into place; every lane takes part (no divergence here)
-    auto ldg = [&](uint32_t node, float* out) {
-        if constexpr (!COOP) ld(node, out);
-        else {
-            const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
-#pragma unroll
-            for (int j = 0; j < G; j++) {
-                const uint32_t rj = group_bcast<G>(node, j);
-                const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)rj * DIM) + sub);
-                out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
-            }
-        }
-    };
     auto untangle = [&](float* r) {
         if constexpr (COOP) {
             const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1), base = (uint32_t)lane & ~(uint32_t)(G - 1);
@@ -184,6 +170,25 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     const uint64_t local = local0 + (uint64_t)lane;
     const bool valid = local < nodes_owned;
     const uint32_t v = (uint32_t)(c.node_lo + (valid ? local : nodes_owned - 1));
+    // gather of a partner row.  COOP: `out` receives the group's rows in quarters (out[4 j ..] = this lane's quarter of the
+    // row wanted by the group's lane j) until untangle() swaps them into place; every lane takes part (no divergence here)
+    auto ldg = [&](uint32_t node, bool want, float* out) {
+        if constexpr (!COOP) ld(want ? node : v, out);
+        else {
+            // a row nobody wants (idle lane, in-edge without a push) is not requested at all: `out` keeps its previous
+            // (finite) content, which the masked arithmetic ignores.  The predicate is uniform over the lane group.
+            const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const uint32_t rj = group_bcast<G>(node, j);
+                const uint32_t wj = group_bcast<G>(want ? 1u : 0u, j);
+                if (wj) {
+                    const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)rj * DIM) + sub);
+                    out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
+                }
+            }
+        }
+    };
     uint64_t ib;
     uint32_t k;
     if (c.uniform_k) { ib = (uint64_t)v * c.uniform_k; k = c.uniform_k; }
@@ -204,12 +209,24 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
         nbr_reg[m] = c.nbr[ib + mm];
         pr_raw[m] = c.proba[ib + mm];
     }
-    ld(v, yv);
+    // the wave's own 64 rows are contiguous in memory: for wide rows they are read (and written back, st_rows) as one
+    // coalesced block through the hand-over buffer -- 8 lines per instruction instead of one line per lane
+    const uint32_t v0 = (uint32_t)(c.node_lo + local0);
+    const uint64_t n_here = (nodes_owned - local0) < 64ull ? (nodes_owned - local0) : 64ull;
+    f4 own_raw[G];
+    if constexpr (COOP) {
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const uint32_t e = (uint32_t)(i * 64 + lane), row = e / (uint32_t)G, qq = e % (uint32_t)G;
+            const uint32_t rc = row < (uint32_t)n_here ? row : (uint32_t)n_here - 1u;
+            own_raw[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)(v0 + rc) * DIM) + qq);
+        }
+    } else {
+        ld(v, yv);
+    }
     const float s_v = c.emb_scale[v];
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
     // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
-    const uint32_t v0 = (uint32_t)(c.node_lo + local0);
-    const uint64_t n_here = (nodes_owned - local0) < 64ull ? (nodes_owned - local0) : 64ull;
     const uint64_t t_begin = a.tptr[v0], t_end = a.tptr[v0 + n_here];
     const uint64_t tb_v = valid ? a.tptr[v] : 0ull, te_v = valid ? a.tptr[v + 1] : 0ull;
     InEdge recA[NQ], recB[NQ];
@@ -261,6 +278,40 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
     const float inv_s2 = rcp(s_v * s_v);
+    if constexpr (COOP) {
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const uint32_t e = (uint32_t)(i * 64 + lane), row = e / (uint32_t)G, qq = e % (uint32_t)G;
+            *reinterpret_cast<f4*>(&s_tr[row * RS + qq * 4u]) = own_raw[i];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            const f4 t = *reinterpret_cast<const f4*>(&s_tr[(uint32_t)lane * RS + (uint32_t)q * 4u]);
+            yv[4 * q] = t.x; yv[4 * q + 1] = t.y; yv[4 * q + 2] = t.z; yv[4 * q + 3] = t.w;
+        }
+        wave_lds_sync();
+    }
+    // write-back of the wave's rows, all lanes (COOP only): a row has one writer, rewriting an unchanged row is harmless
+    auto st_rows = [&]() {
+        if constexpr (COOP) {
+            constexpr int H = DIM / 2;
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+                f4 t; t.x = yv[4 * q]; t.y = yv[4 * q + 1]; t.z = yv[4 * q + 2]; t.w = yv[4 * q + 3];
+                *reinterpret_cast<f4*>(&s_tr[(uint32_t)lane * RS + (uint32_t)q * 4u]) = t;
+            }
+            wave_lds_sync();
+            uint64_t* dst = reinterpret_cast<uint64_t*>(c.y + (uint64_t)v0 * DIM);
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                const uint32_t e = (uint32_t)(i * 64 + lane), row = e / (uint32_t)H, h = e % (uint32_t)H;
+                const uint64_t bits = *reinterpret_cast<const uint64_t*>(&s_tr[row * RS + h * 2u]);
+                if (row < (uint32_t)n_here) __hip_atomic_store(dst + e, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_lds_sync();
+        }
+    };
     const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
     AE_TICK(0)
     // ---- stage B.  prepare(t0): node sets of samples t0 .. t0+S-1 and their 6 S gathers;  replay(): the
@@ -356,7 +407,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             const bool act = (pl.act >> s) & 1u;
             ck.ws[s] = pl.ws[s];
 #pragma unroll
-            for (int g = 0; g < 6; g++) ldg(act ? pl.idx[s][g] : v, ck.rows[s][g]);
+            for (int g = 0; g < 6; g++) ldg(pl.idx[s][g], act, ck.rows[s][g]);
         }
     };
     auto replay = [&](Chunk& ck) {
@@ -395,7 +446,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     auto stage_b = [&](auto hub_tag) {
         ChunkPlan pl;
         if constexpr (DIM <= 16) {
-            Chunk cA, cB;
+            Chunk cA = {}, cB = {};  // zeroed once: a row that is not requested keeps finite content
             if (nmax) {
                 plan_chunk(hub_tag, 0u, pl, [] {});
                 issue(pl, cA);
@@ -427,7 +478,8 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     };
     if (hub) stage_b(std::true_type{});
     else stage_b(std::false_type{});
-    if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
+    if constexpr (COOP) { if (a.store_mode == 2) st_rows(); }
+    else if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
     // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,
     // gathers of the sources' rows, an exclusive scan of the counts = position of every push in the list of
     // pushes of the pass (zero counts vanish, a count of c takes c slots, a node's pushes are contiguous since
@@ -435,7 +487,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     bool any_push = false;
     if (t_begin < t_end) {
         uint32_t cn[NQ];
-        float yu[NQ][DIM];
+        float yu[NQ][DIM] = {};
         auto count_and_gather = [&](uint64_t cb) {
             float mu[NQ], u[NQ];
 #pragma unroll
@@ -446,7 +498,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
             poisson_batch<NQ>(u, mu, cn);
 #pragma unroll
-            for (int q = 0; q < NQ; q++) ldg(cn[q] ? recA[q].src : v, yu[q]);
+            for (int q = 0; q < NQ; q++) ldg(recA[q].src, cn[q] != 0u, yu[q]);
         };
         load_recs(t_begin + CH, recB);  // (clamped inside when past the end)
         count_and_gather(t_begin);
@@ -558,7 +610,8 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
             }
         }
     }
-    if (valid && ((a.store_mode == 2 && any_push) || (a.store_mode == 3 && (any_push || nv)))) st(v, yv);
+    if constexpr (COOP) { if (a.store_mode == 2 || a.store_mode == 3) st_rows(); }
+    else if (valid && ((a.store_mode == 2 && any_push) || (a.store_mode == 3 && (any_push || nv)))) st(v, yv);
     // samples drawn: one atomic per wave, spread over 1024 counters (a single address serialises at ~12 ns each)
     unsigned long long mine = valid ? (unsigned long long)nv : 0ull;
 #pragma unroll
