@@ -198,33 +198,39 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_begin = tk0;
 #define AE_TICK(i) if (a.prof) { const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); tk_acc[i] += tk1 - tk0; tk0 = tk1; }
-    // ---- loads of stage A first: they depend on v only.  The in-edge records below need tptr (a dependent hop); were
-    // they requested first, stage A would wait behind them (loads complete in order) -- two round trips, ~36 k cycles each
-    // when the memory system is saturated by the other waves' gathers (C4 / C5 shapes)
+    // ---- loads of stage A: they depend on v only.  Where they are issued is a measured choice per kernel family:
+    // d >= 8 (C4 / C5 shapes, memory system saturated, a dependent round trip ~36 k cycles): ahead of everything else;
+    // d <= 4: after the in-edge record prefetch, the own row after the counts (C2: 48.3 us per launch against 48.8 us)
+    constexpr bool LATE_RECS = DIM >= 8;
     uint32_t nbr_reg[KMAX];
-    float pr_raw[KMAX], yv[DIM];
-#pragma unroll
-    for (int m = 0; m < KMAX; m++) {  // unconditional loads (clamped index): all in flight together
-        const uint32_t mm = (uint32_t)m < k ? (uint32_t)m : k - 1u;
-        nbr_reg[m] = c.nbr[ib + mm];
-        pr_raw[m] = c.proba[ib + mm];
-    }
-    // the wave's own 64 rows are contiguous in memory: for wide rows they are read (and written back, st_rows) as one
-    // coalesced block through the hand-over buffer -- 8 lines per instruction instead of one line per lane
+    float pr_raw[KMAX], yv[DIM], s_v;
     const uint32_t v0 = (uint32_t)(c.node_lo + local0);
     const uint64_t n_here = (nodes_owned - local0) < 64ull ? (nodes_owned - local0) : 64ull;
     f4 own_raw[G];
-    if constexpr (COOP) {
+    auto row_loads = [&] {
 #pragma unroll
-        for (int i = 0; i < G; i++) {
-            const uint32_t e = (uint32_t)(i * 64 + lane), row = e / (uint32_t)G, qq = e % (uint32_t)G;
-            const uint32_t rc = row < (uint32_t)n_here ? row : (uint32_t)n_here - 1u;
-            own_raw[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)(v0 + rc) * DIM) + qq);
+        for (int m = 0; m < KMAX; m++) {  // unconditional loads (clamped index): all in flight together
+            const uint32_t mm = (uint32_t)m < k ? (uint32_t)m : k - 1u;
+            nbr_reg[m] = c.nbr[ib + mm];
+            pr_raw[m] = c.proba[ib + mm];
         }
-    } else {
-        ld(v, yv);
-    }
-    const float s_v = c.emb_scale[v];
+    };
+    // the wave's own 64 rows are contiguous in memory: for wide rows they are read (and written back, st_rows) as one
+    // coalesced block through the hand-over buffer -- 8 lines per instruction instead of one line per lane
+    auto own_loads = [&] {
+        if constexpr (COOP) {
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                const uint32_t e = (uint32_t)(i * 64 + lane), row = e / (uint32_t)G, qq = e % (uint32_t)G;
+                const uint32_t rc = row < (uint32_t)n_here ? row : (uint32_t)n_here - 1u;
+                own_raw[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)(v0 + rc) * DIM) + qq);
+            }
+        } else {
+            ld(v, yv);
+        }
+        s_v = c.emb_scale[v];
+    };
+    if constexpr (LATE_RECS) { row_loads(); own_loads(); }
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
     // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
     const uint64_t t_begin = a.tptr[v0], t_end = a.tptr[v0 + n_here];
@@ -240,11 +246,11 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
     // d >= 8: the kernel is at the register limit and the compiler parks the records in AGPRs as soon as they arrive, i.e.
     // it waits for them on the spot -- a second exposed round trip in front of stage A.  There the first records are
     // requested together with the gathers of the first chunk of stage B (one wait for both).
-    constexpr bool LATE_RECS = DIM >= 8;
     auto late_recs = [&] {
         if constexpr (LATE_RECS) { if (t_begin < t_end) load_recs(t_begin, recA); }
     };
     if constexpr (!LATE_RECS) { if (t_begin < t_end) load_recs(t_begin, recA); }
+    if constexpr (!LATE_RECS) row_loads();
     // ---- stage A: the node's row in registers (rejection test) and in an LDS column private to the lane
     // (dynamic index, no barrier needed), cumulative Poisson counts of the out-edges packed 4 per register
     uint32_t cumP[KP];
@@ -277,6 +283,7 @@ __global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    if constexpr (!LATE_RECS) own_loads();
     const float inv_s2 = rcp(s_v * s_v);
     if constexpr (COOP) {
 #pragma unroll
