@@ -43,15 +43,26 @@ def main():
         q = A.quality_estimate_from_edge_length(large, y, 6)
         return {"nb_without_match": q.nb_without_match, "mean_matches": q.mean_nbmatch, "median_ratio": q.median_ratio}
 
-    for name, mode in (("gpu_fast", A.AE_CE_HOGWILD), ("gpu_sequential", A.AE_CE_SEQUENTIAL)):
-        par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
-                               nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode)
-        emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
+    modes = (("gpu_fast", A.AE_CE_HOGWILD),) if os.environ.get("AE_FID_FAST_ONLY") else (("gpu_fast", A.AE_CE_HOGWILD), ("gpu_sequential", A.AE_CE_SEQUENTIAL))
+    hub = os.environ.get("AE_FID_HUB", "1") == "1"
+    rho = float(os.environ.get("AE_FID_RHO", "0.75"))
+    nbatch = int(os.environ.get("AE_FID_BATCH", "40"))
+    for name, mode in modes:
+        par = A.EmbedderParams(asked_dim=2, nb_grad_batch=nbatch, grad_factor=5, scale_rho=rho, beta=1.0, grad_step=1.0,
+                               nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=hub, ce_mode=mode)
+        if os.environ.get("AE_FID_FLAT"):
+            par.dmap_init = os.environ.get("AE_FID_FLAT") == "dmap"
+            emb = A.Embedder(large, par)
+        else:
+            emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
         t0 = time.perf_counter()
         emb.embed()
         dt = time.perf_counter() - t0
         ce = emb.get_cross_entropy()
         res["runs"][name] = dict(embed_s=dt, ce_before=ce[0], ce_after=ce[1], **quality(emb.get_embedded()))
+    if os.environ.get("AE_FID_FAST_ONLY") or os.environ.get("AE_FID_NO_ORACLE"):
+        print(json.dumps(res))
+        return
     sm, lg = small.get_neighbours(), large.get_neighbours()
     op = O.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
                           nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True)
