@@ -478,20 +478,43 @@ __global__ void svqb_scale_kernel(const double* __restrict__ evals, const double
     m[idx] = (lam > rel_tol * lmax && lam > 0.) ? evecs[idx] / sqrt(lam) : 0.;
 }
 
-__global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
-    // exact left-to-right f32 sum (the reference's iter().sum::<f32>() / fold order): the workgroup stages chunks in
-    // LDS with coalesced loads, lane 0 adds them in order, always 16 values ahead in registers (the add chain, not
-    // the LDS latency, sets the pace)
-    constexpr int CH = 4096;
-    __shared__ float buf[CH + 16];
-    float s = 0.f;
-    for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+__global__ void __launch_bounds__(1024) seq_sum_kernel(const float* __restrict__ x, uint64_t n, uint64_t stride, float* __restrict__ out) {
+    // exact left-to-right f32 sum (the reference's iter().sum::<f32>() / fold order): lane 0 adds the values in order out of
+    // LDS, always 16 values ahead in registers (the add chain, not the LDS latency, sets the pace), while waves 1..15 stage
+    // the NEXT chunk into the other buffer with all their loads in flight together -- the staging (one memory round trip
+    // per 256 values with the former 256-thread loop) was 3/4 of the time, not the chain
+    constexpr int CH = 6144, LOADERS = 960;
+    __shared__ __attribute__((aligned(16))) float buf[2][CH + 16];
+    const uint64_t nchunks = (n + CH - 1) / CH;
+    auto fill = [&](int b, uint64_t c) {  // threads 64..1023
+        const uint64_t c0 = c * CH;
         const uint32_t m = (uint32_t)((n - c0) < (uint64_t)CH ? (n - c0) : (uint64_t)CH);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < CH + 16; i += 256) buf[i] = i < m ? x[(c0 + i) * stride] : 0.f;
-        __syncthreads();
+        const uint32_t t = threadIdx.x - 64u;
+        if (stride == 1 && m == (uint32_t)CH && ((reinterpret_cast<uintptr_t>(x + c0) & 15u) == 0)) {
+            const float4* src = reinterpret_cast<const float4*>(x + c0);
+            float4 v[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) { const uint32_t j = t + (uint32_t)r * LOADERS; v[r] = j < CH / 4 ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int r = 0; r < 2; r++) { const uint32_t j = t + (uint32_t)r * LOADERS; if (j < CH / 4) reinterpret_cast<float4*>(buf[b])[j] = v[r]; }
+        } else {
+            float v[7];
+#pragma unroll
+            for (int r = 0; r < 7; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; v[r] = i < m ? x[(c0 + i) * stride] : 0.f; }
+#pragma unroll
+            for (int r = 0; r < 7; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; if (i < (uint32_t)CH) buf[b][i] = v[r]; }
+        }
+    };
+    if (threadIdx.x >= 64 && nchunks) fill(0, 0);
+    __syncthreads();
+    float s = 0.f;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        if (threadIdx.x >= 64 && c + 1 < nchunks) fill((int)((c + 1) & 1), c + 1);
         if (threadIdx.x == 0) {
-            const float4* b4 = reinterpret_cast<const float4*>(buf);
+            const uint64_t c0 = c * CH;
+            const uint32_t m = (uint32_t)((n - c0) < (uint64_t)CH ? (n - c0) : (uint64_t)CH);
+            const float* bb = buf[c & 1];
+            const float4* b4 = reinterpret_cast<const float4*>(bb);
             float4 a0 = b4[0], a1 = b4[1], a2 = b4[2], a3 = b4[3];
             uint32_t i = 0;
             for (; i + 16 <= m; i += 16) {
@@ -500,8 +523,9 @@ __global__ void __launch_bounds__(256) seq_sum_kernel(const float* __restrict__ 
                 s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w;
                 a0 = n0; a1 = n1; a2 = n2; a3 = n3;
             }
-            for (; i < m; i++) s += buf[i];
+            for (; i < m; i++) s += bb[i];
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0) *out = s;
 }
@@ -628,7 +652,7 @@ void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t 
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
     static DevBuf<float> out;
     if (!out.n) out.alloc(1);
-    hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(256), 0, stream(), d_x, n, stride, out.p);
+    hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(1024), 0, stream(), d_x, n, stride, out.p);
     check_launch("seq_sum");
     float h;
     out.download(&h, 1);
@@ -636,32 +660,57 @@ float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
 }
 // column sums of a row-major n x dim array, each column added in row order (the reference's `for i { means[j] += data[[i, j]] }`,
 // embedder.rs:1391-1394): dim independent sequential chains, one lane each, over LDS-staged row blocks
-__global__ void __launch_bounds__(256) seq_sum_cols_kernel(const float* __restrict__ x, uint64_t n, uint32_t dim, float* __restrict__ out) {
-    extern __shared__ float cbuf[];  // rows_per_chunk x dim
-    const uint32_t rpc = 4096u / dim;
-    float s = 0.f;
-    for (uint64_t r0 = 0; r0 < n; r0 += rpc) {
+__global__ void __launch_bounds__(1024) seq_sum_cols_kernel(const float* __restrict__ x, uint64_t n, uint32_t dim, float* __restrict__ out) {
+    // lanes 0..dim-1 add their column in row order out of LDS, 8 rows ahead in registers; threads 256..1023 stage the next
+    // row block into the other buffer meanwhile (all their loads in flight together)
+    extern __shared__ __attribute__((aligned(16))) float cbuf[];  // 2 x (rpc + 8) x dim
+    constexpr uint32_t CHF = 6144, LOADERS = 768;
+    const uint32_t rpc = CHF / dim, bstride = (rpc + 8u) * dim;
+    const uint64_t nchunks = (n + rpc - 1) / rpc;
+    auto fill = [&](int b, uint64_t c) {  // threads 256..1023
+        const uint64_t r0 = c * rpc;
         const uint32_t nr = (uint32_t)((n - r0) < (uint64_t)rpc ? (n - r0) : (uint64_t)rpc);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nr * dim; i += 256) cbuf[i] = x[r0 * dim + i];
-        __syncthreads();
+        const uint32_t t = threadIdx.x - 256u, cntf = nr * dim;
+        const float* src = x + r0 * dim;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; v[r] = i < cntf ? src[i] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; if (i < bstride) cbuf[(uint32_t)b * bstride + i] = v[r]; }
+    };
+    if (threadIdx.x >= 256 && nchunks) fill(0, 0);
+    __syncthreads();
+    float s = 0.f;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        if (threadIdx.x >= 256 && c + 1 < nchunks) fill((int)((c + 1) & 1), c + 1);
         if (threadIdx.x < dim) {
+            const uint64_t r0 = c * rpc;
+            const uint32_t nr = (uint32_t)((n - r0) < (uint64_t)rpc ? (n - r0) : (uint64_t)rpc);
+            const float* bb = cbuf + (uint32_t)(c & 1) * bstride + threadIdx.x;
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = bb[q * dim];
             uint32_t r = 0;
-            for (; r + 4 <= nr; r += 4) {
-                const float v0 = cbuf[r * dim + threadIdx.x], v1 = cbuf[(r + 1) * dim + threadIdx.x];
-                const float v2 = cbuf[(r + 2) * dim + threadIdx.x], v3 = cbuf[(r + 3) * dim + threadIdx.x];
-                s += v0; s += v1; s += v2; s += v3;
+            for (; r + 8 <= nr; r += 8) {
+                float nx[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) nx[q] = bb[(r + 8 + q) * dim];  // next 8 rows (padding rows past nr)
+#pragma unroll
+                for (int q = 0; q < 8; q++) s += a[q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = nx[q];
             }
-            for (; r < nr; r++) s += cbuf[r * dim + threadIdx.x];
+            for (; r < nr; r++) s += bb[r * dim];
         }
+        __syncthreads();
     }
     if (threadIdx.x < dim) out[threadIdx.x] = s;
 }
 void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_out) {
-    if (dim == 0 || dim > 256) fail(AE_ERR_INVALID_ARG, "seq_sum_cols: dimension %u unsupported", dim);
+    if (dim == 0 || dim > 128) fail(AE_ERR_INVALID_ARG, "seq_sum_cols: dimension %u unsupported", dim);
     DevBuf<float> out;
     out.alloc_pooled(dim);
-    hipLaunchKernelGGL(seq_sum_cols_kernel, dim3(1), dim3(256), sizeof(float) * (4096u / dim) * dim, stream(), d_x, n, dim, out.p);
+    hipLaunchKernelGGL(seq_sum_cols_kernel, dim3(1), dim3(1024), sizeof(float) * 2u * (6144u / dim + 8u) * dim, stream(), d_x, n, dim, out.p);
     check_launch("seq_sum_cols");
     out.download(host_out, dim);
 }
