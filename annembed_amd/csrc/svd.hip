@@ -515,14 +515,24 @@ __global__ void __launch_bounds__(1024) seq_sum_kernel(const float* __restrict__
             const uint32_t m = (uint32_t)((n - c0) < (uint64_t)CH ? (n - c0) : (uint64_t)CH);
             const float* bb = buf[c & 1];
             const float4* b4 = reinterpret_cast<const float4*>(bb);
-            float4 a0 = b4[0], a1 = b4[1], a2 = b4[2], a3 = b4[3];
+            // two register sets in turn (no copies: the compiler would fold a copied "next" set back into a load at the
+            // top of the trip and wait for it there); the scheduling barriers keep each set's loads ahead of the other's adds
+            float4 a0 = b4[0], a1 = b4[1], a2 = b4[2], a3 = b4[3], c0_, c1_, c2_, c3_;
+#define AE_ADD16(p0, p1, p2, p3) s += p0.x; s += p0.y; s += p0.z; s += p0.w; s += p1.x; s += p1.y; s += p1.z; s += p1.w; \
+                                 s += p2.x; s += p2.y; s += p2.z; s += p2.w; s += p3.x; s += p3.y; s += p3.z; s += p3.w;
             uint32_t i = 0;
-            for (; i + 16 <= m; i += 16) {
-                const float4 n0 = b4[i / 4 + 4], n1 = b4[i / 4 + 5], n2 = b4[i / 4 + 6], n3 = b4[i / 4 + 7];  // next 16 (padding past m)
-                s += a0.x; s += a0.y; s += a0.z; s += a0.w; s += a1.x; s += a1.y; s += a1.z; s += a1.w;
-                s += a2.x; s += a2.y; s += a2.z; s += a2.w; s += a3.x; s += a3.y; s += a3.z; s += a3.w;
-                a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            for (; i + 32 <= m; i += 32) {
+                c0_ = b4[i / 4 + 4]; c1_ = b4[i / 4 + 5]; c2_ = b4[i / 4 + 6]; c3_ = b4[i / 4 + 7];
+                __builtin_amdgcn_sched_barrier(0);
+                AE_ADD16(a0, a1, a2, a3)
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = b4[i / 4 + 8]; a1 = b4[i / 4 + 9]; a2 = b4[i / 4 + 10]; a3 = b4[i / 4 + 11];  // (padding past m)
+                __builtin_amdgcn_sched_barrier(0);
+                AE_ADD16(c0_, c1_, c2_, c3_)
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (i + 16 <= m) { AE_ADD16(a0, a1, a2, a3) i += 16; }
+#undef AE_ADD16
             for (; i < m; i++) s += bb[i];
         }
         __syncthreads();
@@ -687,18 +697,28 @@ __global__ void __launch_bounds__(1024) seq_sum_cols_kernel(const float* __restr
             const uint64_t r0 = c * rpc;
             const uint32_t nr = (uint32_t)((n - r0) < (uint64_t)rpc ? (n - r0) : (uint64_t)rpc);
             const float* bb = cbuf + (uint32_t)(c & 1) * bstride + threadIdx.x;
-            float a[8];
+            float a[8], b2[8];  // two register sets in turn (see seq_sum_kernel)
 #pragma unroll
             for (int q = 0; q < 8; q++) a[q] = bb[q * dim];
             uint32_t r = 0;
-            for (; r + 8 <= nr; r += 8) {
-                float nx[8];
+            for (; r + 16 <= nr; r += 16) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) nx[q] = bb[(r + 8 + q) * dim];  // next 8 rows (padding rows past nr)
+                for (int q = 0; q < 8; q++) b2[q] = bb[(r + 8 + q) * dim];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 8; q++) s += a[q];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 8; q++) a[q] = nx[q];
+                for (int q = 0; q < 8; q++) a[q] = bb[(r + 16 + q) * dim];  // (padding rows past nr)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 8; q++) s += b2[q];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (r + 8 <= nr) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) s += a[q];
+                r += 8;
             }
             for (; r < nr; r++) s += bb[r * dim];
         }
