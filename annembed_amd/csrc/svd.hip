@@ -543,25 +543,42 @@ __global__ void __launch_bounds__(1024) seq_sum_kernel(const float* __restrict__
 // ndarray's Array1::sum() order (numeric_util::unrolled_fold: eight interleaved accumulators, then
 // ((p0+p4) + (p1+p5)) ... and the tail), used by the reference for q.sum() (diffmaps.rs:469, :546, :889, :932).
 // Eight lanes run the eight chains.
-__global__ void __launch_bounds__(256) ndarray_sum_kernel(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
-    constexpr int CH = 4096;
-    __shared__ float buf[CH];
+__global__ void __launch_bounds__(1024) ndarray_sum_kernel(const float* __restrict__ x, uint64_t n, float* __restrict__ out) {
+    constexpr int CH = 6144, LOADERS = 960;  // staging by waves 1..15 into the other buffer while the eight lanes add (see seq_sum_kernel)
+    __shared__ float buf[2][CH];
     __shared__ float p8[8];
     float p = 0.f;
     const uint64_t n8 = n & ~7ull;
-    for (uint64_t c0 = 0; c0 < n8; c0 += CH) {
+    const uint64_t nchunks = (n8 + CH - 1) / CH;
+    auto fill = [&](int b, uint64_t c) {  // threads 64..1023
+        const uint64_t c0 = c * CH;
         const uint32_t m = (uint32_t)((n8 - c0) < (uint64_t)CH ? (n8 - c0) : (uint64_t)CH);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m; i += 256) buf[i] = x[c0 + i];
-        __syncthreads();
+        const uint32_t t = threadIdx.x - 64u;
+        float v[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; v[r] = i < m ? x[c0 + i] : 0.f; }
+#pragma unroll
+        for (int r = 0; r < 7; r++) { const uint32_t i = t + (uint32_t)r * LOADERS; if (i < (uint32_t)CH) buf[b][i] = v[r]; }
+    };
+    if (threadIdx.x >= 64 && nchunks) fill(0, 0);
+    __syncthreads();
+    for (uint64_t c = 0; c < nchunks; c++) {
+        if (threadIdx.x >= 64 && c + 1 < nchunks) fill((int)((c + 1) & 1), c + 1);
         if (threadIdx.x < 8) {
+            const uint64_t c0 = c * CH;
+            const uint32_t m = (uint32_t)((n8 - c0) < (uint64_t)CH ? (n8 - c0) : (uint64_t)CH);
+            const float* bb = buf[c & 1];
             uint32_t i = threadIdx.x;
-            for (; i + 24 < m; i += 32) {
-                const float v0 = buf[i], v1 = buf[i + 8], v2 = buf[i + 16], v3 = buf[i + 24];
-                p += v0; p += v1; p += v2; p += v3;
+            for (; i + 56 < m; i += 64) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = bb[i + 8 * q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) p += v[q];
             }
-            for (; i < m; i += 8) p += buf[i];
+            for (; i < m; i += 8) p += bb[i];
         }
+        __syncthreads();
     }
     if (threadIdx.x < 8) p8[threadIdx.x] = p;
     __syncthreads();
@@ -738,7 +755,7 @@ void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_ou
 float ndarray_sum_f32(const float* d_x, uint64_t n) {
     static DevBuf<float> out;
     if (!out.n) out.alloc(1);
-    hipLaunchKernelGGL(ndarray_sum_kernel, dim3(1), dim3(256), 0, stream(), d_x, n, out.p);
+    hipLaunchKernelGGL(ndarray_sum_kernel, dim3(1), dim3(1024), 0, stream(), d_x, n, out.p);
     check_launch("ndarray_sum");
     float h = 0.f;
     out.download(&h, 1);
