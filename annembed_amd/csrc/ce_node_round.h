@@ -112,7 +112,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 template <int DIM, bool PAD, bool B1, int KMAX>
-__global__ void __launch_bounds__(64) ce_round_node_kernel(NodeArgs a) {
+__global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(NodeArgs a) {  // d = 8: two waves per SIMD (10 registers spilled; the kernel otherwise lands on 267 registers, i.e. one wave, and the C4 shape is latency-bound)
     using Cfg = NodeKernelCfg<DIM>;
     constexpr int LS = 65, S = Cfg::S, CH = Cfg::CH, NQ = Cfg::NQ, EC = Cfg::EC, KP = KMAX / 4;
     __shared__ uint32_t s_nbr[KMAX * LS];
