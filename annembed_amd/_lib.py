@@ -24,6 +24,7 @@ AE_ERR_OOM = 10
 AE_CE_HOGWILD = 0
 AE_CE_SEQUENTIAL = 1
 AE_CE_SAMPLE_RACY = 2
+AE_CE_EVENT = 3
 AE_SAMPLER_ROWCDF = 0
 AE_SAMPLER_ALIAS = 1
 

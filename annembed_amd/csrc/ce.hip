@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "ce_internal.h"
+#include "ce_sample_math.h"
 #include <chrono>
 #include "philox.h"
 
@@ -196,67 +197,6 @@ __device__ __forceinline__ void store_row(float* __restrict__ y, uint32_t node, 
     }
 }
 
-// common part of the gradient coefficient, embedder.rs:1216-1222 / :1275-1281
-__device__ __forceinline__ double grad_coeff(double d_scaled, double scale, double b) {
-    if (b != 1.) {
-        double cw = 1. / (1. + pow(d_scaled, b));
-        return 2. * b * cw * pow(d_scaled, b - 1.) / (scale * scale);
-    }
-    double cw = 1. / (1. + d_scaled);
-    return 2. * b * cw / (scale * scale);
-}
-
-// ce_optim_edge_shannon, embedder.rs:1167-1302, one sample, on rows held in registers, in its two kinds of steps:
-// the attraction along the sampled edge (updates y_i and y_j, :1207-1238) ...
-template <int DIM>
-__device__ __forceinline__ void sample_attract(float* yi, float* yj, float* grad, float w, double scale, double b, double grad_step) {
-#pragma unroll
-    for (int t = 0; t < DIM; t++) grad[t] = 0.f;  // :1199
-    const double weight = (double)w;                // :1202
-    float acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < DIM; t++) {  // :1207-1211
-        float df = yi[t] - yj[t];
-        acc += df * df;
-    }
-    const double d_ij_scaled = (double)acc / (scale * scale);  // :1214
-    const double coeff = grad_coeff(d_ij_scaled, scale, b);
-    if (d_ij_scaled > 0.) {  // :1223-1236
-        const double alfa = (double)(1.0f / kProbaMin);
-        const double coeff_repulsion = 1. / fmax(d_ij_scaled * d_ij_scaled, alfa);
-        const double coeff_ij = fmax(grad_step * coeff * (-weight + (1. - weight) * coeff_repulsion), -0.49);
-        const float cf = (float)coeff_ij;
-#pragma unroll
-        for (int t = 0; t < DIM; t++) grad[t] = (yj[t] - yi[t]) * cf;
-    }
-#pragma unroll
-    for (int t = 0; t < DIM; t++) {  // :1237-1238
-        yi[t] -= grad[t];
-        yj[t] += grad[t];
-    }
-}
-// ... and one repulsion from a negative sample (updates y_i only, :1267-1297; `grad` carries over, see the quirk below)
-template <int DIM>
-__device__ __forceinline__ void sample_repulse(float* yi, const float* yk, float* grad, double scale, double b, double grad_step) {
-    float ak = 0.f;
-#pragma unroll
-    for (int t = 0; t < DIM; t++) {  // :1267-1271
-        float df = yi[t] - yk[t];
-        ak += df * df;
-    }
-    const double d_ik = (double)ak;
-    const double d_ik_scaled = d_ik / (scale * scale);  // :1274
-    const double cf2 = grad_coeff(d_ik_scaled, scale, b);
-    if (d_ik > 0.) {  // :1286-1295
-        const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
-        const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
-        const float cf = (float)coeff_ik;
-#pragma unroll
-        for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
-    }  // else: `gradient` keeps its previous value, as in the reference
-#pragma unroll
-    for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
-}
 // the whole sample: yi / yj are updated in place (the values the reference stores at :1301 / :1239)
 template <int DIM>
 __device__ __forceinline__ void sample_update(float* yi, float* yj, const float (*yk)[DIM], float w, double scale, double b, double grad_step) {
@@ -461,45 +401,6 @@ __global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nod
 // A version row is published by its stores alone: the buffer is filled with an all-ones pattern (a NaN no arithmetic
 // produces: hardware NaNs are the canonical 0x7FC00000) before the kernel, a reader polls the row itself and takes it
 // once every part differs from the pattern -- one memory round trip per dependency hop instead of flag + data.
-constexpr uint64_t kUnpublished64 = ~0ull;
-constexpr uint32_t kUnpublished32 = ~0u;
-template <int DIM>
-__device__ __forceinline__ bool df_try_load_version(const float* __restrict__ ver, uint32_t pv, float* out) {
-    const float* p = ver + (uint64_t)pv * DIM;  // version index = sample * 2 + slot
-    bool ok = true;
-    if constexpr (DIM % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 2; q++) {
-            const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= bits != kUnpublished64;
-            out[2 * q] = __uint_as_float((uint32_t)bits);
-            out[2 * q + 1] = __uint_as_float((uint32_t)(bits >> 32));
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) {
-            const uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= bits != kUnpublished32;
-            out[t] = __uint_as_float(bits);
-        }
-    }
-    return ok;
-}
-template <int DIM>
-__device__ __forceinline__ void df_store_version(float* __restrict__ ver, uint64_t v, const float* in) {
-    float* p = ver + v * DIM;
-    if constexpr (DIM % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 2; q++) {
-            const uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 template <int DIM>
 __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
                                                           const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
@@ -699,6 +600,9 @@ static void launch_planned(ae_entropy_optim* o, const uint32_t* order, uint64_t 
 static void check_err_flag(ae_entropy_optim* o) {
     unsigned int h = 0;
     o->err.download(&h, 1);
+    if (h) { o->err.zero(); }  // reported once: the flag does not poison later calls on the handle
+    if (h & 16u) fail(AE_ERR_STATE, "event-ordered kernel: a wave's event lists exceeded its LDS pool (window sizing violated)");
+    if (h & 32u) fail(AE_ERR_STATE, "event-ordered kernel: poll budget exceeded (a lane's partner never arrived: scheduling invariant violated)");
     if (h & 2u) fail(AE_ERR_INVALID_ARG, "sample plan capacity exceeded (edge probabilities of a row sum to more than 1?)");
     if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
 }
@@ -948,6 +852,7 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         }
         sync();
         if (params->ce_mode != AE_CE_SEQUENTIAL) ce_node_build_transpose(o.get());
+        if (params->ce_mode == AE_CE_EVENT) ce_event_prepare(o.get());
         return o.release();
     }
 }
@@ -1001,6 +906,12 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         AE_HIP(hipEventCreate(&e0));
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
+        if (o->params.ce_mode == AE_CE_EVENT) {
+            ce_event_gradient_iteration(o, nb_sample, grad_step, (uint32_t)iter);
+            AE_HIP(hipEventRecord(e1, stream()));
+            o->events.emplace_back(e0, e1);
+            return;
+        }
         if (o->params.ce_mode != AE_CE_SAMPLE_RACY && !ce_node_supports(o))
             fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
         if (o->params.ce_mode == AE_CE_SAMPLE_RACY) {

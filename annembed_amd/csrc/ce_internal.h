@@ -75,6 +75,11 @@ struct ae_entropy_optim {
     DevBuf<uint8_t> cnt;     // per-edge sample counts of the current round
     DevBuf<uint32_t> tot;    // per-node planned out-samples
     DevBuf<uint32_t> plan;   // per-node sample plans (cap slots x 6 words)
+    // event-ordered mode (ce_event.hip): graph statistics that size the windows, rendezvous slots
+    float ev_wave_rate_max = 0.f, ev_node_rate_max = 0.f, ev_pmax = 0.f;
+    uint32_t ev_indeg_max = 0;
+    uint64_t ev_resident_blocks = 0;
+    DevBuf<float> ev_slots;
     ~ae_entropy_optim() {
         for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
@@ -85,4 +90,8 @@ namespace ae {
 bool ce_node_supports(const ae_entropy_optim* o);
 void ce_node_build_transpose(ae_entropy_optim* o);
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
+// event-ordered batch (ce_event.hip): sequentially consistent attraction steps in an i.i.d. order, `rounds` = windows
+void ce_event_prepare(ae_entropy_optim* o);
+const char* ce_event_unsupported(const ae_entropy_optim* o);
+void ce_event_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
 }  // namespace ae

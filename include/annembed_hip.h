@@ -86,21 +86,28 @@ typedef struct ae_embedder_params {
 } ae_embedder_params;
 
 enum {
-    /* Lock-free asynchronous updates, the counterpart of the reference's rayon loop
-       (src/embedder.rs:1311-1315, "Hogwild" comment :1197), restructured owner-computes: thread v owns
-       y_v and replays the samples whose source or target is v; per-edge sample counts are Poisson with
-       the means of the reference's i.i.d. edge draw.  Fast path; f32 arithmetic; the schedule is not
-       reproducible run to run (neither is the reference's).  Dimensions 2,3,4,8,16; other dimensions
-       fall back to AE_CE_SAMPLE_RACY. */
+    /* Owner-computes ROUNDS (ce_node.hip): thread v owns y_v and replays, round by round, the samples whose source or
+       target is v against the other rows as they were when the round started; per-edge sample counts are Poisson with
+       the means of the reference's i.i.d. edge draw.  f32 arithmetic.  A throughput mode: it is NOT inside the
+       reference's own run-to-run envelope (stale partner rows change what the stiff attraction step converges to: final
+       cross entropy 0.6-0.9x the sequential loop's).  asked_dim <= 32 and rows of <= 32 neighbours
+       (longer rows: asked_dim in {2,3,4,8,16}); anything else fails with AE_ERR_INVALID_ARG. */
     AE_CE_HOGWILD = 0,
-    /* Deterministic: executes exactly the sequential order sample 0,1,2,... of the reference's
-       `gradient_iteration` (src/embedder.rs:1305-1309) through a conflict-free level schedule.
-       Bit-exact against the CPU oracle; slow; meant for parity tests. */
+    /* Deterministic: the result of executing samples 0,1,2,... of the reference's `gradient_iteration`
+       (src/embedder.rs:1305-1309) in order, obtained by a device-side dataflow over row versions.  Bit-exact against the
+       CPU oracle; the parity mode. */
     AE_CE_SEQUENTIAL = 1,
     /* One thread per sample with racy read-modify-write of both end points, the literal transcription
        of the rayon loop.  Kept for comparison only: on a GPU with more lanes than nodes most updates are
        lost, it is NOT statistically equivalent to the reference at small N. */
-    AE_CE_SAMPLE_RACY = 2
+    AE_CE_SAMPLE_RACY = 2,
+    /* Event-ordered (ce_event.hip), the counterpart of the reference's rayon loop (src/embedder.rs:1311-1315): every
+       sample is applied to the current rows of both its end points with ONE gradient (embedder.rs:1228-1239), in an
+       i.i.d. random order, the reference's f64 scalar arithmetic -- a sequentially consistent execution; only the five
+       negatives' rows are read unsynchronised.  Not reproducible sample by sample (neither is the reference); its
+       statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
+       at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
+    AE_CE_EVENT = 3
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
