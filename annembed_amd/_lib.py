@@ -25,6 +25,7 @@ AE_CE_HOGWILD = 0
 AE_CE_SEQUENTIAL = 1
 AE_CE_SAMPLE_RACY = 2
 AE_CE_EVENT = 3
+AE_CE_AUTO = 4
 AE_SAMPLER_ROWCDF = 0
 AE_SAMPLER_ALIAS = 1
 
@@ -115,6 +116,7 @@ SIGNATURES = {
     "ae_entropy_optim_create": [_vp, _vp, _P(CEmbedderParams), _vp, _vp, _u64, _u64, _P(_vp)],
     "ae_entropy_optim_destroy": [_vp],
     "ae_entropy_optim_get_nb_edges": [_vp, _P(_u64)],
+    "ae_entropy_optim_get_ce_mode": [_vp, _P(C.c_uint32)],
     "ae_entropy_optim_ce": [_vp, _P(_f64)],
     "ae_entropy_optim_gradient_iteration": [_vp, _u64, _f64, _u64],
     "ae_entropy_optim_plan": [_vp, _u64, _u64, _u64, _vp, _vp],

@@ -302,6 +302,11 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_get_nb_edges(self._h, C.byref(v)))
         return v.value
 
+    def get_ce_mode(self):
+        v = C.c_uint32()
+        check(L.load().ae_entropy_optim_get_ce_mode(self._h, C.byref(v)))
+        return v.value
+
     def ce_compute_threaded(self):
         v = C.c_double()
         check(L.load().ae_entropy_optim_ce(self._h, C.byref(v)))

@@ -851,8 +851,22 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
             d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
         }
         sync();
-        if (params->ce_mode != AE_CE_SEQUENTIAL) ce_node_build_transpose(o.get());
-        if (params->ce_mode == AE_CE_EVENT) ce_event_prepare(o.get());
+        // AE_CE_AUTO: the faithful mode that fits -- event-ordered, else sequential-equivalent, else (sharded range, other
+        // dimensions) the rounds mode
+        const bool sharded = node_lo != 0 || node_hi != n;
+        const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
+        uint32_t mode = params->ce_mode;
+        if (mode > AE_CE_AUTO) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
+        if (mode == AE_CE_AUTO && (sharded || !df_dim)) mode = AE_CE_HOGWILD;
+        if (mode == AE_CE_AUTO || mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
+        if (mode == AE_CE_AUTO || mode == AE_CE_EVENT) {
+            ce_event_prepare(o.get());
+            if (mode == AE_CE_AUTO) {
+                mode = ce_event_unsupported(o.get()) ? AE_CE_SEQUENTIAL : AE_CE_EVENT;
+                if (mode == AE_CE_SEQUENTIAL && params->nb_sampling_by_edge * (edge_hi - edge_lo) >= (1ull << 31)) mode = AE_CE_HOGWILD;
+            }
+        }
+        o->params.ce_mode = mode;
         return o.release();
     }
 }
@@ -874,6 +888,13 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim* o, uint64_t* nnz) 
     return guard([&] {
         if (!o || !nnz) fail(AE_ERR_INVALID_ARG, "null argument");
         *nnz = o->dev.shard_edges;
+    });
+}
+
+int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim* o, uint32_t* ce_mode) {
+    return guard([&] {
+        if (!o || !ce_mode) fail(AE_ERR_INVALID_ARG, "null argument");
+        *ce_mode = o->params.ce_mode;
     });
 }
 

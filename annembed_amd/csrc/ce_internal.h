@@ -76,8 +76,9 @@ struct ae_entropy_optim {
     DevBuf<uint32_t> tot;    // per-node planned out-samples
     DevBuf<uint32_t> plan;   // per-node sample plans (cap slots x 6 words)
     // event-ordered mode (ce_event.hip): graph statistics that size the windows, rendezvous slots
-    float ev_wave_rate_max = 0.f, ev_node_rate_max = 0.f, ev_pmax = 0.f;
+    float ev_wave_rate_max[3] = {0.f, 0.f, 0.f}, ev_node_rate_max = 0.f, ev_pmax = 0.f;  // waves of 64 / 32 / 16 nodes
     uint32_t ev_indeg_max = 0;
+    int ev_npw = 0;  // nodes per wave
     uint64_t ev_resident_blocks = 0;
     DevBuf<float> ev_slots;
     ~ae_entropy_optim() {

@@ -354,7 +354,7 @@ int32_t ae_embedder_params_default(ae_embedder_params* p) {
         p->hierarchy_layer = 0;
         p->hubness_weighting = 0;
         p->seed = kDefaultSeed;
-        p->ce_mode = AE_CE_HOGWILD;
+        p->ce_mode = AE_CE_AUTO;
         p->ce_sampler = AE_SAMPLER_ROWCDF;
     });
 }

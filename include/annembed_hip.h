@@ -81,7 +81,7 @@ typedef struct ae_embedder_params {
     /* ---- build extras (no reference counterpart: the reference draws from an unseeded
      * thread RNG, src/embedder.rs:1121,1182) ---- */
     uint64_t seed;      /* Philox key for every random draw of the embedding. default 4664397  */
-    uint32_t ce_mode;   /* AE_CE_* below. default AE_CE_HOGWILD                                 */
+    uint32_t ce_mode;   /* AE_CE_* below. default AE_CE_AUTO                                    */
     uint32_t ce_sampler; /* AE_SAMPLER_* below. default AE_SAMPLER_ROWCDF                       */
 } ae_embedder_params;
 
@@ -107,7 +107,11 @@ enum {
        negatives' rows are read unsynchronised.  Not reproducible sample by sample (neither is the reference); its
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
-    AE_CE_EVENT = 3
+    AE_CE_EVENT = 3,
+    /* Default.  The faithful mode that fits the problem: AE_CE_EVENT when it supports it, else AE_CE_SEQUENTIAL
+       (asked_dim in {2,3,4,8,16}, < 2^31 samples per batch), else -- and for a sharded node range, i.e. several GPUs --
+       AE_CE_HOGWILD.  ae_entropy_optim_get_ce_mode reports the choice. */
+    AE_CE_AUTO = 4
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
@@ -309,6 +313,8 @@ int32_t ae_entropy_optim_create(const ae_kgraph *g, const ae_node_params *np,
                                 ae_entropy_optim **out);
 int32_t ae_entropy_optim_destroy(ae_entropy_optim *o);
 int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz); /* :1027 */
+/* the AE_CE_* mode the handle runs (AE_CE_AUTO resolved at create) */
+int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim *o, uint32_t *ce_mode);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);
 /* gradient_iteration_threaded(nb_sample, grad_step) (embedder.rs:1311-1315).  `iter` keys the RNG

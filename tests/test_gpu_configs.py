@@ -1,0 +1,192 @@
+"""GPU tests at the sizes of BASELINE.json's configs (run with -m gpu on an MI355X): the default CE mode (AE_CE_AUTO ->
+the event-ordered kernel where it fits) against AE_CE_SEQUENTIAL -- which is bit-exact against the oracle's sequential
+loop (test_gpu_parity.py) and fast enough to be the reference at 60 k nodes -- on the full schedules of the reference's
+examples, and size-independent properties where a second run is not affordable.
+
+Tolerances: the sequential loop's own seed-to-seed spread at these sizes was measured at 1 % (final CE) and 2-4 % (edge
+length quantiles); the bars below are 3 % / 5 % unless a comment says otherwise."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import annembed_amd as A
+    from annembed_amd import _lib
+    _lib.load()
+    return A
+
+
+def _edge_q(indptr, nbr, y, qs=(0.25, 0.5, 0.75)):
+    src = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr.astype(np.int64)))
+    return np.quantile(np.linalg.norm(y[src] - y[nbr], axis=1), qs)
+
+
+def _blobs(n, dim=28, ncomp=64, seed=2):
+    rng = np.random.default_rng(seed)
+    means = rng.normal(size=(ncomp, dim)) * 2.0
+    scales = 0.5 + rng.random((ncomp, dim))
+    lab = rng.integers(0, ncomp, n)
+    x = means[lab] + scales[lab] * rng.normal(size=(n, dim))
+    x = (x - x.mean(0)) / x.std(0)
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+def _mnist_shaped_graph(A, n, k):
+    import bench
+    x = bench.synth_points(n, 784, seed=1)
+    nb_t, ds_t = bench.knn_rows(x, 0, n, k)
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    nbr, dist = nb_t.cpu().numpy().astype(np.uint32).reshape(-1), ds_t.cpu().numpy().reshape(-1)
+    return A.KGraph(indptr, nbr, dist, k), indptr, nbr
+
+
+def _run_ce(A, g, npar, y0, nb_batch, mode, seed=4664397, hub=None):
+    par = A.EmbedderParams(nb_grad_batch=nb_batch, ce_mode=mode, seed=seed, hubness_weighting=hub is not None, grad_step=1.0)
+    eo = A.EntropyOptim(g, npar, par, y0, hub_counts=hub)
+    S = 10 * eo.get_nb_edges()
+    for it in range(1, nb_batch + 1):
+        eo.gradient_iteration_threaded(S, 1.0 * (1 - it / nb_batch), it)
+    return eo.get_embedded(), eo.ce_compute_threaded(), eo
+
+
+def _assert_close(A, indptr, nbr, run, ref, tol_ce=0.03, tol_q=0.05):
+    (y, ce, _), (yr, cer, _) = run, ref
+    assert np.isfinite(y).all()
+    assert abs(ce - cer) < tol_ce * cer, (ce, cer)
+    q, qr = _edge_q(indptr, nbr, y), _edge_q(indptr, nbr, yr)
+    assert np.all(np.abs(q - qr) < tol_q * qr), (q, qr)
+
+
+def test_k6_blobs_without_hubness_40_batches(A):
+    """The case the rounds mode misses by 28 % (final CE 0.72x, median edge 1.76x: 60 k points of 28-d blobs, k = 6,
+    scale_rho 0.75, no hubness weighting, 40 batches from a random initialisation).  Event-ordered vs sequential:
+    measured CE +0.8 %, quartiles -1 ... -2 %."""
+    n = 60000
+    g = A.KGraph.bruteforce_l2(_blobs(n), 6)
+    indptr, nbr, _ = g.get_neighbours()
+    npar = A.to_proba_edges(g, 0.75, 1.0)
+    y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
+    ref = _run_ce(A, g, npar, y0, 40, A.AE_CE_SEQUENTIAL)
+    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_AUTO)
+    assert run[2].get_ce_mode() == A.AE_CE_EVENT
+    _assert_close(A, indptr, nbr, run, ref)
+    rounds = _run_ce(A, g, npar, y0, 40, A.AE_CE_HOGWILD)  # evidence: the rounds mode is outside the envelope here
+    assert rounds[1] < 0.85 * ref[1]
+
+
+@pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])
+def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
+    """configs[0] / configs[1] shapes -- 60 000 x 784 MNIST-shaped points, k = 6 / 30 batches (examples/mnist_digits.rs:92-109)
+    and k = 12 / 25 batches (examples/mnist_fashion.rs:92-110): Embedder::embed() with the default parameters' mode against
+    the same call in sequential mode (same dmap initialisation, checked equal)."""
+    g, indptr, nbr = _mnist_shaped_graph(A, 60000, k)
+    out = {}
+    for name, mode in (("seq", A.AE_CE_SEQUENTIAL), ("auto", A.AE_CE_AUTO)):
+        par = A.EmbedderParams(nb_grad_batch=nb_batch, scale_rho=1.0, beta=1.0, grad_step=1.0, nb_sampling_by_edge=10, dmap_init=True,
+                               hubness_weighting=False, ce_mode=mode)
+        e = A.Embedder(g, par)
+        assert e.embed() == 1
+        out[name] = (e.get_embedded(), e.get_cross_entropy()[1], e.get_initial_embedding())
+    assert np.array_equal(out["seq"][2], out["auto"][2])
+    assert abs(np.abs(out["auto"][2]).max() - 5.0) < 1e-4
+    _assert_close(A, indptr, nbr, out["auto"][:2] + (None,), out["seq"][:2] + (None,))
+
+
+def test_c3_schedule_hierarchical_60k(A):
+    """configs[2] schedule (examples/higgs.rs:204-242: hierarchical, grad_factor 5 x 40 batches on the small graph, 40 on the
+    large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: default mode vs sequential."""
+    n, k = 60000, 6
+    x = _blobs(n)
+    n_small = n // 24
+    large, small = A.KGraph.bruteforce_l2(x, k), A.KGraph.bruteforce_l2(x[:n_small], k)
+    x64 = x.astype(np.float64)
+    dd = (x64 ** 2).sum(1)[:, None] + (x64[:n_small] ** 2).sum(1)[None, :] - 2 * x64 @ x64[:n_small].T
+    pn = dd.argmin(1).astype(np.uint32)
+    pd = np.sqrt(np.maximum(dd.min(1), 0)).astype(np.float32)
+    pn[:n_small] = np.arange(n_small)
+    pd[:n_small] = 0
+    indptr, nbr, _ = large.get_neighbours()
+    out = {}
+    for name, mode in (("seq", A.AE_CE_SEQUENTIAL), ("auto", A.AE_CE_AUTO)):
+        par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
+                               nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode)
+        emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
+        assert emb.embed() == 1
+        out[name] = (emb.get_embedded(), emb.get_cross_entropy()[1], None)
+    # two stages of stochastic optimisation: the small graph's end state is the large one's start (5 % / 8 %)
+    _assert_close(A, indptr, nbr, out["auto"], out["seq"], tol_ce=0.05, tol_q=0.08)
+
+
+def test_c3_full_size_properties(A):
+    """configs[2] at full size: 1 650 000 x 28 Higgs-shaped points, k = 6, hierarchical (small graph = first n / 24 points),
+    through Embedder.from_hkgraph(...).embed() with the default mode (event-ordered on the 68 750-node small graph, the
+    sequential-equivalent dataflow on the 1.65 M-node one).  Size-independent properties: finite, centred initial box,
+    embedding inside the reference's clipping envelope, CE reported for both ends."""
+    import torch
+    n, k = 1650000, 6
+    x = _blobs(n)
+    n_small = n // 24
+    large, small = A.KGraph.bruteforce_l2(x, k), A.KGraph.bruteforce_l2(x[:n_small], k)
+    xt = torch.from_numpy(x).cuda()
+    xs = xt[:n_small]
+    sq_s = (xs * xs).sum(1)
+    pn = torch.empty(n, dtype=torch.int64, device="cuda")
+    pd = torch.empty(n, dtype=torch.float32, device="cuda")
+    for b in range(0, n, 65536):
+        e = min(b + 65536, n)
+        d2 = (xt[b:e] * xt[b:e]).sum(1)[:, None] + sq_s[None, :] - 2.0 * (xt[b:e] @ xs.T)
+        v, i = d2.min(1)
+        pn[b:e], pd[b:e] = i, v.clamp_min(0).sqrt()
+    pn[:n_small] = torch.arange(n_small, device="cuda")
+    pd[:n_small] = 0
+    pn_h, pd_h = pn.cpu().numpy().astype(np.uint32), pd.cpu().numpy()
+    del xt, xs, pn, pd
+    torch.cuda.empty_cache()
+    par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
+                           nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True)
+    emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn_h, pd_h), par)
+    assert emb.embed() == 1
+    y, y0 = emb.get_embedded(), emb.get_initial_embedding()
+    assert y.shape == (n, 2) and np.isfinite(y).all() and np.isfinite(y0).all()
+    assert np.max(np.abs(y0[n_small:] - y0[pn_h[n_small:]])) <= 2.0 + 1e-5  # projected points start within clip(., 2) of their projection (embedder.rs:265)
+    b, a = emb.get_cross_entropy()
+    assert np.isfinite(b) and np.isfinite(a) and a > 0
+    assert np.abs(y).max() < 1e3  # no blow-up: every step is clipped (c in [-0.49, 2], embedder.rs:1233,1293)
+
+
+def test_c4_shape_single_gpu_properties(A):
+    """configs[3] shape on ONE GPU: 11 M nodes, k = 6, asked_dim 8, on a ring-lattice graph whose node ids are randomly
+    PERMUTED (positive edges are not memory-local).  The event-ordered kernel says it does not fit; AE_CE_AUTO resolves to
+    the sequential-equivalent dataflow; one batch of the rounds mode (660 M samples) keeps its invariants: samples drawn
+    within 6 sigma of nb_sample, finite rows, every row moved, the box stays bounded."""
+    n, k, d = 11_000_000, 6, 8
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n).astype(np.int64)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    base = inv  # lattice position of every node id
+    cols = [perm[(base + o) % n] for o in (1, 2, 3)] + [perm[(base - o) % n] for o in (1, 2, 3)]
+    nbr = np.stack(cols, 1).astype(np.uint32).reshape(-1)
+    dist = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1).reshape(-1)
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    g = A.KGraph(indptr, nbr, dist, k)
+    del cols, perm, inv
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(rng.normal(size=(n, d)).astype(np.float32), 10.0)
+    auto = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d), y0)
+    assert auto.get_ce_mode() == A.AE_CE_SEQUENTIAL
+    del auto
+    with pytest.raises(A.AnnembedError):
+        ev = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_EVENT), y0)
+        ev.gradient_iteration_threaded(1000, 1.0, 1)
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_HOGWILD), y0)
+    S = 10 * eo.get_nb_edges()
+    eo.gradient_iteration_threaded(S, 0.5, 1)
+    y = eo.get_embedded()
+    drawn, rounds = eo.samples_drawn()
+    assert abs(drawn - S) < 6 * np.sqrt(S) and rounds >= 15
+    assert np.isfinite(y).all() and np.abs(y).max() < 1e3
+    assert (np.abs(y - y0).max(1) > 0).mean() > 0.999

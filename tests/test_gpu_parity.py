@@ -313,39 +313,50 @@ def test_sequential_bit_exact_at_full_c2_size(A, oracle):
     assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
 
 
-def test_hogwild_statistics_match_oracle(A, oracle):
-    """The Hogwild schedule is not reproducible (neither is the reference's rayon loop); its statistics are:
-    same samples, same arithmetic => final cross entropy close to the oracle's sequential run and to the
-    oracle's own OpenMP Hogwild run."""
-    indptr, nbr, dist, _, _ = synthetic_graph(n=20000, dim=8, k=8, seed=2, ncomp=6, )
+def _edge_len(indptr, nbr, y):
+    src = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr.astype(np.int64)))
+    return np.linalg.norm(y[src] - y[nbr], axis=1)
+
+
+def test_event_mode_statistics_match_oracle(A, oracle):
+    """The default CE mode (AE_CE_AUTO -> AE_CE_EVENT) is not reproducible sample by sample (neither is the reference's
+    rayon loop); its statistics are the sequential loop's: final cross entropy within 3 % and edge-length quantiles within
+    5 % of the oracle's sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n).
+    Kept as evidence next to it: the rounds mode (AE_CE_HOGWILD, stale partner rows) and the literal racy per-sample
+    transcription are NOT inside that envelope."""
+    n = 20000
+    indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=8, seed=2, ncomp=6)
     g = A.KGraph(indptr, nbr, dist)
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
-    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(20000, 2)).astype(np.float32), 10.0)
-    par = A.EmbedderParams(nb_grad_batch=6)
-    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), par, y0)
+    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
+    assert eo.get_ce_mode() == A.AE_CE_EVENT
+    y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 6)
     assert abs(ce0 - oce0) < 1e-10 * oce0
     assert np.isfinite(y).all()
-    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
-    # edge lengths in the embedding have the same distribution
-    src = np.repeat(np.arange(20000), 8)
-    lg = np.linalg.norm(y[src] - y[nbr], axis=1)
-    lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
+    assert abs(ce1 - oce1) < 0.03 * oce1, (ce1, oce1)
+    lg, lo = _edge_len(indptr, nbr, y), _edge_len(indptr, nbr, yo)
     for q in (0.25, 0.5, 0.75, 0.95):
-        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.15 * np.quantile(lo, q)
+        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.05 * np.quantile(lo, q), q
+    # rounds mode: a throughput mode outside the envelope (documented; DESIGN 4.2) -- only sanity here
+    yr, _, cer = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD), y0)
+    assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1
     # the literal per-sample racy transcription is NOT equivalent on a GPU (most updates are lost): keep the evidence
-    yr, _, cer = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_SAMPLE_RACY), y0)
-    lr = np.linalg.norm(yr[src] - yr[nbr], axis=1)
-    assert np.quantile(lr, 0.5) > 1.4 * np.quantile(lo, 0.5)
+    yr, _, cer = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_SAMPLE_RACY), y0)
+    assert np.quantile(_edge_len(indptr, nbr, yr), 0.5) > 1.4 * np.quantile(lo, 0.5)
 
 
 @pytest.mark.parametrize("dim,k,hub,b", [(5, 8, False, 1.0), (10, 20, True, 1.0), (20, 28, False, 1.0), (3, 32, False, 1.0), (7, 12, True, 1.0),
                                          (2, 10, False, 0.8), (6, 20, True, 1.3), (8, 12, False, 1.0), (16, 10, True, 1.0), (8, 30, True, 1.0),
                                          (16, 16, False, 0.9)])
-def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub, b):
-    """asked_dim without an exact kernel instantiation (run zero-padded to 8 / 16 / 32 columns), rows of up to 32
-    neighbours, hubness-weighted negatives, exponent b != 1: same statistical bar as the 2-D case against the
-    oracle's sequential run.  d = 8 and 16 are the kernels whose partner rows are gathered by lane groups."""
+def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
+    """Every asked_dim and row length through the default mode.  asked_dim in {2,3,4,8,16} resolves to the event-ordered
+    kernel (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours): CE within 5 %, edge-length median /
+    q90 within 8 % of the oracle's sequential run on these 4000-node graphs (the oracle's own seed spread here is ~3 %).
+    Other dimensions have no faithful kernel and resolve to the rounds mode (zero-padded to 8 / 16 / 32 columns): the
+    approximate mode's bar."""
     n = 4000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
     g = A.KGraph(indptr, nbr, dist)
@@ -360,19 +371,21 @@ def test_hogwild_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     y, ce1 = eo.get_embedded(), eo.ce_compute_threaded()
     yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc, b=b)
     assert np.isfinite(y).all() and y.shape == (n, dim)
-    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
+    faithful = dim in (2, 3, 4, 8, 16)
+    assert eo.get_ce_mode() == (A.AE_CE_EVENT if faithful else A.AE_CE_HOGWILD)
+    tol_ce, tol_q = (0.05, 0.08) if faithful else (0.25, 0.2)
+    assert abs(ce1 - oce1) < tol_ce * oce1, (ce1, oce1)
     src = np.repeat(np.arange(n), k)
     lg = np.linalg.norm(y[src] - y[nbr], axis=1)
     lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
     for q in (0.5, 0.9):
-        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.2 * np.quantile(lo, q), (q, np.quantile(lg, q), np.quantile(lo, q))
+        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < tol_q * np.quantile(lo, q), (q, np.quantile(lg, q), np.quantile(lo, q))
 
 
-def test_hogwild_converged_run_matches_reference_quality(A, oracle):
-    """Full schedule (dmap initialisation, 20 batches): the fast mode's embedding against the oracle's sequential
+def test_converged_run_matches_reference_quality(A, oracle):
+    """Full schedule (dmap initialisation, 20 batches): the default mode's embedding against the oracle's sequential
     run on the reference's own yardsticks -- final cross entropy and get_quality_estimate_from_edge_length
-    (embedder.rs:620-753).  The transient differences of short runs (10-14 % in CE after 6 batches) die out:
-    measured +1.6 % CE, -2 % nodes without a match, -4 % median ratio on n = 20 k."""
+    (embedder.rs:620-753)."""
     n, k, nb = 10000, 10, 20
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=10, k=k, seed=7, ncomp=8)
     g = A.KGraph(indptr, nbr, dist)
@@ -381,18 +394,18 @@ def test_hogwild_converged_run_matches_reference_quality(A, oracle):
     y0 = oracle.set_data_box(y0, 10.0)
     yo, _, oce = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb)
     y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb), y0)
-    assert abs(ce - oce) < 0.06 * oce, (ce, oce)
+    assert abs(ce - oce) < 0.03 * oce, (ce, oce)
     q, qo = A.quality_estimate_from_edge_length(g, y, 30), A.quality_estimate_from_edge_length(g, yo, 30)
-    # measured over seeds and runs (the kernel's schedule is not reproducible) at n = 10 k: -10 ... -14 % (fewer); -2 % at 20 k
-    assert abs(q.nb_without_match - qo.nb_without_match) < 0.20 * qo.nb_without_match
-    assert abs(q.mean_nbmatch - qo.mean_nbmatch) < 0.06 * qo.mean_nbmatch
-    assert abs(q.median_ratio - qo.median_ratio) < 0.10 * qo.median_ratio
-    assert abs(q.radii_quantiles[2] - qo.radii_quantiles[2]) < 0.06 * qo.radii_quantiles[2]
+    assert abs(q.nb_without_match - qo.nb_without_match) < 0.05 * qo.nb_without_match
+    assert abs(q.mean_nbmatch - qo.mean_nbmatch) < 0.05 * qo.mean_nbmatch
+    assert abs(q.median_ratio - qo.median_ratio) < 0.08 * qo.median_ratio
+    assert abs(q.radii_quantiles[2] - qo.radii_quantiles[2]) < 0.05 * qo.radii_quantiles[2]
 
 
-def test_hogwild_hub_and_ragged_rows(A, oracle):
-    """a node that is everybody's neighbour (in-degree n - 1: its pushes overflow the in-edge windows of the round
-    kernel and are replayed by one lane) and rows of unequal length"""
+def test_hub_and_ragged_rows(A, oracle):
+    """a node that is everybody's neighbour (in-degree n - 1: in the event-ordered kernel its event list is sorted by the
+    whole wave and it serves runs of target events per trip; in the rounds kernel its pushes overflow the in-edge windows)
+    and rows of unequal length"""
     rng = np.random.default_rng(4)
     n = 3000
     x = rng.normal(size=(n, 4)).astype(np.float32)
@@ -416,14 +429,16 @@ def test_hogwild_hub_and_ragged_rows(A, oracle):
     y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5), y0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5)
     assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
-    # rounds are sized by the largest in-weight too (176 rounds here instead of 8): measured 0.89 (0.75 without)
-    assert abs(ce1 - oce1) < 0.25 * oce1, (ce1, oce1)
+    assert abs(ce1 - oce1) < 0.05 * oce1, (ce1, oce1)
     src = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
     lg, lo = np.linalg.norm(y[src] - y[nbr], axis=1), np.linalg.norm(yo[src] - yo[nbr], axis=1)
-    assert abs(np.median(lg) - np.median(lo)) < 0.2 * np.median(lo)  # measured +3 % (+23 % without)
+    assert abs(np.median(lg) - np.median(lo)) < 0.06 * np.median(lo)
+    # the rounds mode on the same graph (rounds sized by the largest in-weight: 176 here): measured 0.89x CE, median +3 %
+    yr, _, cer = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0)
+    assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1
 
 
-def test_hogwild_unsupported_shape_fails_loudly(A, oracle):
+def test_unsupported_shape_fails_loudly(A, oracle):
     indptr, nbr, dist, _, _ = synthetic_graph(n=600, dim=6, k=6, seed=1, ncomp=1)
     g = A.KGraph(indptr, nbr, dist)
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
@@ -431,6 +446,11 @@ def test_hogwild_unsupported_shape_fails_loudly(A, oracle):
     eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=40), y0)
     with pytest.raises(A.AnnembedError) as e:  # no silent fall-back to the racy per-sample kernel
         eo.gradient_iteration_threaded(1000, 1.0, 1)
+    assert e.value.code == 1
+    y0 = y0[:, :2].copy()
+    ev = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=2, ce_mode=A.AE_CE_EVENT), y0, node_lo=0, node_hi=300)
+    with pytest.raises(A.AnnembedError) as e:  # the event-ordered kernel does not shard: says so instead of running something else
+        ev.gradient_iteration_threaded(1000, 1.0, 1)
     assert e.value.code == 1
 
 
@@ -578,7 +598,7 @@ def test_embedder_one_step(A, oracle, graph):
         sgn = np.sign(np.dot(y0[:, c], ref["y0"][:, c]))
         assert np.max(np.abs(sgn * y0[:, c] - ref["y0"][:, c])) < 2e-2 * 5.0
     b, a = e.get_cross_entropy()
-    assert abs(b - ref["ce_before"]) < 2e-2 * ref["ce_before"] and abs(a - ref["ce_after"]) < 0.25 * ref["ce_after"]
+    assert abs(b - ref["ce_before"]) < 2e-2 * ref["ce_before"] and abs(a - ref["ce_after"]) < 0.06 * ref["ce_after"]
     assert np.array_equal(e.get_embedded_reindexed(), y)
     perm = np.random.default_rng(0).permutation(2500).astype(np.uint64)
     assert np.array_equal(e.get_embedded_reindexed(perm)[perm], y)
@@ -617,7 +637,7 @@ def test_embedder_hierarchical(A, oracle):
                              oracle.EmbedderParams(nb_grad_batch=4, grad_factor=2, scale_rho=0.75, hubness_weighting=True))
     assert rc == 0 and y.shape == (6000, 2) and np.isfinite(y).all()
     b, a = e.get_cross_entropy()
-    assert abs(a - ref["ce_after"]) < 0.3 * ref["ce_after"]
+    assert abs(a - ref["ce_after"]) < 0.08 * ref["ce_after"], (a, ref["ce_after"])
     # projected points start near their projection (clip(.,2) noise, embedder.rs:265)
     y0 = e.get_initial_embedding()
     assert np.max(np.abs(y0[n_small:] - y0[proj_node[n_small:]])) <= 2.0 + 1e-5
@@ -639,7 +659,7 @@ def test_full_size_properties(A):
     p = p.reshape(n, k)
     assert np.allclose(p.sum(1), 1.0, atol=2e-5) and (p > 0).all() and (np.diff(p, axis=1) <= 1e-7).all()  # sorted dists -> sorted probas
     y0 = A.set_data_box(rng.normal(size=(n, 2)).astype(np.float32), 10.0)
-    par = A.EmbedderParams(nb_grad_batch=5)
+    par = A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD)
     eo = A.EntropyOptim(g, npar, par, y0)
     nodes, w = eo.plan(0, 200000, 1)
     src, cnt = np.unique(nodes[:, 0], return_counts=True)
@@ -656,6 +676,15 @@ def test_full_size_properties(A):
     assert cnt == 2 and ms > 0
     drawn, rounds = eo.samples_drawn()  # Poisson(nb_sample) total per batch
     assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S) and rounds == 15  # 120 samples per node and batch, 8 per round
+    # the same properties in the default (event-ordered) mode
+    ev = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0)
+    assert ev.get_ce_mode() == A.AE_CE_EVENT
+    ev.gradient_iteration_threaded(S, 0.0, 1)
+    assert np.array_equal(ev.get_embedded(), before)
+    ev.gradient_iteration_threaded(S, 1.0, 2)
+    assert np.isfinite(ev.get_embedded()).all() and np.isfinite(ev.ce_compute_threaded())
+    drawn, windows = ev.samples_drawn()
+    assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S) and 4 <= windows <= 64
 
 
 # ------------------------------------------------------------------------------------------------
@@ -698,7 +727,7 @@ def test_device_coords_alias_and_sharded_hogwild(A, oracle, graph):
     drawn = sum(eo.samples_drawn()[0] for _, _, eo in shards)
     assert abs(drawn - 3 * 10 * len(nbr)) < 6 * np.sqrt(3 * 10 * len(nbr))
     # the union of the two shards behaves like the single-GPU run: same statistics
-    full = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0)
+    full = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0)
     for it in range(1, 4):
         full.gradient_iteration_threaded(10 * len(nbr), 1.0, it)
     ce_full = full.ce_compute_threaded()
@@ -740,7 +769,7 @@ def test_sharded_hogwild_wide_rows(A, oracle, graph, dim):
         torch.cuda.synchronize()
     ys = [eo.get_embedded() for _, _, eo in shards]
     assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2]) and np.isfinite(ys[0]).all()
-    full = A.EntropyOptim(g, npar, par, y0)
+    full = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0)
     for it in range(1, 4):
         full.gradient_iteration_threaded(10 * len(nbr), 1.0 * (1 - it / 5), it)
     ce_full = full.ce_compute_threaded()
