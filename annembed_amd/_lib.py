@@ -117,6 +117,11 @@ SIGNATURES = {
     "ae_entropy_optim_destroy": [_vp],
     "ae_entropy_optim_get_nb_edges": [_vp, _P(_u64)],
     "ae_entropy_optim_get_ce_mode": [_vp, _P(C.c_uint32)],
+    "ae_comm_unique_id": [_vp],
+    "ae_comm_init": [C.c_int32, C.c_int32, _vp, _P(_vp)],
+    "ae_comm_destroy": [_vp],
+    "ae_comm_all_reduce_sum": [_vp, _P(C.c_double)],
+    "ae_entropy_optim_set_comm": [_vp, _vp, C.c_uint32],
     "ae_entropy_optim_ce": [_vp, _P(_f64)],
     "ae_entropy_optim_gradient_iteration": [_vp, _u64, _f64, _u64],
     "ae_entropy_optim_plan": [_vp, _u64, _u64, _u64, _vp, _vp],

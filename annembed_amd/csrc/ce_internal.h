@@ -47,6 +47,8 @@ using namespace ae;  // internal header: the handle below is declared at global 
         default: FN<0>(__VA_ARGS__); break;    \
     }
 
+struct ae_comm;
+
 struct ae_entropy_optim {
     const ae_kgraph* g = nullptr;
     const ae_node_params* np = nullptr;
@@ -81,6 +83,11 @@ struct ae_entropy_optim {
     int ev_npw = 0;  // nodes per wave
     uint64_t ev_resident_blocks = 0;
     DevBuf<float> ev_slots;
+    // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch
+    ae_comm* comm = nullptr;
+    std::vector<uint64_t> comm_ranges;
+    bool comm_equal = false;
+    uint32_t comm_exchanges = 1;
     ~ae_entropy_optim() {
         for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
@@ -92,6 +99,7 @@ bool ce_node_supports(const ae_entropy_optim* o);
 void ce_node_build_transpose(ae_entropy_optim* o);
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
 // event-ordered batch (ce_event.hip): sequentially consistent attraction steps in an i.i.d. order, `rounds` = windows
+void ce_comm_exchange(ae_entropy_optim* o);  // comm.hip: all-gather of the owned coordinate rows on the library's stream
 void ce_event_prepare(ae_entropy_optim* o);
 const char* ce_event_unsupported(const ae_entropy_optim* o);
 void ce_event_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);

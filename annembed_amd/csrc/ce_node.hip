@@ -638,20 +638,30 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     // and stores share vmcnt and may return out of order, so every wait after a store drains it: +50 % time)
     // for a fidelity gain that shorter rounds give more cheaply
     a.store_mode = getenv("AE_CE_STORE") ? atoi(getenv("AE_CE_STORE")) : 2;
+    // multi-GPU: the owned rows are exchanged `comm_exchanges` times per batch, after equal runs of rounds (the last
+    // exchange ends the batch): remote rows are rounds / exchanges rounds old instead of a whole batch
+    const uint32_t exch = o->comm ? std::min(std::max(1u, o->comm_exchanges), rounds) : 0u;
+    auto exchange_after = [&](uint32_t r) {
+        if (!exch) return;
+        const uint32_t before = (uint32_t)(((uint64_t)r * exch) / rounds), after = (uint32_t)(((uint64_t)(r + 1) * exch) / rounds);
+        if (after != before) ce_comm_exchange(o);
+    };
     for (uint32_t r = 0; r < rounds; r++) {
         a.round_key = (iter << 10) | r;
         if (node_kernel) {
             if (legacy_dim(o->dev.dim)) launch_round_node_exact(o, a, nodes);
             else launch_round_node_padded(o, a, nodes);
+            exchange_after(r);
             continue;
         }
-        if (group_kernel) { AE_DISPATCH_DIM(o->dev.dim, launch_round_fused, o, a, nodes); continue; }
+        if (group_kernel) { AE_DISPATCH_DIM(o->dev.dim, launch_round_fused, o, a, nodes); exchange_after(r); continue; }
         const unsigned plan_grid = blocks_for(nodes * 64, kBlock);
         if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
         else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
         if (sharded) hipLaunchKernelGGL(ce_count_remote_kernel, dim3(grid_cap(o->dev.nnz, kBlock)), dim3(kBlock), 0, stream(), a);
         hipLaunchKernelGGL(ce_sum_tot_kernel, dim3(1), dim3(1024), 0, stream(), (const uint32_t*)o->tot.p, nodes, o->sample_counter.p);
         AE_DISPATCH_DIM(o->dev.dim, launch_apply_group, o, a, nodes);
+        exchange_after(r);
     }
     check_launch("ce_node");
     if (a.prof) {

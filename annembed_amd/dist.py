@@ -1,5 +1,10 @@
 """Multi-GPU driver of the CE loop: one process per GPU, points sharded by source node, coordinates
-replicated and all-gathered (RCCL over xGMI through torch.distributed) once per CE batch.
+replicated and all-gathered over RCCL / xGMI.  Two ways to run the exchange:
+
+  * LibraryComm (default of bench.py): the library's own RCCL communicator (include/annembed_hip.h, ae_comm_*) --
+    ae_entropy_optim_gradient_iteration all-gathers the owned rows itself, in place, on its stream, `exchanges` times per
+    batch; a host in any language can do the same, torch is only used here to pass the 128-byte id to the other ranks;
+  * ShardedCE: the exchange through torch.distributed (gloo in the CPU tests, where the oracle is the compute backend).
 
 No reference counterpart (the reference is single-process, shared-memory rayon).  Semantics:
   * rank r owns source nodes [lo_r, hi_r): it draws positive edges only from its own rows
@@ -54,11 +59,26 @@ class ShardedCE:
             return
         if self.pre_gather is not None:
             self.pre_gather()
-        own = self.y[self.lo:self.hi].clone()
+        if isinstance(self.backend, HipBackend):
+            # the batch's kernels run on the library's own (non-blocking) stream and self.y IS the library's coordinate
+            # array: the collective must be ordered after them and before the next batch's -- run it on that stream
+            import torch
+            with torch.cuda.stream(library_stream()):
+                self._gather()
+        else:
+            self._gather()
+
+    def _gather(self):
         if self.equal:
+            # in place: the send buffer is this rank's slot of the receive buffer (what NCCL / RCCL define as in-place
+            # all-gather) -- no clone, no copy back; gloo gets a copy (it does not accept aliased buffers)
+            own = self.y[self.lo:self.hi]
+            if not self.y.is_cuda:
+                own = own.clone()
             self.dist.all_gather_into_tensor(self.y, own, group=self.group)
         else:
             import torch
+            own = self.y[self.lo:self.hi].clone()
             parts = [torch.empty((s, self.dim), dtype=self.y.dtype, device=self.y.device) for s in self.sizes]
             self.dist.all_gather(parts, own, group=self.group)
             off = 0
@@ -121,3 +141,38 @@ def library_stream():
     sp = ctypes.c_void_p()
     L.check(L.load().ae_get_stream(ctypes.byref(sp)))
     return torch.cuda.ExternalStream(sp.value)
+
+
+class LibraryComm:
+    """The library's RCCL communicator (ae_comm_*, include/annembed_hip.h).  The 128-byte id travels from rank 0 to the other
+    ranks through an already initialised torch.distributed group (any backend); nothing else of torch is involved."""
+
+    def __init__(self, rank, world):
+        import ctypes
+        from . import _lib as L
+        self._L, self.rank, self.world = L, rank, world
+        ident = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            L.check(L.load().ae_comm_unique_id(ident))
+        if world > 1:
+            import torch.distributed as dist
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        L.check(L.load().ae_comm_init(rank, world, ident, ctypes.byref(h)))
+        self._h = h
+
+    def attach(self, entropy_optim, exchanges_per_batch=1):
+        self._L.check(self._L.load().ae_entropy_optim_set_comm(entropy_optim._h, self._h, exchanges_per_batch))
+
+    def all_reduce_sum(self, value):
+        import ctypes
+        v = ctypes.c_double(value)
+        self._L.check(self._L.load().ae_comm_all_reduce_sum(self._h, ctypes.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h:
+            self._L.check(self._L.load().ae_comm_destroy(self._h))
+            self._h = None

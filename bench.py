@@ -7,11 +7,22 @@ nb_sampling_by_edge * nnz SGD samples), plus the SVD-init GFLOP/s of the diffusi
 Workload at N=1: configs[1] "MNIST-fashion 60k x 784 -> 2D, k=12, dmap init + CE loop, fp32"
 (parameters of examples/mnist_fashion.rs:92-110).  The real dataset is absent (no network): a
 synthetic Gaussian mixture of the same shape stands in and the exact kNN graph is built
-on the GPU before the timed region.  N>1: weak scaling -- every rank owns 60k source nodes of an
-N*60k point graph, coordinates are replicated and all-gathered (RCCL) once per CE batch.
+on the GPU before the timed region.  The headline `value` is the DEFAULT CE mode (AE_CE_AUTO -> the
+event-ordered kernel: one gradient for both ends on current rows, the reference's f64 scalars), the mode
+that is inside the reference's own envelope; the same line carries
+  * "fidelity": final CE and edge-length quartiles of the default mode and of the rounds mode after the full
+    25-batch schedule, as ratios to the sequential mode (bit-exact vs the oracle) on the same graph and start;
+  * "rounds_mode" (AE_CE_HOGWILD: a throughput mode OUTSIDE that envelope) and "exact_mode" (AE_CE_SEQUENTIAL);
+  * "scale_shapes": the configs[2] / configs[3] shapes (1.65 M x k6 -> 2-D, 11 M x k6 -> 8-D) on a ring-lattice
+    graph whose node ids are randomly permuted, so that positive edges are not memory-local.
 
-A "step" = one CE batch.  The timed region holds only `ae_entropy_optim_gradient_iteration` launches
-(+ the per-batch all-gather when N>1) with every input already resident in HBM.
+N>1 (default): STRONG scaling of the configs[3] shape -- a fixed 11 M-node graph, its source nodes sharded
+over the ranks, the coordinate rows all-gathered by the library's own RCCL communicator inside
+ae_entropy_optim_gradient_iteration (`--exchanges` times per batch).  Only the rounds mode shards.
+`--weak` keeps the round-1 arrangement (60 k MNIST-shaped points per GPU).
+
+A "step" = one CE batch.  The timed region holds only `ae_entropy_optim_gradient_iteration` calls
+(the collective is inside them when N>1) with every input already resident in HBM.
 
 Prints ONE JSON line on rank 0.
 """
@@ -71,6 +82,115 @@ def svd_flops(n, nnz_a, l=20, nbiter=5):
             + 2 * n * l * l)
 
 
+def lattice_graph(n, k, seed, permute):
+    """ring lattice (neighbours at Fibonacci offsets, gamma-distributed distances): a kNN-shaped graph at sizes where an
+    exact kNN is out of reach of brute force.  permute: node ids are a random permutation of the ring positions, so that
+    the rows a sample touches are scattered over the coordinate array as they are for a real kNN graph in arbitrary order."""
+    rng = np.random.default_rng(seed)
+    offs = np.array([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597][:(k + 1) // 2])
+    if permute:
+        perm = rng.permutation(n).astype(np.int64)   # ring position -> node id
+        pos = np.empty(n, np.int64)
+        pos[perm] = np.arange(n)                     # node id -> ring position
+        cols = [perm[(pos + o) % n] for o in offs] + [perm[(pos - o) % n] for o in offs]
+    else:
+        base = np.arange(n, dtype=np.int64)
+        cols = [(base + o) % n for o in offs] + [(base - o) % n for o in offs]
+    nbr = np.stack(cols[:k], 1).astype(np.uint32).reshape(-1)
+    dst = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1).reshape(-1)
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    return indptr, nbr, dst
+
+
+def edge_quartiles(indptr, nbr, y):
+    src = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr.astype(np.int64)))
+    return np.quantile(np.linalg.norm(y[src] - y[nbr], axis=1), [0.25, 0.5, 0.75])
+
+
+MODE_NAMES = {0: "rounds (AE_CE_HOGWILD)", 1: "sequential (AE_CE_SEQUENTIAL)", 2: "racy", 3: "event-ordered (AE_CE_EVENT)"}
+MODE_KERNEL = {0: "ce_round_node_kernel (one launch per round)", 1: "ce_dataflow_kernel (one cooperative launch per batch)",
+               3: "ce_event_window_kernel (one launch per window)"}
+
+
+def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo=0, hi=None, comm=None, exchanges=1, fence=None):
+    """`warmup` untimed + `steps` timed CE batches of one mode; returns timing and the per-launch roofline inputs"""
+    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=mode)
+    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi)
+    if comm is not None:
+        comm.attach(eo, exchanges)
+    nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
+    total = max(nb_batch, warmup + steps + 1)
+    sync = fence or (lambda: L.check(L.load().ae_synchronize()))
+    ce_before = eo.ce_compute_threaded()
+    it = 0
+    for _ in range(warmup):
+        it += 1
+        eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / total), it)
+    sync()
+    eo.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        it += 1
+        eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / total), it)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eo.kernel_time()
+    resolved = eo.get_ce_mode()
+    rounds = int(eo.samples_drawn()[1]) if resolved in (0, 3) else 1
+    return dict(eo=eo, elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, kernel_ms=kernel_ms, batches_timed=int(launches), rounds=rounds,
+                mode=resolved, nb_sample=nb_sample, ce_before=ce_before, ce_after=eo.ce_compute_threaded())
+
+
+def roofline_of(run, k, d):
+    """algorithmic bytes per SGD sample B = 24 + 4 k + 36 d; one launch of the dominant kernel processes
+    nb_sample / launches_per_batch samples; achieved = bytes per launch / average launch duration (hipEvents on the library's
+    stream around the batch's launches / launches per batch)"""
+    bytes_per_sample = 24 + 4 * k + 36 * d
+    lpb = max(run["rounds"], 1)
+    kernel_ms = run["kernel_ms"] if run["kernel_ms"] > 0 else run["ms_per_step"]
+    launch_ms = kernel_ms / lpb
+    bytes_per_launch = bytes_per_sample * run["nb_sample"] / lpb
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "kernel": MODE_KERNEL.get(run["mode"], "?"), "launches_per_batch": lpb, "launch_avg_ms": launch_ms, "batch_kernel_ms": kernel_ms,
+            "batches_timed": run["batches_timed"], "bytes_per_sample": bytes_per_sample, "bytes_per_launch": bytes_per_launch}
+
+
+def full_schedule(A, kg, node_params, y0, d, mode, nb_batch=25):
+    p = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=mode)
+    y, _, ce = A.entropy_optimize(kg, node_params, p, y0)
+    return y, ce
+
+
+def scale_shape(A, L, name, n, k, d, steps, with_sequential):
+    """configs[2] / configs[3] shapes on one GPU, on the node-permuted lattice graph: the rounds mode (and the sequential mode
+    where it is affordable); the default mode resolves to the sequential mode at these sizes (more nodes than resident lanes)"""
+    import torch
+    indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)
+    kg = A.KGraph(indptr, nbr, dst, k)
+    t0 = time.perf_counter()
+    y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
+    L.check(L.load().ae_synchronize())
+    init_s = time.perf_counter() - t0
+    node_params = A.to_proba_edges(kg, 1.0, 1.0)
+    out = {"nodes": n, "k": k, "asked_dim": d, "graph": "ring lattice, node ids randomly permuted", "dmap_init_s": init_s}
+    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, steps, 1)
+    out["rounds_mode"] = {"faithful": False, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
+                          "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
+    del r
+    auto = A.EntropyOptim(kg, node_params, A.EmbedderParams(asked_dim=d), y0)
+    out["default_mode_resolves_to"] = MODE_NAMES.get(auto.get_ce_mode())
+    del auto
+    if with_sequential:
+        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, max(2, steps // 2), 1)
+        out["exact_mode"] = {"faithful": True, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
+                             "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
+        del r
+    del kg, node_params
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,13 +203,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-svd", action="store_true")
     ap.add_argument("--no-exact-mode", action="store_true")
+    ap.add_argument("--no-fidelity", action="store_true")
+    ap.add_argument("--no-scale-shapes", action="store_true")
+    ap.add_argument("--ce-mode", default="auto", choices=["auto", "event", "rounds", "sequential"], help="mode of the headline figure at N = 1")
     ap.add_argument("--lattice-graph", action="store_true",
-                    help="scale runs (C3 / C4 shapes): ring-lattice kNN graph with gamma-distributed distances instead of an exact kNN of synthetic points (an 11 M-point exact kNN is out of reach of brute force)")
-    ap.add_argument("--force-dist", action="store_true", help="exercise the collective path with world size 1 (validation)")
+                    help="N = 1 scale runs: ring-lattice kNN graph (node ids permuted) with --points-per-gpu nodes instead of the MNIST-shaped points")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling on 60 k MNIST-shaped points per GPU (round-1 arrangement) instead of the strong-scaling configs[3] shape")
+    ap.add_argument("--scale-nodes", type=int, default=11_000_000, help="N > 1 strong scaling: nodes of the fixed graph (k = 6, asked_dim 8)")
+    ap.add_argument("--exchanges", type=int, default=4, help="N > 1: all-gathers of the owned rows per CE batch")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the communicator path with world size 1 (validation)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="validation only: gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices), so the whole "
-                         "N > 1 code path -- sharded node ranges, gathered kNN rows, per-batch all-gather, max-over-ranks timing -- "
-                         "can be run end to end on a single-GPU box; the figure it prints is not a benchmark result")
+                    help="torch.distributed backend used for rendezvous, barriers and timing reductions (gloo: validation runs with several "
+                         "ranks sharing ONE GPU; RCCL refuses duplicate devices, so the exchange then goes through torch/gloo and the figure is not a result)")
     args = ap.parse_args()
 
     import torch
@@ -119,37 +244,34 @@ def main():
 
     import annembed_amd as A
     from annembed_amd import _lib as L
+    from annembed_amd.dist import LibraryComm, ShardedCE, HipBackend, device_tensor, shard_range
     L.check(L.load().ae_set_device(local_rank))
 
-    ppg, k, d = args.points_per_gpu, args.knbn, args.asked_dim
-    n = ppg * world
-    lo, hi = rank * ppg, (rank + 1) * ppg
+    def fence():
+        L.check(L.load().ae_synchronize())
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
 
-    # ---------------- input preparation (untimed) ----------------
+    if use_dist:
+        multi_gpu(args, A, L, dist, torch, rank, world, fence)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # =============================== N = 1 ===============================
+    k, d = args.knbn, args.asked_dim
+    n = args.points_per_gpu
+    svd_dense = knn_producer = None
     if args.lattice_graph:
-        rng = np.random.default_rng(1)
-        base = np.arange(n, dtype=np.int64)
-        offs = np.array([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377, 610, 987, 1597][:(k + 1) // 2])
-        cols = [(base + o) % n for o in offs] + [(base - o) % n for o in offs]
-        nbr = np.stack(cols[:k], 1).astype(np.uint32).reshape(-1)
-        dst = np.sort(rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32), axis=1).reshape(-1)
-        indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
-        svd_dense = None
-        knn_producer = None
+        indptr, nbr, dst = lattice_graph(n, k, seed=1, permute=True)
     else:
         x = synth_points(n, args.dim, seed=1)
-        nbr_l, dist_l = knn_rows(x, lo, hi, k)
-        if world > 1:
-            nbr_all = torch.empty((n, k), dtype=torch.int64, device=x.device)
-            dist_all = torch.empty((n, k), dtype=torch.float32, device=x.device)
-            dist.all_gather_into_tensor(nbr_all, nbr_l)
-            dist.all_gather_into_tensor(dist_all, dist_l)
-        else:
-            nbr_all, dist_all = nbr_l, dist_l
-        # secondary figure (rank 0, N = 1): the dense range finder of tools::svdapprox on the data matrix itself --
-        # subspace_iteration_full + direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
-        svd_dense = None
-        if world == 1 and not args.no_dense_svd:
+        nbr_all, dist_all = knn_rows(x, 0, n, k)
+        # secondary figure: the dense range finder of tools::svdapprox on the data matrix itself -- subspace_iteration_full +
+        # direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
+        if not args.no_dense_svd:
             mat = A.MatRepr.from_array2(x.cpu().numpy())
             A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))  # warm
             L.check(L.load().ae_synchronize())
@@ -163,10 +285,7 @@ def main():
                          "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
                          "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
             del mat
-        # secondary figure (rank 0, N = 1): the exact kNN-graph producer on the matrix cores, host matrix in,
-        # KGraph out (includes the PCIe upload of the points)
-        knn_producer = None
-        if world == 1 and not args.no_dense_svd:
+            # the exact kNN-graph producer on the matrix cores, host matrix in, KGraph out (PCIe upload included)
             xh = x.cpu().numpy()
             A.KGraph.bruteforce_l2(xh, k)  # warm
             t0 = time.perf_counter()
@@ -179,7 +298,7 @@ def main():
         indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
         nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
         dst = dist_all.cpu().numpy().reshape(-1)
-        del nbr_all, dist_all, nbr_l, dist_l
+        del nbr_all, dist_all
     torch.cuda.empty_cache()
     kg = A.KGraph(indptr, nbr, dst, k)
 
@@ -199,43 +318,154 @@ def main():
     y0 = A.set_data_box(y0, 10.0)
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
 
+    mode = {"auto": A.AE_CE_AUTO, "event": A.AE_CE_EVENT, "rounds": A.AE_CE_HOGWILD, "sequential": A.AE_CE_SEQUENTIAL}[args.ce_mode]
+    head = time_mode(A, L, kg, node_params, y0, d, mode, args.steps, args.warmup, fence=fence)
+    head_eo = head.pop("eo")
     params = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0)
+    nb_batch = max(25, args.warmup + args.steps + 1)
+    del head_eo
+
+    # secondary figures on the same graph and start
+    rounds_mode = exact_mode = fidelity = None
+    if head["mode"] != A.AE_CE_HOGWILD:
+        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, args.steps, args.warmup)
+        r.pop("eo")
+        rounds_mode = {"ce_mode": MODE_NAMES[0], "faithful": False, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
+                       "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
+    if not args.no_exact_mode and head["mode"] != A.AE_CE_SEQUENTIAL:
+        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, 3, 1)
+        r.pop("eo")
+        exact_mode = {"ce_mode": "sequential (device-scheduled dataflow, bit-exact vs the oracle)", "faithful": True, "ms_per_step": r["ms_per_step"],
+                      "points_per_s": n / (r["ms_per_step"] * 1e-3), "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3),
+                      "roofline": roofline_of(r, k, d)}
+    if not args.no_fidelity:
+        # the full 25-batch schedule from the dmap initialisation in the three modes: what each mode converges to
+        ys, ces = full_schedule(A, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL)
+        qs = edge_quartiles(indptr, nbr, ys)
+        fidelity = {"schedule": "25 batches from the dmap initialisation, same graph and start", "reference": "AE_CE_SEQUENTIAL (bit-exact vs the oracle's sequential loop)",
+                    "ce_sequential": ces, "edge_quartiles_sequential": qs.tolist()}
+        for name, m in (("default", mode), ("rounds", A.AE_CE_HOGWILD)):
+            ym, cem = full_schedule(A, kg, node_params, y0, d, m)
+            qm = edge_quartiles(indptr, nbr, ym)
+            fidelity[name] = {"ce/ce_seq": cem / ces, "q25_ratio": qm[0] / qs[0], "q50_ratio": qm[1] / qs[1], "q75_ratio": qm[2] / qs[2]}
+        # a second sequential run with another seed: the reference's own spread
+        p2 = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=A.AE_CE_SEQUENTIAL, seed=12345)
+        y2, _, ce2 = A.entropy_optimize(kg, node_params, p2, y0)
+        q2 = edge_quartiles(indptr, nbr, y2)
+        fidelity["sequential_other_seed"] = {"ce/ce_seq": ce2 / ces, "q25_ratio": q2[0] / qs[0], "q50_ratio": q2[1] / qs[1], "q75_ratio": q2[2] / qs[2]}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch)
+
+    scale_shapes = None
+    if not args.no_scale_shapes and not args.lattice_graph:
+        del kg, node_params, lap
+        torch.cuda.empty_cache()
+        scale_shapes = {
+            "c3_shape": scale_shape(A, L, "c3", 1_650_000, 6, 2, 6, with_sequential=True),
+            "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 4, with_sequential=False),
+        }
+
+    roof = roofline_of(head, k, d)
+    replay = pmc_traffic(head["mode"])
+    if replay:
+        roof.update(replay)
+    out = {
+        "metric": "embedded_points_per_sec_ce_epoch",
+        "value": n / (head["ms_per_step"] * 1e-3),
+        "unit": "points/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 coordinates, f64 scalars" if head["mode"] in (1, 3) else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("ring-lattice kNN graph (node ids permuted) %d nodes -> %dD, k=%d, dmap init + CE loop (scale run)" % (n, d, k))
+                        if args.lattice_graph else
+                        ("MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1])" % (n, args.dim, d, k)),
+            "nb_sampling_by_edge": 10, "samples_per_step": int(head["nb_sample"]), "ce_mode": MODE_NAMES.get(head["mode"]),
+            "ce_mode_requested": args.ce_mode,
+        },
+        "roofline": roof,
+        "fidelity": fidelity,
+        "rounds_mode": rounds_mode,
+        "exact_mode": exact_mode,
+        "scale_shapes": scale_shapes,
+        "svd_init": {"gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5},
+        "svd_dense": svd_dense,
+        "knn_producer": knn_producer,
+        "samples_per_s": head["nb_sample"] / (head["ms_per_step"] * 1e-3),
+        "ce_before": head["ce_before"], "ce_after": head["ce_after"],
+    }
+    if cpu:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+
+
+def multi_gpu(args, A, L, dist, torch, rank, world, fence):
+    """N > 1 (or --force-dist): the source nodes of ONE graph sharded over the ranks, rounds mode, the owned coordinate rows
+    exchanged inside ae_entropy_optim_gradient_iteration by the library's RCCL communicator.  Default: strong scaling of the
+    configs[3] shape (fixed --scale-nodes graph); --weak: 60 k MNIST-shaped points per GPU."""
+    from annembed_amd.dist import LibraryComm, ShardedCE, HipBackend, device_tensor, shard_range
+    if args.weak:
+        ppg, k, d = args.points_per_gpu, args.knbn, args.asked_dim
+        n = ppg * world
+        lo, hi = rank * ppg, (rank + 1) * ppg
+        x = synth_points(n, args.dim, seed=1)
+        nbr_l, dist_l = knn_rows(x, lo, hi, k)
+        nbr_all = torch.empty((n, k), dtype=torch.int64, device=x.device)
+        dist_all = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        if world > 1:
+            dist.all_gather_into_tensor(nbr_all, nbr_l)
+            dist.all_gather_into_tensor(dist_all, dist_l)
+        else:
+            nbr_all, dist_all = nbr_l, dist_l
+        del x
+        indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+        nbr = nbr_all.cpu().numpy().astype(np.uint32).reshape(-1)
+        dst = dist_all.cpu().numpy().reshape(-1)
+        del nbr_all, dist_all, nbr_l, dist_l
+        workload = "MNIST-fashion-shaped %dx%d -> %dD, k=%d, %d points per GPU (weak scaling)" % (n, args.dim, d, k, ppg)
+        scaling = "weak"
+    else:
+        n, k, d = args.scale_nodes, 6, 8
+        lo, hi = shard_range(n, world, rank)
+        indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)  # the same graph on every rank
+        workload = "Higgs-11M-shaped ring lattice (node ids permuted) %d nodes -> %dD, k=%d, source nodes sharded over %d GPUs (configs[3], strong scaling)" % (n, d, k, world)
+        scaling = "strong"
+    torch.cuda.empty_cache()
+    kg = A.KGraph(indptr, nbr, dst, k)
+    y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)  # replicated (DESIGN 5)
+    node_params = A.to_proba_edges(kg, 1.0, 1.0)
+    nb_batch = max(25, args.warmup + args.steps + 1)
+    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=A.AE_CE_HOGWILD)
     eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi)
-    nnz_shard = eo.get_nb_edges()
-    nb_sample = params.nb_sampling_by_edge * nnz_shard
-    nb_batch = max(params.nb_grad_batch, args.warmup + args.steps + 1)
+    nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
+    library_comm = args.backend == "nccl"
+    comm = sharded = None
+    if library_comm:
+        comm = LibraryComm(rank, world)
+        comm.attach(eo, args.exchanges)
+    else:  # validation over gloo: ranks share a GPU, the exchange goes through torch (once per batch)
+        sharded = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world)
     ce_before = eo.ce_compute_threaded()
-
-    y_all = None
-    lib_stream = None
-    if use_dist:
-        ptr, nn, dd = eo.device_coords()
-
-        class _Arr:  # wraps the library's device buffer as a torch tensor (no copy)
-            __cuda_array_interface__ = {"shape": (nn, dd), "typestr": "<f4", "data": (ptr, False), "version": 2}
-        y_all = torch.as_tensor(_Arr(), device="cuda")
-        # the library's HIP stream as a torch stream: the collective is ordered after the batch's kernels and before the
-        # next batch's by stream events (torch's NCCL work waits on / is waited by the current stream) -- no host sync
-        import ctypes
-        sp = ctypes.c_void_p()
-        L.check(L.load().ae_get_stream(ctypes.byref(sp)))
-        lib_stream = torch.cuda.ExternalStream(sp.value)
-        y_gather = torch.empty((nn, dd), dtype=torch.float32, device="cuda")
 
     def one_step(it):
         eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / nb_batch), it)
-        if use_dist:
-            with torch.cuda.stream(lib_stream):
-                # the collective works on torch-owned buffers (no assumption about RCCL and memory it did not see
-                # allocated); the gathered replica is copied into the library's coordinate array on the same stream
-                dist.all_gather_into_tensor(y_gather, y_all[lo:hi].clone())
-                y_all.copy_(y_gather)
-
-    def fence():
-        L.check(L.load().ae_synchronize())
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        if sharded is not None:
+            L.check(L.load().ae_synchronize())
+            y_host = device_tensor(eo).cpu()
+            sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
+            own = torch.zeros((max(sizes), d))
+            own[:hi - lo] = y_host[lo:hi]
+            parts = [torch.empty((max(sizes), d)) for _ in range(world)]  # gloo wants equal shapes: padded
+            dist.all_gather(parts, own)
+            device_tensor(eo).copy_(torch.cat([parts[r][:sizes[r]] for r in range(world)]).cuda())
             torch.cuda.synchronize()
 
     it = 0
@@ -243,7 +473,7 @@ def main():
         it += 1
         one_step(it)
     fence()
-    eo.kernel_time()  # reset the event accumulators
+    eo.kernel_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         it += 1
@@ -251,99 +481,66 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eo.kernel_time()
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ce_after = eo.ce_compute_threaded()
-
-    # secondary figure: the exact mode (AE_CE_SEQUENTIAL, bit-exact against the oracle's sequential loop -- tests),
-    # same graph, same batch size
-    exact_mode = None
-    if world == 1 and not args.no_exact_mode:
-        pe = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0,
-                              ce_mode=A.AE_CE_SEQUENTIAL)
-        ex = A.EntropyOptim(kg, node_params, pe, y0)
-        ex.gradient_iteration_threaded(nb_sample, 0.9, 1)  # warm (allocations)
-        L.check(L.load().ae_synchronize())
-        t0 = time.perf_counter()
-        reps = 3
-        for r in range(reps):
-            ex.gradient_iteration_threaded(nb_sample, 0.9, 2 + r)
-        L.check(L.load().ae_synchronize())
-        dt = (time.perf_counter() - t0) / reps
-        exact_mode = {"ce_mode": "sequential (device-scheduled dataflow, bit-exact vs the oracle)", "ms_per_step": dt * 1e3,
-                      "points_per_s": n / dt, "samples_per_s": nb_sample / dt}
-        del ex
-
+    elapsed, kernel_ms_max = float(tt[0].item()), float(tt[1].item())
+    ce_local = eo.ce_compute_threaded()
+    if comm is not None:
+        ce_after, ce0 = comm.all_reduce_sum(ce_local), comm.all_reduce_sum(ce_before)
+    else:
+        t2 = torch.tensor([ce_local, ce_before], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t2)
+        ce_after, ce0 = float(t2[0]), float(t2[1])
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        points_per_s = n * args.steps / elapsed
-        bytes_per_sample = 24 + 4 * k + 36 * d  # SURVEY 8d / DESIGN.md
-        # dominant kernel: ce_round_node_kernel, one launch per round; kernel_ms = hipEvent duration of one batch
-        # (= `rounds` back-to-back launches) on the library's stream, averaged over the timed steps
         rounds = int(eo.samples_drawn()[1])
-        launch_ms = kernel_ms / rounds if rounds else 0.0
-        bytes_per_launch = bytes_per_sample * nb_sample / max(rounds, 1)
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        # the committed PMC passes are of the default single-GPU workload only
-        default_workload = (world == 1 and not args.lattice_graph and ppg == 60000 and k == 12 and d == 2 and args.dim == 784)
-        traffic = pmc_traffic() if default_workload else None
+        run = dict(rounds=rounds, kernel_ms=kernel_ms_max, ms_per_step=elapsed / args.steps * 1e3, nb_sample=nb_sample, batches_timed=int(launches), mode=0)
+        roof = roofline_of(run, k, d)
+        roof["note"] = "per GPU: bytes of this rank's samples / the slowest rank's batch time, collectives included"
+        points = n if not args.weak else n
         out = {
             "metric": "embedded_points_per_sec_ce_epoch",
-            "value": points_per_s,
+            "value": points * args.steps / elapsed,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if args.backend == "nccl" else "synthetic (VALIDATION RUN over gloo, ranks sharing a GPU: not a result)",
-            "config": {
-                "workload": ("ring-lattice kNN graph %d nodes -> %dD, k=%d, dmap init + CE loop (scale run); %d points per GPU" % (n, d, k, ppg))
-                            if args.lattice_graph else
-                            ("MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1]); %d points per GPU"
-                             % (n, args.dim, d, k, ppg)),
-                "nb_sampling_by_edge": 10, "samples_per_step": int(nb_sample * world), "sampler": "rowcdf", "ce_mode": "hogwild",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "kernel": "ce_round_node_kernel (one launch per round, `rounds` launches per CE batch)",
-                "rounds": rounds, "launch_avg_ms": launch_ms, "batch_kernel_ms": kernel_ms, "batches_timed": int(launches),
-                "bytes_per_sample": bytes_per_sample, "bytes_per_launch": bytes_per_launch,
-            },
-            "svd_init": {
-                "gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5,
-            },
-            "svd_dense": svd_dense,
-            "knn_producer": knn_producer,
-            "exact_mode": exact_mode,
-            "samples_per_s": nb_sample * world * args.steps / elapsed,
-            "ce_before": ce_before, "ce_after": ce_after,
+            "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * len(nbr)), "ce_mode": MODE_NAMES[0] + " -- the only mode that shards; approximate (see fidelity in the N = 1 line)",
+                       "exchanges_per_batch": args.exchanges if library_comm else 1,
+                       "collective": "in-place RCCL all-gather of the owned rows inside ae_entropy_optim_gradient_iteration (library communicator)" if library_comm else "torch/gloo (validation)"},
+            "roofline": roof,
+            "per_rank_batch_ms_max": kernel_ms_max,
+            "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
+            "ce_before": ce0, "ce_after": ce_after,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch)
         print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        del eo
+        comm.close()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>/pmc_ce_round.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate
-    passes, KiB -> bytes); None when no profile of the current kernel is committed."""
+def pmc_traffic(mode):
+    """HBM bytes per launch of the dominant kernel REPLAYED from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/pmc_ce_*.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes).
+    Not a measurement of this run: reported under its own keys, `traffic` stays null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_ce_round.json")))
+    name = {0: "pmc_ce_round.json", 3: "pmc_ce_event.json"}.get(mode)
+    if not name:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
     try:
         with open(files[-1]) as f:
             j = json.load(f)
-        return float(j["hbm_bytes_per_launch"])
+        return {"traffic_replayed": float(j["hbm_bytes_per_launch"]), "traffic_replayed_from": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 

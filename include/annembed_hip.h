@@ -313,6 +313,21 @@ int32_t ae_entropy_optim_create(const ae_kgraph *g, const ae_node_params *np,
                                 ae_entropy_optim **out);
 int32_t ae_entropy_optim_destroy(ae_entropy_optim *o);
 int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz); /* :1027 */
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (no reference counterpart: the reference is one shared-memory
+ * process, src/embedder.rs:1311-1315; SURVEY 8b "8-GPU entry point", north star "RCCL all-gather of the low-dim coordinate
+ * array ... once per CE batch").  Rank 0 obtains a 128-byte id (ae_comm_unique_id) and hands it to the other ranks by any
+ * host channel; every rank calls ae_comm_init on its own device (ae_set_device first).  A communicator attached to an
+ * EntropyOptim created on this rank's node range [node_lo, node_hi) -- the ranges of the ranks must tile [0, n) in rank
+ * order -- makes ae_entropy_optim_gradient_iteration exchange the owned coordinate rows itself: in place, on the library's
+ * stream, `exchanges_per_batch` times per batch at equal runs of rounds (1 = once per batch, at its end).  Only the rounds
+ * mode (AE_CE_HOGWILD, what AE_CE_AUTO resolves to for a sharded range) shards.  The final cross entropy is the sum of the
+ * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
+typedef struct ae_comm ae_comm;
+int32_t ae_comm_unique_id(uint8_t *id128);
+int32_t ae_comm_init(int32_t rank, int32_t world, const uint8_t *id128, ae_comm **out);
+int32_t ae_comm_destroy(ae_comm *c);
+int32_t ae_comm_all_reduce_sum(ae_comm *c, double *value);
+int32_t ae_entropy_optim_set_comm(ae_entropy_optim *o, ae_comm *c, uint32_t exchanges_per_batch);
 /* the AE_CE_* mode the handle runs (AE_CE_AUTO resolved at create) */
 int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim *o, uint32_t *ce_mode);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */

@@ -867,11 +867,12 @@ def test_range_approx_epsil_stops_at_the_rank(A, oracle):
     assert np.linalg.norm(a64 - q64 @ (q64.T @ a64)) < 1e-4 * np.linalg.norm(a64)
 
 
-def test_bench_sharded_path_two_ranks_on_one_gpu():
-    """bench.py's N > 1 path end to end -- two processes, sharded node ranges, gathered kNN rows, the per-batch
-    all-gather on the library's stream, max-over-ranks timing, one JSON line from rank 0 -- with the two ranks sharing
-    this box's single GPU over gloo (RCCL refuses duplicate devices; the collective is the only difference to the
-    8-GPU launch of the driver)."""
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_sharded_path_two_ranks_on_one_gpu(strong):
+    """bench.py's N > 1 path end to end -- two processes, sharded node ranges, the owned rows exchanged once per batch,
+    max-over-ranks timing, one JSON line from rank 0 -- with the two ranks sharing this box's single GPU over gloo (RCCL
+    refuses duplicate devices; the collective is the only difference to the 8-GPU launch of the driver).  Both arrangements:
+    weak scaling on MNIST-shaped shards and strong scaling of one fixed (here: small) lattice graph."""
     import json
     import socket
     import subprocess
@@ -882,12 +883,41 @@ def test_bench_sharded_path_two_ranks_on_one_gpu():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--points-per-gpu", "6000", "--dim", "64", "--no-cpu-baseline"]
+           "--backend", "gloo"]
+    cmd += ["--scale-nodes", "20001"] if strong else ["--weak", "--points-per-gpu", "6000", "--dim", "64"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
-    assert j["config"]["samples_per_step"] == 2 * 6000 * 12 * 10
-    assert j["value"] > 0 and np.isfinite(j["ce_after"]) and j["roofline"]["rounds"] >= 1
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == ("strong" if strong else "weak")
+    assert j["config"]["samples_per_step"] == (20001 * 6 * 10 if strong else 2 * 6000 * 12 * 10)
+    assert j["value"] > 0 and np.isfinite(j["ce_after"]) and j["roofline"]["launches_per_batch"] >= 1
+
+
+def test_library_communicator_world_one(A, oracle, graph):
+    """The RCCL entry points of the C ABI (ae_comm_*, include/annembed_hip.h) with one rank -- all that one GPU allows: the
+    communicator initialises, attaches to a rounds-mode handle whose range tiles [0, n), the in-batch exchanges are no-ops
+    that leave the result equal to the same run without a communicator, the all-reduce returns its input; attaching to a
+    faithful-mode handle (which cannot shard) or to a partial range is refused."""
+    from annembed_amd.dist import LibraryComm
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    y0 = oracle.set_data_box(np.random.default_rng(4).normal(size=(2500, 2)).astype(np.float32), 10.0)
+    comm = LibraryComm(0, 1)
+    par = A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD)
+    a, b = A.EntropyOptim(g, npar, par, y0), A.EntropyOptim(g, npar, par, y0)
+    comm.attach(a, 4)
+    for it in (1, 2):
+        a.gradient_iteration_threaded(10 * len(nbr), 0.8, it)
+        b.gradient_iteration_threaded(10 * len(nbr), 0.8, it)
+    assert np.isfinite(a.get_embedded()).all()
+    assert abs(a.ce_compute_threaded() - b.ce_compute_threaded()) < 0.05 * b.ce_compute_threaded()  # same mode, same draws; float order of the rounds differs
+    assert comm.all_reduce_sum(1.25) == 1.25
+    with pytest.raises(A.AnnembedError):
+        comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # event-ordered: does not shard
+    with pytest.raises(A.AnnembedError):
+        comm.attach(A.EntropyOptim(g, npar, par, y0, node_lo=0, node_hi=1000), 1)  # one rank must own [0, n)
+    comm.close()

@@ -47,7 +47,7 @@ def test_embedder_params_default_matches_reference():
     p = A.EmbedderParams()
     assert (p.asked_dim, p.dmap_init, p.beta, p.b, p.scale_rho, p.grad_step) == (2, True, 1.0, 1.0, 1.0, 2.0)
     assert (p.nb_sampling_by_edge, p.nb_grad_batch, p.grad_factor, p.hierarchy_layer, p.hubness_weighting) == (10, 20, 4, 0, False)
-    assert p.seed == 4664397 and p.ce_mode == A.AE_CE_HOGWILD and p.ce_sampler == A.AE_SAMPLER_ROWCDF
+    assert p.seed == 4664397 and p.ce_mode == A.AE_CE_AUTO and p.ce_sampler == A.AE_SAMPLER_ROWCDF
     p.set_dim(5)
     p.set_nb_gradient_batch(7)
     assert p.c().asked_dim == 5 and p.c().nb_grad_batch == 7
@@ -107,32 +107,30 @@ def test_shard_ranges():
     assert sample_offset(0) == 0 and sample_offset(5) == 5 << 24
 
 
-def test_committed_bench_evidence_is_well_formed():
-    """the bench lines kept under profiles/ carry every field of the bench contract (the GPU box regenerates them;
-    this only guards the schema and the arithmetic of the committed evidence)"""
-    import glob
-    import json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_r*_v*.json")))
-    assert files, "no committed bench line"
-    with open(files[-1]) as f:
-        j = json.loads(f.read().strip().splitlines()[-1])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline", "cpu_baseline"):
-        assert key in j, key
-    assert j["config"]["workload"] and j["higher_is_better"] is True and j["vs_baseline"] is None and j["scaling"] == "weak"
-    r = j["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in r, key
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    # achieved = algorithmic bytes per launch / average launch duration
-    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_avg_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
-    c = j["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
-        assert key in c, key
-    assert c["kind"] in ("port", "reference") and c["unit"] == j["unit"]
-    pmc = os.path.join(os.path.dirname(files[-1]), "pmc_ce_round.json")
-    with open(pmc) as f:
-        assert abs(json.load(f)["hbm_bytes_per_launch"] - r["traffic"]) < 0.05 * r["traffic"]
+def test_bench_roofline_arithmetic_and_permuted_lattice():
+    """bench.py's own code (no GPU): the roofline object is algorithmic bytes per launch / average launch duration with
+    B = 24 + 4 k + 36 d bytes per SGD sample; the scale graph is a k-regular ring lattice whose node ids are a
+    random permutation of the ring positions (edges are NOT memory-local), identical for the same seed on every rank."""
+    import bench
+    run = dict(rounds=15, kernel_ms=0.75, ms_per_step=0.8, nb_sample=7_200_000, batches_timed=20, mode=0)
+    r = bench.roofline_of(run, 12, 2)
+    assert r["bytes_per_sample"] == 24 + 48 + 72 and r["launches_per_batch"] == 15
+    assert abs(r["bytes_per_launch"] - 144 * 7_200_000 / 15) < 1e-6
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_avg_ms"] * 1e-3) / 1e9) < 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-15 and r["bound"] == "hbm" and r["traffic"] is None
+    n, k = 5000, 6
+    ip, nb, ds = bench.lattice_graph(n, k, seed=7, permute=True)
+    ip2, nb2, ds2 = bench.lattice_graph(n, k, seed=7, permute=True)
+    assert np.array_equal(nb, nb2) and np.array_equal(ds, ds2) and len(nb) == n * k and ip[-1] == n * k
+    rows = nb.reshape(n, k).astype(np.int64)
+    assert (rows != np.arange(n)[:, None]).all() and all(len(set(r_)) == k for r_ in rows[:200])
+    assert np.bincount(nb, minlength=n).min() == k and np.bincount(nb, minlength=n).max() == k  # a permuted REGULAR graph
+    assert (np.diff(ds.reshape(n, k), axis=1) >= 0).all()
+    gap = np.abs(rows - np.arange(n)[:, None])
+    assert np.median(np.minimum(gap, n - gap)) > n / 10  # neighbours are far apart in memory ...
+    _, nb0, _ = bench.lattice_graph(n, k, seed=7, permute=False)
+    gap0 = np.abs(nb0.reshape(n, k).astype(np.int64) - np.arange(n)[:, None])
+    assert np.minimum(gap0, n - gap0).max() <= 3  # ... which they are not on the plain ring
 
 
 def test_oracle_knn_definition_matches_f64_bruteforce():
