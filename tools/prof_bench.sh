@@ -7,9 +7,11 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_sq.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_pmc_write.log 2>&1
+# counters: their own passes, the C2 workload only (the scale shapes instantiate the same kernel templates)
+PMCARGS="--no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd"
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_sq.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_write.log 2>&1
 cd $OUT
 ls -R . | head -50
 python3 - <<'PY'
@@ -43,15 +45,15 @@ def avg(d, counter, needle):
             if needle in r['Kernel_Name'] and r['Counter_Name'] == counter:
                 tot += float(r['Counter_Value']); seen.add(r['Dispatch_Id'])
     return (tot / len(seen), len(seen)) if seen else (None, 0)
-needle = 'ce_round_node_kernel'
-fetch, nf = avg('pmc_fetch', 'FETCH_SIZE', needle)
-write, nw = avg('pmc_write', 'WRITE_SIZE', needle)
-if fetch is not None and write is not None:
-    j = {"kernel": needle, "dispatches": nf, "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
-         "fetch_correction": 2.0, "hbm_bytes_per_launch": 2.0 * fetch * 1024 + write * 1024,
-         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu-baseline`; gfx950 FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"}
-    json.dump(j, open('pmc_ce_round.json', 'w'), indent=1)
-    print(j)
+for needle, fname in (('ce_event_window_kernel', 'pmc_ce_event.json'), ('ce_round_node_kernel', 'pmc_ce_round.json')):
+    fetch, nf = avg('pmc_fetch', 'FETCH_SIZE', needle)
+    write, nw = avg('pmc_write', 'WRITE_SIZE', needle)
+    if fetch is not None and write is not None:
+        j = {"kernel": needle, "dispatches": nf, "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+             "fetch_correction": 2.0, "hbm_bytes_per_launch": 2.0 * fetch * 1024 + write * 1024,
+             "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd` (C2 workload); gfx950 FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"}
+        json.dump(j, open(fname, 'w'), indent=1)
+        print(j)
 PY
 # keep only small summaries
 find $OUT -name "*.db" -delete
