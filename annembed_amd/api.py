@@ -234,6 +234,14 @@ class KGraphProjection(_Handle):
     def get_small_graph(self):
         return self.small
 
+    def projection_init(self, y_small, seed=4664397):
+        """the initial embedding h_embed gives the large graph (src/embedder.rs:245-269)"""
+        y_small = _f32(y_small)
+        n_large = self.large.get_nb_nodes()
+        y0 = np.zeros((n_large, y_small.shape[1]), np.float32)
+        check(L.load().ae_projection_init(self._h, ptr(y_small), y_small.shape[1], seed, ptr(y0)))
+        return y0
+
     def get_large_graph(self):
         return self.large
 

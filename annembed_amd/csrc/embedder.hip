@@ -179,6 +179,22 @@ void h_embed_device(const ae_kgraph_projection* proj, const ae_embedder_params& 
 
 extern "C" {
 
+// stage-level entry of the projection initialisation (embedder.rs:245-269): the first n_small rows are y_small, every other
+// node starts at its projection's row plus clip(N(0,1) sqrt(proj_dist / median / dim), 2).  Host arrays in, host array out.
+int32_t ae_projection_init(const ae_kgraph_projection* proj, const float* y_small, uint64_t dim, uint64_t seed, float* y0) {
+    return guard([&] {
+        require_device();
+        if (!proj || !y_small || !y0 || dim == 0) fail(AE_ERR_INVALID_ARG, "bad argument");
+        const uint64_t n_small = proj->small_graph->n, n_large = proj->large_graph->n;
+        DevBuf<float> ys(n_small * dim), out(n_large * dim);
+        ys.upload(y_small, n_small * dim);
+        hipLaunchKernelGGL(projection_init_kernel, dim3(blocks_for(n_large * dim, 256)), dim3(256), 0, stream(), (const float*)ys.p, n_small,
+                           n_large, (uint32_t)dim, proj->proj_node.p, proj->proj_dist.p, proj->median_dist, seed, out.p);
+        check_launch("projection_init");
+        out.download(y0, n_large * dim);
+    });
+}
+
 int32_t ae_embedder_new(const ae_kgraph* g, const ae_embedder_params* params, ae_embedder** out) {
     return guard([&] {
         if (!g || !params || !out) fail(AE_ERR_INVALID_ARG, "null argument");

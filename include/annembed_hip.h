@@ -200,6 +200,8 @@ int32_t ae_kgraph_projection_create(const ae_kgraph *small, const ae_kgraph *lar
                                     const uint32_t *proj_node, const float *proj_dist,
                                     ae_kgraph_projection **out);
 int32_t ae_kgraph_projection_destroy(ae_kgraph_projection *p);
+/* h_embed's projection initialisation alone (src/embedder.rs:245-269): y_small [n_small x dim] -> y0 [n_large x dim], host arrays */
+int32_t ae_projection_init(const ae_kgraph_projection *proj, const float *y_small, uint64_t dim, uint64_t seed, float *y0);
 
 /* ------------------------------------------------------------------------------------------- */
 /* a2. to_proba_edges -- src/tools/kdumap.rs:26-116, 132-235                                    */

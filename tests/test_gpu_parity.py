@@ -13,6 +13,7 @@ from tests.util import gaussian_mixture, knn_graph, synthetic_graph
 pytestmark = pytest.mark.gpu
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz"))
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.npz"))  # second restatement: tests/golden/make_golden_v2.py
 
 
 @pytest.fixture(scope="module")
@@ -507,6 +508,59 @@ def test_dmap_embedding_parity_up_to_sign(A, oracle, graph):
         # sigma_2 - sigma_3 = 2.2e-5 on this graph: f32 roundoff (1e-7) of two different SVD algorithms / summation orders
         # rotates the pair by ~5e-3; measured 1.7e-3 .. 2.1e-3
         assert err < 6e-3, (c, err)
+
+
+def test_dense_laplacian_and_y0_golden_v2(A):
+    """The dense branch (n <= 5000) of the laplacian, do_svd and the diffusion-map coordinates on the golden graph with healthy
+    spectral gaps (three clusters in a chain: sigma_k - sigma_k+1 = 4e-3, 1.2e-2, 2e-2), HIP path vs the numpy restatement of
+    tests/golden/make_golden_v2.py: q / beta scales / normalizer 1e-5, kernel 1e-5 of its largest entry, sigma[0..20] 2e-5,
+    Y0 up to the sign of each column at 1e-4 of the box -- the north star's coordinate tolerance (the 6e-3 of the test above is
+    a property of THAT graph's 2.2e-5 gap)."""
+    g = A.KGraph(GOLD2["gap_indptr"], GOLD2["gap_nbr"], GOLD2["gap_dist"])
+    dm = A.DiffusionMaps(A.DiffusionParams(2, 5.0, 12))
+    lap = dm.laplacian_from_kgraph(g, force_repr=1)
+    assert not lap.is_csr()
+    v = lap.get_vectors()
+    assert _relmax(v["q_density"], GOLD2["dense_q"]) < 1e-5 and _relmax(v["beta_scales"], GOLD2["dense_beta_scales"]) < 1e-5
+    assert _relmax(v["normalizer"], GOLD2["dense_normalizer"]) < 1e-5
+    assert np.max(np.abs(lap.get_sym_kernel() - GOLD2["dense_lap"])) < 1e-5 * np.abs(GOLD2["dense_lap"]).max()
+    sv = lap.do_svd()
+    assert np.max(np.abs(sv.s[:20] - GOLD2["dense_sigma"])) < 2e-5
+    y0 = dm.embed_from_kgraph(g)
+    assert y0.shape == GOLD2["dense_y0"].shape
+    for c in range(2):
+        nz = np.nonzero(GOLD2["dense_y0"][:, c])[0][0]
+        sgn = np.sign(y0[nz, c])
+        assert np.max(np.abs(sgn * y0[:, c] - GOLD2["dense_y0"][:, c])) < 1e-4 * np.abs(GOLD2["dense_y0"]).max(), c
+
+
+@pytest.mark.parametrize("b,key", [(1.0, "sgd_y_after_b1"), (0.8, "sgd_y_after_b08")])
+def test_sequential_sgd_golden_v2(A, b, key):
+    """1 000 sequential SGD samples (src/embedder.rs:1167-1302) from the golden start with the build's Philox stream:
+    AE_CE_SEQUENTIAL against the numpy restatement's committed vectors -- the plan (7 nodes of every sample) and the
+    coordinates, bit for bit, b = 1 and b = 0.8 (the oracle is checked against the same vectors on the CPU)."""
+    g = A.KGraph(GOLD["g_indptr"], GOLD["g_nbr"], GOLD["g_dist"])
+    npar = A.NodeParams.from_host(g, GOLD["proba"], GOLD["scale"])
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(ce_mode=A.AE_CE_SEQUENTIAL, b=b), GOLD["y_box"])
+    nodes, _ = eo.plan(0, 1000, int(GOLD2["sgd_iter"]))
+    assert np.array_equal(nodes, GOLD2["sgd_plan"])
+    eo.gradient_iteration_threaded(1000, float(GOLD2["sgd_step"]), int(GOLD2["sgd_iter"]))
+    assert np.array_equal(eo.get_embedded(), GOLD2[key])
+
+
+def test_projection_init_golden_v2(A):
+    """h_embed's projection initialisation alone (src/embedder.rs:245-269) through ae_projection_init, against the numpy
+    restatement: 2e-6 absolute (libm vs device logf / cosf / sinf on values of order 1); the projected rows stay within the
+    reference's clip(., 2) of their projection's row"""
+    x = np.random.default_rng(3).normal(size=(40, 3)).astype(np.float32)
+    ip_s, nb_s, d_s = knn_graph(x, 5)
+    small = A.KGraph(ip_s, nb_s, d_s)
+    large = A.KGraph(GOLD2["gap_indptr"], GOLD2["gap_nbr"], GOLD2["gap_dist"])
+    proj = A.KGraphProjection(small, large, GOLD2["proj_node"], GOLD2["proj_dist"])
+    y0 = proj.projection_init(GOLD2["proj_y_small"], 4664397)
+    assert np.array_equal(y0[:40], GOLD2["proj_y_small"])
+    assert np.max(np.abs(y0 - GOLD2["proj_y0"])) < 2e-6
+    assert np.max(np.abs(y0[40:] - GOLD2["proj_y_small"][GOLD2["proj_node"][40:]])) <= 2.0 + 1e-6
 
 
 def test_dmap_errors(A, graph):

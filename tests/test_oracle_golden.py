@@ -268,3 +268,54 @@ def test_hubness_and_sampler_weights(oracle):
     assert c.sum() == len(nb) and np.array_equal(c, np.bincount(nb, minlength=len(ip) - 1))
     w = oracle.node_sampler_weights(c)
     assert abs(w.mean() - 1.0) < 1e-5 and w.min() > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# golden_v2: the second, independent restatement (tests/golden/make_golden_v2.py) of the hot function, the dense-branch
+# laplacian, the diffusion-map coordinates and the projection initialisation
+# ------------------------------------------------------------------------------------------------
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.npz"))
+
+
+@pytest.mark.parametrize("b,key", [(1.0, "sgd_y_after_b1"), (0.8, "sgd_y_after_b08")])
+def test_sgd_sample_golden_bit_exact(oracle, b, key):
+    """ce_optim_edge_shannon (src/embedder.rs:1167-1302): the plan (Philox stream, row cdf, rejection of the 5 negatives) and the
+    coordinates after 1 000 sequential samples, C oracle vs the numpy restatement: bit for bit, b = 1 and b = 0.8"""
+    eo = oracle.EntropyOptim(GOLD["g_indptr"], GOLD["g_nbr"], GOLD["proba"], GOLD["scale"], GOLD["y_box"], b=b)
+    plan = np.array([eo.plan(s, int(GOLD2["sgd_iter"]))[0] for s in range(1000)])
+    assert np.array_equal(plan, GOLD2["sgd_plan"])
+    eo.gradient_iteration(1000, float(GOLD2["sgd_step"]), int(GOLD2["sgd_iter"]))
+    assert np.array_equal(eo.y, GOLD2[key])
+
+
+def test_dense_laplacian_and_dmap_coordinates_golden(oracle):
+    """dense branch (n <= 5000) of kernel0_to_density / compute_laplacian (src/diffmaps.rs:427-508, 855-892), do_svd and
+    embed_from_laplacian (:1145-1243) against the numpy restatement.  The row sums are f32 sums whose order the two
+    restatements choose differently (ndarray's eight-lane fold vs numpy's pairwise sum): 2e-6 relative on q, 1e-5 on the
+    normalised kernel; sigma[0..20] at 1e-5; Y0 at 1e-4 of the box up to the sign of each column (spectral gaps of this graph:
+    GOLD2["dense_gap"]: 4e-3, 1.2e-2, 2e-2)."""
+    dp = oracle.DiffusionParams(2, 5.0, 12)
+    rc, lap = oracle.dmap_laplacian(GOLD2["gap_indptr"], GOLD2["gap_nbr"], GOLD2["gap_dist"], 6, dp, force_repr=1)
+    assert rc == 0 and not lap["is_csr"]
+    assert np.max(np.abs(lap["q"] - GOLD2["dense_q"]) / GOLD2["dense_q"]) < 2e-6
+    assert np.max(np.abs(lap["beta_scales"] - GOLD2["dense_beta_scales"]) / GOLD2["dense_beta_scales"]) < 2e-6
+    assert np.max(np.abs(lap["normalizer"] - GOLD2["dense_normalizer"]) / GOLD2["dense_normalizer"]) < 5e-6
+    assert np.max(np.abs(lap["dense"] - GOLD2["dense_lap"])) < 1e-5 * np.abs(GOLD2["dense_lap"]).max()
+    s, u = oracle.laplacian_do_svd(lap)
+    assert np.max(np.abs(s[:20] - GOLD2["dense_sigma"])) < 1e-5
+    assert GOLD2["dense_gap"].min() > 4e-3
+    rc, y0 = oracle.embed_from_svd(s, u, lap["normalizer"], lap["normed_scales"], 2, 5.0)
+    assert rc == 0
+    for c in range(2):
+        nz = np.nonzero(GOLD2["dense_y0"][:, c])[0][0]
+        sgn = np.sign(y0[nz, c])
+        assert np.max(np.abs(sgn * y0[:, c] - GOLD2["dense_y0"][:, c])) < 1e-4 * np.abs(GOLD2["dense_y0"]).max()
+
+
+def test_projection_init_golden(oracle):
+    """h_embed's projection initialisation (src/embedder.rs:245-269), Philox + Box-Muller noise: C oracle vs numpy restatement.
+    logf / cosf / sinf are the C library's in one and numpy's in the other: 1e-6 absolute on values of order 1."""
+    y0 = oracle.projection_init(GOLD2["proj_y_small"], 300, GOLD2["proj_node"], GOLD2["proj_dist"], np.float32(GOLD2["proj_median"]), 4664397)
+    assert np.array_equal(y0[:40], GOLD2["proj_y_small"])
+    assert np.max(np.abs(y0 - GOLD2["proj_y0"])) < 2e-6
+    assert np.max(np.abs(y0[40:] - GOLD2["proj_y_small"][GOLD2["proj_node"][40:]])) <= 2.0 + 1e-6
