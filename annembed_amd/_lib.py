@@ -117,6 +117,7 @@ SIGNATURES = {
     "ae_entropy_optim_destroy": [_vp],
     "ae_entropy_optim_get_nb_edges": [_vp, _P(_u64)],
     "ae_entropy_optim_get_ce_mode": [_vp, _P(C.c_uint32)],
+    "ae_entropy_optim_dataflow_time": [_vp, _P(C.c_double), _P(_u64)],
     "ae_projection_init": [_vp, _vp, _u64, _u64, _vp],
     "ae_comm_unique_id": [_vp],
     "ae_comm_init": [C.c_int32, C.c_int32, _vp, _P(_vp)],

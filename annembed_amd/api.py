@@ -349,6 +349,11 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_device_coords(self._h, C.byref(p), C.byref(n), C.byref(d)))
         return p.value, n.value, d.value
 
+    def dataflow_time(self):
+        ms, cnt = C.c_double(), C.c_uint64()
+        check(L.load().ae_entropy_optim_dataflow_time(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def kernel_time(self):
         ms, cnt = C.c_double(), C.c_uint64()
         check(L.load().ae_entropy_optim_kernel_time(self._h, C.byref(ms), C.byref(cnt)))

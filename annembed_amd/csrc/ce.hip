@@ -608,7 +608,7 @@ static void check_err_flag(ae_entropy_optim* o) {
 }
 
 template <int DIM>
-static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
+static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
     if constexpr (DIM > 0) {
         static int blocks_per_cu = 0, cus = 0;
         if (!blocks_per_cu) {
@@ -618,11 +618,11 @@ static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const 
             AE_HIP(hipGetDeviceProperties(&prop, dev));
             cus = prop.multiProcessorCount;
         }
-        const unsigned bs = getenv("AE_DF_BLOCK") ? (unsigned)atoi(getenv("AE_DF_BLOCK")) : 128u;
+        const unsigned bs = debug_knob("AE_DF_BLOCK") ? (unsigned)atoi(debug_knob("AE_DF_BLOCK")) : 128u;
         int bpc = 0;
         AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, (int)bs, 0));
         blocks_per_cu = std::max(1, std::min(bpc, 8));
-        const uint64_t blocks_cap = (uint64_t)blocks_per_cu * cus;
+        const uint64_t blocks_cap = (uint64_t)((double)blocks_per_cu * cus * 0.9);
         // The run is bound by the dependency chain: per hop one trip of the carrying wave through its loop (poll round
         // trip + the f64 arithmetic of the lanes that advance).  Enough carrier lanes to keep every chain moving
         // (~512 samples per carrier, at least 16 K carriers), spread thinly over the waves (every 8th lane) while the
@@ -632,59 +632,86 @@ static void launch_dataflow(ae_entropy_optim* o, uint64_t S, double step, const 
         const uint64_t carriers_want = std::min<uint64_t>(S, std::max<uint64_t>(16384, S / 512));
         uint32_t lane_stride = 8;
         while (lane_stride > 1 && blocks_cap * bs / lane_stride < carriers_want) lane_stride /= 2;
-        if (getenv("AE_DF_LANE_STRIDE")) lane_stride = (uint32_t)atoi(getenv("AE_DF_LANE_STRIDE"));
+        if (debug_knob("AE_DF_LANE_STRIDE")) lane_stride = (uint32_t)atoi(debug_knob("AE_DF_LANE_STRIDE"));
         if (lane_stride == 0 || (bs % lane_stride) != 0) lane_stride = 1;
         unsigned grid = (unsigned)std::min<uint64_t>(blocks_cap, std::max<uint64_t>(1, (carriers_want * lane_stride + bs - 1) / bs));
-        if (getenv("AE_DF_GRID")) grid = (unsigned)std::min<uint64_t>(blocks_cap, std::max(1, atoi(getenv("AE_DF_GRID"))));
+        if (debug_knob("AE_DF_GRID")) grid = (unsigned)std::min<uint64_t>(blocks_cap, std::max(1, atoi(debug_knob("AE_DF_GRID"))));
         CeDev dev = o->dev;
-        const uint32_t* pn = o->plan_nodes.p;
-        const float* pw = o->plan_w.p;
-        const uint32_t* pred = o->df_pred.p;
+        const uint32_t* pn = st.plan_nodes.p;
+        const float* pw = st.plan_w.p;
+        const uint32_t* pred = st.pred.p;
         float* ver = o->df_ver.p;
         unsigned int* err = o->err.p;
         void* args[] = {&dev, &S, &pn, &pw, &pred, &ver, &step, &err, &lane_stride};
         AE_HIP(hipMemsetAsync(ver, 0xFF, sizeof(float) * S * 2 * DIM, stream()));  // every version "unpublished"
-        // cooperative launch: the runtime refuses a grid that cannot be resident at once (the progress argument needs it)
-        AE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<void*>(ce_dataflow_kernel<DIM>), dim3(grid), dim3(bs), args, 0, stream()));
+        // The progress argument needs every block resident: the grid is sized from the occupancy query with a margin (the
+        // query can be one block per CU high).  A plain launch: same residency as a cooperative one without its +15-19 us.
+        if (o->df_events.size() >= 64) {  // nobody asks for the timings: keep the list short
+            (void)hipEventDestroy(o->df_events.front().first);
+            (void)hipEventDestroy(o->df_events.front().second);
+            o->df_events.erase(o->df_events.begin());
+        }
+        hipEvent_t e0, e1;
+        AE_HIP(hipEventCreate(&e0));
+        AE_HIP(hipEventCreate(&e1));
+        AE_HIP(hipEventRecord(e0, stream()));
+        (void)args;
+        hipLaunchKernelGGL((ce_dataflow_kernel<DIM>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, lane_stride);
+        AE_HIP(hipEventRecord(e1, stream()));
+        o->df_events.emplace_back(e0, e1);
         hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
                            (const float*)ver, o->dev.y);
     }
 }
 
-// AE_CE_SEQUENTIAL scheduled on the device (see the dataflow kernels above)
-static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter) {
-    if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
-    const uint32_t dim = o->dev.dim;
-    if (o->plan_nodes.n < S * 7) o->plan_nodes.alloc(S * 7);
-    if (o->plan_w.n < S) o->plan_w.alloc(S);
-    if (o->df_pred.n < S * 7) o->df_pred.alloc(S * 7);
-    if (o->df_ver.n < S * 2 * dim) o->df_ver.alloc(S * 2 * dim);
-    if (o->df_keys0.n < 2 * S) { o->df_keys0.alloc(2 * S); o->df_keys1.alloc(2 * S); }
-    if (o->df_rowptr.n < o->dev.n + 1) o->df_rowptr.alloc(o->dev.n + 1);
-    const bool prof = getenv("AE_CE_PROF") != nullptr;
-    auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    launch_plan(o, o->sample_offset, S, iter, o->plan_nodes.p, o->plan_w.p);
-    const double t1 = now();
+// everything of a sequential batch that depends only on (graph, RNG stream, batch index): the plan of its samples, their write
+// events sorted by node, every read's predecessor.  Runs on whatever stream() is current.
+static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, uint32_t iter) {
+    if (st.plan_nodes.n < S * 7) st.plan_nodes.alloc(S * 7);
+    if (st.plan_w.n < S) st.plan_w.alloc(S);
+    if (st.pred.n < S * 7) st.pred.alloc(S * 7);
+    if (st.keys0.n < 2 * S) { st.keys0.alloc(2 * S); st.keys1.alloc(2 * S); }
+    if (st.rowptr.n < o->dev.n + 1) st.rowptr.alloc(o->dev.n + 1);
+    launch_plan(o, o->sample_offset, S, iter, st.plan_nodes.p, st.plan_w.p);
     // each key buffer holds 2 S node keys followed by 2 S version ids
-    uint32_t* k0 = reinterpret_cast<uint32_t*>(o->df_keys0.p);
-    uint32_t* k1 = reinterpret_cast<uint32_t*>(o->df_keys1.p);
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(st.keys0.p);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(st.keys1.p);
     uint32_t *v0 = k0 + 2 * S, *v1 = k1 + 2 * S;
-    hipLaunchKernelGGL(df_write_keys_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p, k0, v0);
+    hipLaunchKernelGGL(df_write_keys_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p, k0, v0);
     unsigned node_bits = 1;
     while (node_bits < 32 && (o->dev.n >> node_bits)) node_bits++;
     sort_pairs_u32_u32(k0, k1, v0, v1, 2 * S, node_bits);
     hipLaunchKernelGGL(df_rowptr_kernel, dim3(blocks_for(o->dev.n + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)k1, 2 * S,
-                       (uint64_t)o->dev.n, o->df_rowptr.p);
-    hipLaunchKernelGGL(df_pred_kernel, dim3(blocks_for(S * 7, 256)), dim3(256), 0, stream(), S, (const uint32_t*)o->plan_nodes.p,
-                       (const uint32_t*)v1, (const uint64_t*)o->df_rowptr.p, o->df_pred.p);
+                       (uint64_t)o->dev.n, st.rowptr.p);
+    hipLaunchKernelGGL(df_pred_kernel, dim3(blocks_for(S * 7, 256)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
+                       (const uint32_t*)v1, (const uint64_t*)st.rowptr.p, st.pred.p);
     check_launch("df_pred");
-    const double t2 = now();
-    AE_DISPATCH_DIM(dim, launch_dataflow, o, S, step, (const uint64_t*)o->df_rowptr.p, (const uint32_t*)v1);
+}
+
+// AE_CE_SEQUENTIAL scheduled on the device (see the dataflow kernels above).
+// (Tried and dropped: preparing the set of batch b + 1 on a second stream while the dataflow kernel of batch b runs -- the
+// preparation depends only on graph, RNG stream and batch index.  The kernels do overlap, but the latency-bound dataflow slows
+// by what the overlap saves: C2 11.3 -> 11.5 ms per batch, C3 shape 68.6 -> 69.0 ms, dataflow kernel alone 14.9 -> 21.7 ms.)
+static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter) {
+    if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
+    const uint32_t dim = o->dev.dim;
+    if (o->df_ver.n < S * 2 * dim) o->df_ver.alloc(S * 2 * dim);
+    const bool prof = debug_knob("AE_CE_PROF") != nullptr;
+    auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    ae_entropy_optim::DfSet& st = o->df_set;
+    df_prepare_set(o, st, S, iter);
+    const double t1 = now();
+    uint32_t* v1 = reinterpret_cast<uint32_t*>(st.keys1.p) + 2 * S;
+    if (dim == 2) launch_dataflow<2>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    else if (dim == 3) launch_dataflow<3>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    else if (dim == 4) launch_dataflow<4>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    else if (dim == 8) launch_dataflow<8>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    else if (dim == 16) launch_dataflow<16>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
     check_launch("ce_dataflow");
     sync();
-    if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan %.2f ms, sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
-                      (unsigned long long)S, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now() - t2) * 1e3);
+    if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan + sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
+                      (unsigned long long)S, (t1 - t0) * 1e3, (now() - t1) * 1e3);
     unsigned int h = 0;
     o->err.download(&h, 1);
     if (h & 8u) fail(AE_ERR_STATE, "sequential dataflow kernel: poll budget exceeded (scheduling invariant violated)");
@@ -694,7 +721,7 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
 static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
     // device-scheduled form for the instantiated dimensions; AE_CE_SEQ_LEVELS=1 keeps the host level schedule (A/B)
     const uint32_t d = o->dev.dim;
-    if ((d == 2 || d == 3 || d == 4 || d == 8 || d == 16) && !getenv("AE_CE_SEQ_LEVELS")) {
+    if ((d == 2 || d == 3 || d == 4 || d == 8 || d == 16) && !debug_knob("AE_CE_SEQ_LEVELS")) {
         run_sequential_dataflow(o, nb_sample, step, iter);
         return;
     }
@@ -703,7 +730,7 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
     if (o->plan_w.n < nb_sample) o->plan_w.alloc(nb_sample);
     if (o->order.n < nb_sample) o->order.alloc(nb_sample);
     launch_plan(o, o->sample_offset, nb_sample, iter, o->plan_nodes.p, o->plan_w.p);
-    const bool prof = getenv("AE_CE_PROF") != nullptr;
+    const bool prof = debug_knob("AE_CE_PROF") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     std::vector<uint32_t> nodes(nb_sample * 7);
@@ -851,21 +878,19 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
             d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
         }
         sync();
-        // AE_CE_AUTO: the faithful mode that fits -- event-ordered, else sequential-equivalent, else (sharded range, other
-        // dimensions) the rounds mode
+        // AE_CE_AUTO: the sequential-equivalent dataflow (exact, reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one
+        // device, < 2^31 samples per batch --, else the event-ordered kernel when IT fits, else the rounds mode
         const bool sharded = node_lo != 0 || node_hi != n;
         const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
         uint32_t mode = params->ce_mode;
         if (mode > AE_CE_AUTO) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
-        if (mode == AE_CE_AUTO && (sharded || !df_dim)) mode = AE_CE_HOGWILD;
-        if (mode == AE_CE_AUTO || mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
-        if (mode == AE_CE_AUTO || mode == AE_CE_EVENT) {
-            ce_event_prepare(o.get());
-            if (mode == AE_CE_AUTO) {
-                mode = ce_event_unsupported(o.get()) ? AE_CE_SEQUENTIAL : AE_CE_EVENT;
-                if (mode == AE_CE_SEQUENTIAL && params->nb_sampling_by_edge * (edge_hi - edge_lo) >= (1ull << 31)) mode = AE_CE_HOGWILD;
-            }
+        if (mode == AE_CE_AUTO) {
+            if (!sharded && df_dim && params->nb_sampling_by_edge * (edge_hi - edge_lo) < (1ull << 31)) mode = AE_CE_SEQUENTIAL;
+            else if (sharded || !df_dim) mode = AE_CE_HOGWILD;
+            else mode = AE_CE_EVENT;  // (unsupported sizes fail at the first batch with the reason)
         }
+        if (mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
+        if (mode == AE_CE_EVENT) ce_event_prepare(o.get());
         o->params.ce_mode = mode;
         return o.release();
     }
@@ -919,22 +944,40 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
         if (nb_sample == 0) return;
         if (nb_sample >= (1ull << 56)) fail(AE_ERR_INVALID_ARG, "too many samples");
-        if (o->params.ce_mode == AE_CE_SEQUENTIAL) {
-            run_sequential(o, nb_sample, grad_step, (uint32_t)iter);
-            return;
+        if (o->params.ce_mode == AE_CE_EVENT) {
+            if (const char* why = ce_event_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_EVENT: %s; use AE_CE_SEQUENTIAL or AE_CE_HOGWILD", why);
+        } else if (o->params.ce_mode != AE_CE_SAMPLE_RACY && o->params.ce_mode != AE_CE_SEQUENTIAL && !ce_node_supports(o)) {
+            fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
+        }
+        // one event pair per timed batch, created after validation; ae_entropy_optim_kernel_time drains the list -- a caller that
+        // never asks keeps at most kMaxTimedBatches pairs (older batches are folded into a running sum)
+        constexpr size_t kMaxTimedBatches = 64;
+        if (o->events.size() >= kMaxTimedBatches) {
+            AE_HIP(hipEventSynchronize(o->events.front().second));
+            float ms = 0.f;
+            AE_HIP(hipEventElapsedTime(&ms, o->events.front().first, o->events.front().second));
+            o->events_folded_ms += ms;
+            o->events_folded++;
+            (void)hipEventDestroy(o->events.front().first);
+            (void)hipEventDestroy(o->events.front().second);
+            o->events.erase(o->events.begin());
         }
         hipEvent_t e0, e1;
         AE_HIP(hipEventCreate(&e0));
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
+        if (o->params.ce_mode == AE_CE_SEQUENTIAL) {
+            run_sequential(o, nb_sample, grad_step, (uint32_t)iter);
+            AE_HIP(hipEventRecord(e1, stream()));
+            o->events.emplace_back(e0, e1);
+            return;
+        }
         if (o->params.ce_mode == AE_CE_EVENT) {
             ce_event_gradient_iteration(o, nb_sample, grad_step, (uint32_t)iter);
             AE_HIP(hipEventRecord(e1, stream()));
             o->events.emplace_back(e0, e1);
             return;
         }
-        if (o->params.ce_mode != AE_CE_SAMPLE_RACY && !ce_node_supports(o))
-            fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
         if (o->params.ce_mode == AE_CE_SAMPLE_RACY) {
             AE_DISPATCH_DIM(o->dev.dim, launch_hogwild, o, nb_sample, grad_step, (uint32_t)iter);
             check_launch("ce_sgd_hogwild");
@@ -978,7 +1021,10 @@ int32_t ae_entropy_optim_kernel_time(ae_entropy_optim* o, double* avg_ms, uint64
         require_device();
         if (!o || !avg_ms || !launches) fail(AE_ERR_INVALID_ARG, "null argument");
         sync();
-        double tot = 0.;
+        double tot = o->events_folded_ms;
+        const uint64_t folded = o->events_folded;
+        o->events_folded_ms = 0.;
+        o->events_folded = 0;
         for (auto& e : o->events) {
             float ms = 0.f;
             AE_HIP(hipEventElapsedTime(&ms, e.first, e.second));
@@ -986,10 +1032,29 @@ int32_t ae_entropy_optim_kernel_time(ae_entropy_optim* o, double* avg_ms, uint64
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
-        *launches = o->events.size();
-        *avg_ms = o->events.empty() ? 0. : tot / (double)o->events.size();
+        *launches = o->events.size() + folded;
+        *avg_ms = *launches ? tot / (double)*launches : 0.;
         o->events.clear();
         check_err_flag(o);
+    });
+}
+
+int32_t ae_entropy_optim_dataflow_time(ae_entropy_optim* o, double* avg_ms, uint64_t* launches) {
+    return guard([&] {
+        require_device();
+        if (!o || !avg_ms || !launches) fail(AE_ERR_INVALID_ARG, "null argument");
+        sync();
+        double tot = 0.;
+        for (auto& e : o->df_events) {
+            float ms = 0.f;
+            AE_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        *launches = o->df_events.size();
+        *avg_ms = o->df_events.empty() ? 0. : tot / (double)o->df_events.size();
+        o->df_events.clear();
     });
 }
 

@@ -82,6 +82,18 @@ __device__ __forceinline__ void slot_clear(float* p) {
     }
 }
 
+// A row of the coordinate array as the memory side has it NOW: agent-scope loads.  A plain or non-temporal load may be served
+// by this XCD's L2, whose copy of a line another XCD's owner keeps rewriting is not refreshed before the launch ends (the
+// per-XCD L2s are not coherent): negatives read that way were up to a whole window old -- measured as final CE +1 ... +3 %
+// and the shortest edge-length quantiles -3 ... -12 % against the sequential loop.
+template <int DIM>
+__device__ __forceinline__ void load_row_coherent(const float* __restrict__ y, uint32_t node, float* out) {
+    float tmp[DIM];
+    (void)df_try_load_version<DIM>(y + (uint64_t)node * DIM, 0, tmp);
+#pragma unroll
+    for (int t = 0; t < DIM; t++) out[t] = tmp[t];
+}
+
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -167,7 +179,7 @@ __global__ void __launch_bounds__(64) ce_event_window_kernel(EventArgs a) {
     }
     const uint64_t tb = valid ? a.tptr[v] : 0ull, te = valid ? a.tptr[v + 1] : 0ull;
     float yv[DIM];
-    load_row_fresh<DIM>(c.y, v, yv);
+    load_row_coherent<DIM>(c.y, v, yv);
     const double scale = (double)c.emb_scale[v];
     const double S2own = scale * scale, two_step = 2. * a.step;
     const uint32_t hk = pcg_hash(pcg_hash((uint32_t)c.seed ^ 0x5bd1e995u) ^ pcg_hash(a.window_key + (uint32_t)(c.seed >> 32)));
@@ -377,7 +389,7 @@ __global__ void __launch_bounds__(64) ce_event_window_kernel(EventArgs a) {
             kk[g] = x;
         }
 #pragma unroll
-        for (int g = 0; g < 5; g++) load_row_fresh<DIM>(c.y, kk[g], nrow[g]);
+        for (int g = 0; g < 5; g++) load_row_coherent<DIM>(c.y, kk[g], nrow[g]);
         waited = 0;
     };
     while (true) {
@@ -561,7 +573,7 @@ void event_kernel(ae_entropy_optim* o, int npw, int op, const EventArgs& a, unsi
 namespace ae {
 
 // tuning / A-B switches are read only when AE_DEBUG_KNOBS is set: a release run cannot be altered from the environment
-static const char* knob(const char* name) { return getenv("AE_DEBUG_KNOBS") ? getenv(name) : nullptr; }
+static const char* knob(const char* name) { return debug_knob("AE_DEBUG_KNOBS") ? getenv(name) : nullptr; }
 
 // Graph statistics that size the windows, once per EntropyOptim (after the transposed graph exists)
 void ce_event_prepare(ae_entropy_optim* o) {
@@ -616,7 +628,12 @@ void ce_event_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const double per_node = (double)nb_sample / (double)n;
     // windows per batch: (a) the largest per-edge mean stays <= 2 (so the clamp at kSlotCap draws loses < 3e-5 of an edge's
     // samples), (b) a wave's 64 event lists fit its LDS pool with a 1.5x margin (+ 8 sigma), (c) the busiest node's list
-    // stays below the cooperative sort's limit, (d) at least 4
+    // stays below the cooperative sort's limit, (d) at least 4.  LONG windows are deliberate: lanes are coupled only through
+    // their own events; in a long window the nodes settle into advancing at a common pace (every node waits for its partners),
+    // while a short window is over before that happens -- quiet nodes rush to its end and the negatives read across the skew are
+    // stale or premature.  Measured on the Higgs-shaped 60 k graph (k = 6, 40 batches from the dmap initialisation; ratio to the
+    // sequential loop): 10-20 windows per batch CE 1.002-1.012 / quartiles within 3 %; 25-45 windows CE 1.02-1.04 / lower
+    // quartiles -6 ... -11 %; 240 windows (half an event per node and window) CE 1.006 / within 2 % again, at 1.4x the time.
     double T = 4.0;
     T = std::max(T, std::ceil(per_node * (double)o->ev_pmax / 2.0));
     T = std::max(T, std::ceil(per_node * (double)o->ev_wave_rate_max[o->ev_npw == 64 ? 0 : (o->ev_npw == 32 ? 1 : 2)] / ((double)(o->ev_npw * kPoolPerNode) / 1.5)));
@@ -644,7 +661,7 @@ void ce_event_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     a.lookahead_min = knob("AE_EV_LOOKAHEAD_MIN") ? (uint32_t)atoi(knob("AE_EV_LOOKAHEAD_MIN")) : 0u;
     static DevBuf<unsigned long long> prof_buf;
     a.prof = nullptr;
-    const bool prof = getenv("AE_CE_PROF") != nullptr;
+    const bool prof = debug_knob("AE_CE_PROF") != nullptr;
     if (prof) {
         if (!prof_buf.n) { prof_buf.alloc(8); prof_buf.zero(); }
         a.prof = prof_buf.p;

@@ -62,11 +62,19 @@ struct ae_entropy_optim {
     // sequential-mode scratch
     DevBuf<uint32_t> plan_nodes, order;
     DevBuf<float> plan_w;
-    // device-scheduled sequential mode: predecessors, row versions, sorted write events
-    DevBuf<uint32_t> df_pred;
+    // device-scheduled sequential mode: row versions, and what depends only on (graph, stream, batch): plan, sorted write
+    // events, predecessors
+    struct DfSet {
+        DevBuf<uint32_t> plan_nodes, pred;
+        DevBuf<float> plan_w;
+        DevBuf<uint64_t> keys0, keys1, rowptr;
+    };
+    DfSet df_set;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> df_events;  // around the dataflow kernel alone
     DevBuf<float> df_ver;
-    DevBuf<uint64_t> df_keys0, df_keys1, df_rowptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double events_folded_ms = 0.;
+    uint64_t events_folded = 0;
     uint64_t sample_offset = 0;
     // node-centric (owner-computes) Hogwild: transposed graph (in-edges), built at create
     DevBuf<uint64_t> tptr;
@@ -89,6 +97,7 @@ struct ae_entropy_optim {
     bool comm_equal = false;
     uint32_t comm_exchanges = 1;
     ~ae_entropy_optim() {
+        for (auto& e : df_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
 };

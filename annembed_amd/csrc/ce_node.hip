@@ -295,200 +295,6 @@ __global__ void __launch_bounds__(1024) ce_sum_tot_kernel(const uint32_t* __rest
     if (threadIdx.x == 0) *counter += red[0];
 }
 
-// ---- Fused round kernel (default for rows of <= 16 neighbours): counts, planning and replay in ONE launch per
-// round, 8 lanes per node.  Lanes draw the Poisson counts of the node's out-edges (2 per lane), lane 0 resolves
-// the sampled edge, lanes 1..5 draw one admissible negative each (the RNG work of a sample is spread over the
-// group instead of being serial), every lane fetches its row, the group replays the 6 dependent steps.  The
-// in-edge pushes are replayed from counts recomputed with the same edge-keyed Philox block (no cnt[] array, so
-// remote sources on other GPUs need no exchange).
-template <int DIM, bool B1, bool HUB>
-__global__ void __launch_bounds__(kBlock) ce_round_group_kernel(NodeArgs a) {
-    constexpr int NPB = kBlock / kGroup;        // nodes per workgroup
-    __shared__ uint32_t s_row[16 * NPB];        // [m][node in block]: exact neighbour test of a candidate
-    const CeDev c = a.c;
-    const int lane = threadIdx.x & 63;
-    const int r = lane & (kGroup - 1);
-    const int gbase = lane & ~(kGroup - 1);
-    const int nib = threadIdx.x >> 3;           // node in block
-    const uint64_t nodes_owned = c.node_hi - c.node_lo;
-    const uint64_t local = blockIdx.x * (uint64_t)NPB + (uint64_t)nib;
-    const bool valid = local < nodes_owned;
-    const uint64_t lv = valid ? local : nodes_owned - 1;
-    const uint32_t v = (uint32_t)(c.node_lo + lv);
-    uint64_t ib;
-    uint32_t k;
-    if (c.uniform_k) { ib = (uint64_t)v * c.uniform_k; k = c.uniform_k; }
-    else { ib = c.indptr[v]; k = (uint32_t)(c.indptr[v + 1] - ib); }
-    // ---- stage A: counts of the out-edges m = r and m = r + 8
-    uint32_t nbA = 0xFFFFFFFFu, nbB = 0xFFFFFFFFu, cA = 0, cB = 0;
-    float pA = 0.f, pB = 0.f;
-    if ((uint32_t)r < k) {
-        nbA = c.nbr[ib + r]; pA = c.proba[ib + r];
-        if (valid) cA = edge_count(ib + r, a.round_key, c.seed, a.unit * pA);
-    }
-    if ((uint32_t)r + 8u < k) {
-        nbB = c.nbr[ib + r + 8]; pB = c.proba[ib + r + 8];
-        if (valid) cB = edge_count(ib + r + 8, a.round_key, c.seed, a.unit * pB);
-    }
-    s_row[r * NPB + nib] = nbA;
-    s_row[(r + 8) * NPB + nib] = nbB;
-    uint32_t preA = cA, preB = cB;  // inclusive scans inside the 8-lane group
-#pragma unroll
-    for (int off = 1; off < kGroup; off <<= 1) {
-        const uint32_t oa = __shfl_up(preA, off), ob = __shfl_up(preB, off);
-        if (r >= off) { preA += oa; preB += ob; }
-    }
-    const uint32_t totA = __shfl(preA, gbase + 7);
-    const uint32_t nv = totA + __shfl(preB, gbase + 7);
-    unsigned long long sig = 0ull;  // 64-bit signature of the row: cheap "certainly not a neighbour"
-    if ((uint32_t)r < k) sig |= 1ull << (nbA & 63u);
-    if ((uint32_t)r + 8u < k) sig |= 1ull << (nbB & 63u);
-#pragma unroll
-    for (int off = 1; off < kGroup; off <<= 1) sig |= __shfl_xor(sig, off);
-    uint32_t nmax = nv;
-#pragma unroll
-    for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(nmax, off); nmax = o > nmax ? o : nmax; }
-    __syncthreads();  // s_row visible (one barrier per launch)
-    float yv[DIM], grad[DIM];
-    load_row_fresh<DIM>(c.y, v, yv);
-#pragma unroll
-    for (int q = 0; q < DIM; q++) grad[q] = 0.f;
-    const float s_v = c.emb_scale[v];
-    const float inv_s2 = rcp(s_v * s_v);
-    const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
-    // ---- stage B: the samples whose source is v
-    for (uint32_t t = 0; t < nmax; t++) {
-        const bool act = t < nv;
-        // which edge: the lane whose count interval contains t
-        const bool ownA = act && t < totA && t >= preA - cA && t < preA;
-        const uint32_t tb_ = t - totA;
-        const bool ownB = act && t >= totA && tb_ >= preB - cB && tb_ < preB;
-        const unsigned long long mA = __ballot(ownA), mB = __ballot(ownB);
-        const uint32_t gA = (uint32_t)(mA >> gbase) & 0xFFu, gB = (uint32_t)(mB >> gbase) & 0xFFu;
-        const int srcA = gbase + (gA ? __ffs(gA) - 1 : 0), srcB = gbase + (gB ? __ffs(gB) - 1 : 0);
-        const uint32_t jA = __shfl(nbA, srcA), jB = __shfl(nbB, srcB);
-        const float wA = __shfl(pA, srcA), wB = __shfl(pB, srcB);
-        const uint32_t j = gA ? jA : jB;
-        const float w = gA ? wA : wB;
-        uint32_t idx = j;  // lane 0: the sampled neighbour; lanes 1..5: one admissible negative each (:1241-1253)
-        if (act && r >= 1 && r <= 5) {
-            const uint32_t sbase = node_base + t * 128u + (uint32_t)r * 16u;
-            for (uint32_t attempt = 0; attempt < 16u; attempt++) {
-                const uint32_t w0 = pcg_hash(sbase + attempt);
-                uint32_t cand;
-                if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
-                    const uint32_t x = __umulhi(w0, (uint32_t)c.n);
-                    const float u = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                    cand = (u < c.hub_odds[x]) ? x : c.hub_alias[x];
-                } else {
-                    cand = __umulhi(w0, (uint32_t)c.n);  // :1121
-                }
-                bool reject = (cand == v) || (cand == j);
-                if (!reject && ((sig >> (cand & 63u)) & 1ull)) {  // NodeParam::get_edge, nodeparam.rs:83-85
-                    for (uint32_t m = 0; m < k; m++)
-                        if (s_row[m * NPB + nib] == cand) { reject = true; break; }
-                }
-                idx = cand;
-                if (!reject) break;
-            }
-        }
-        float row[DIM];
-#pragma unroll
-        for (int q = 0; q < DIM; q++) row[q] = 0.f;
-        if (act && r < 6) load_row_fresh<DIM>(c.y, idx, row);
-        float other[DIM];
-        group_bcast<DIM>(row, gbase + 0, other);
-        {   // attraction, the y_i half of embedder.rs:1207-1237
-            float d = 0.f;
-#pragma unroll
-            for (int q = 0; q < DIM; q++) { const float df = yv[q] - other[q]; d += df * df; }
-            const float delta = d * inv_s2;
-            if (act && delta > 0.f) {
-                const float coeff = grad_coeff_f32<B1>(delta, inv_s2, a.b);
-                const float rep = rcp(fmaxf(delta * delta, 1.0f / kProbaMin));
-                const float cij = fmaxf(a.step * coeff * (-w + (1.f - w) * rep), -0.49f);
-#pragma unroll
-                for (int q = 0; q < DIM; q++) grad[q] = (other[q] - yv[q]) * cij;
-            } else {
-#pragma unroll
-                for (int q = 0; q < DIM; q++) grad[q] = 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
-        }
-#pragma unroll
-        for (int g = 1; g <= 5; g++) {  // 5 repulsions, :1267-1297
-            group_bcast<DIM>(row, gbase + g, other);
-            float dk = 0.f;
-#pragma unroll
-            for (int q = 0; q < DIM; q++) { const float df = yv[q] - other[q]; dk += df * df; }
-            if (act && dk > 0.f) {
-                const float dks = dk * inv_s2;
-                const float coeff = grad_coeff_f32<B1>(dks, inv_s2, a.b);
-                const float cik = fminf(a.step * coeff * rcp(fmaxf(dks * dks, 1.0f / 16.0f)), 2.0f);
-#pragma unroll
-                for (int q = 0; q < DIM; q++) grad[q] = (other[q] - yv[q]) * cik;
-            }  // else `gradient` keeps its previous value (reference quirk B4)
-            if (act) {
-#pragma unroll
-                for (int q = 0; q < DIM; q++) yv[q] -= grad[q];
-            }
-        }
-        if (a.store_mode == 0 && act && r == 0) store_row_through<DIM>(c.y, v, yv);
-    }
-    if (a.store_mode != 0 && r == 0 && valid && nv) store_row_through<DIM>(c.y, v, yv);
-    // ---- stage C: the samples whose target is v (the y_j half of :1238-1239), counts recomputed per in-edge
-    const uint64_t tb = a.tptr[v];
-    const uint32_t indeg = valid ? (uint32_t)(a.tptr[v + 1] - tb) : 0u;
-    uint32_t dmax = indeg;
-#pragma unroll
-    for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(dmax, off); dmax = o > dmax ? o : dmax; }
-    bool any_push = false;
-    for (uint32_t x0 = 0; x0 < dmax; x0 += kGroup) {
-        const uint32_t x = x0 + (uint32_t)r;
-        uint32_t cnt = 0;
-        float wu = 0.f, su = 1.f;
-        float yu[DIM];
-#pragma unroll
-        for (int q = 0; q < DIM; q++) yu[q] = 0.f;
-        if (x < indeg) {
-            const InEdge rec = a.tin[tb + x];
-            cnt = edge_count(rec.eid, a.round_key, c.seed, a.unit * rec.w);
-            wu = rec.w;
-            su = rec.s_src;
-            if (cnt) load_row_fresh<DIM>(c.y, rec.src, yu);
-        }
-        bool changed = false;
-#pragma unroll
-        for (int sl = 0; sl < kGroup; sl++) {
-            const uint32_t bc = __shfl(cnt, gbase + sl);
-            uint32_t cmax = bc;
-#pragma unroll
-            for (int off = 32; off >= kGroup; off >>= 1) { const uint32_t o = __shfl_xor(cmax, off); cmax = o > cmax ? o : cmax; }
-            if (cmax == 0) continue;  // wave-uniform
-            float other[DIM];
-            group_bcast<DIM>(yu, gbase + sl, other);
-            const float wb = __shfl(wu, gbase + sl);
-            const float sb = __shfl(su, gbase + sl);
-            const float inv_su2 = rcp(sb * sb);
-            for (uint32_t rep_i = 0; rep_i < cmax; rep_i++) {
-                if (rep_i < bc) {
-                    attract<DIM, B1>(yv, other, wb, inv_su2, a.step, a.b, 1.f);
-                    changed = true;
-                }
-            }
-        }
-        any_push |= changed;
-        if (a.store_mode == 0 && changed && r == 0 && valid) store_row_through<DIM>(c.y, v, yv);
-    }
-    if (a.store_mode != 0 && any_push && r == 0 && valid) store_row_through<DIM>(c.y, v, yv);
-    // samples drawn: one atomic per wave, spread over 1024 counters (a single address serialises at ~12 ns each)
-    unsigned long long mine = (r == 0 && valid) ? (unsigned long long)nv : 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if (lane == 0 && mine) atomicAdd(&a.sample_counter[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 1023u], mine);
-}
-
 __global__ void in_edge_keys_kernel(uint64_t n, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ nbr,
                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ payload) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -518,18 +324,6 @@ __global__ void in_weight_max_kernel(uint64_t n, const uint64_t* __restrict__ tp
         for (uint64_t x = tptr[v]; x < tptr[v + 1]; x++) w += tin[x].w;
     for (int off = 32; off > 0; off >>= 1) w = fmaxf(w, __shfl_xor(w, off));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(w));
-}
-
-template <int DIM>
-void launch_round_fused(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
-    if constexpr (DIM > 0) {
-        const unsigned grid = blocks_for(nodes, kBlock / kGroup);
-        const bool hub = a.c.hub_odds != nullptr, b1 = a.b == 1.0f;
-        if (b1 && !hub) hipLaunchKernelGGL((ce_round_group_kernel<DIM, true, false>), dim3(grid), dim3(kBlock), 0, stream(), a);
-        else if (b1 && hub) hipLaunchKernelGGL((ce_round_group_kernel<DIM, true, true>), dim3(grid), dim3(kBlock), 0, stream(), a);
-        else if (!b1 && !hub) hipLaunchKernelGGL((ce_round_group_kernel<DIM, false, false>), dim3(grid), dim3(kBlock), 0, stream(), a);
-        else hipLaunchKernelGGL((ce_round_group_kernel<DIM, false, true>), dim3(grid), dim3(kBlock), 0, stream(), a);
-    }
 }
 
 template <int DIM>
@@ -588,7 +382,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     // node-per-lane kernel runs all its waves concurrently, so within a round every gather sees the previous
     // round's rows (Jacobi-like) and needs shorter rounds (8) than the lane-group kernel (12), whose waves
     // finish at different times, for the same fidelity.
-    const bool force_legacy = getenv("AE_CE_UNFUSED") || getenv("AE_CE_GROUP");
+    const bool force_legacy = debug_knob("AE_CE_UNFUSED") != nullptr;
     const bool node_kernel = node_kernel_ok(o) && !(force_legacy && legacy_dim(o->dev.dim));
     double per_round_target = node_kernel ? 8.0 : 12.0;
     // ... and no edge should be drawn much more than 2/3 times per round on average: two attraction steps of one edge
@@ -597,20 +391,22 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     // (60 k points of 28-d blobs, 40 batches): final CE 0.62x the sequential run's with 8 samples per node and round
     // (1.33 per edge), 0.99x with 4 (0.67 per edge); C2 (k = 12, 8 per round = 0.67 per edge) is unchanged by the rule.
     if (node_kernel) per_round_target = std::min(per_round_target, std::max(1.0, (2.0 / 3.0) * (double)o->dev.nnz / (double)o->dev.n));
-    if (getenv("AE_CE_PER_ROUND")) per_round_target = atof(getenv("AE_CE_PER_ROUND"));
+    if (debug_knob("AE_CE_PER_ROUND")) per_round_target = atof(debug_knob("AE_CE_PER_ROUND"));
     uint32_t rounds = (uint32_t)std::max(1.0, std::ceil(per_node / per_round_target));
     // hubs: a node of in-weight W receives per_node * W / rounds pushes per round, all evaluated against round-start
     // source rows; keep that below 128 (no effect on graphs whose largest in-weight is below ~16)
-    if (!getenv("AE_CE_PER_ROUND"))
+    if (!debug_knob("AE_CE_PER_ROUND"))
         rounds = std::max(rounds, (uint32_t)std::min(1000.0, std::ceil(per_node * (double)o->in_weight_max / 128.0)));
     o->rounds = rounds;
     if (iter >= (1u << 20) || rounds >= (1u << 10)) fail(AE_ERR_INVALID_ARG, "iteration / round index too large for the RNG key");
     const double per_round = per_node / (double)rounds;
     // plan capacity per node and round: Poisson(per_round) exceeds mean + 8 sigma + 8 with probability < 1e-14
     const uint32_t cap = (uint32_t)std::ceil(per_round + 8.0 * std::sqrt(per_round) + 8.0);
-    if (o->plan.n < nodes * (uint64_t)cap * 8) o->plan.alloc(nodes * (uint64_t)cap * 8);
-    if (o->tot.n < nodes) o->tot.alloc(nodes);
-    if (o->cnt.n < o->dev.nnz) { o->cnt.alloc(o->dev.nnz); o->cnt.zero(); }
+    if (!node_kernel) {  // only the wave-per-node plan + lane-group apply kernels (rows of > 32 neighbours) use these
+        if (o->plan.n < nodes * (uint64_t)cap * 8) o->plan.alloc(nodes * (uint64_t)cap * 8);
+        if (o->tot.n < nodes) o->tot.alloc(nodes);
+        if (o->cnt.n < o->dev.nnz) { o->cnt.alloc(o->dev.nnz); o->cnt.zero(); }
+    }
     NodeArgs a;
     a.c = o->dev;
     a.tptr = o->tptr.p;
@@ -626,18 +422,16 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     a.overflow = o->err.p;
     static DevBuf<unsigned long long> prof_buf;
     a.prof = nullptr;
-    if (getenv("AE_CE_PROF")) {
+    if (debug_knob("AE_CE_PROF")) {
         if (!prof_buf.n) { prof_buf.alloc(12); prof_buf.zero(); }
         a.prof = prof_buf.p;
     }
     const bool sharded = o->dev.shard_edges != o->dev.nnz;
-    // A/B switches: AE_CE_GROUP = the 8-lanes-per-node fused kernel, AE_CE_UNFUSED = plan + apply kernels
-    const bool group_kernel = !node_kernel && o->g->max_nbng <= 16 && !getenv("AE_CE_UNFUSED");
-    a.skip = getenv("AE_CE_SKIP") ? atoi(getenv("AE_CE_SKIP")) : 0;
+    a.skip = debug_knob("AE_CE_SKIP") ? atoi(debug_knob("AE_CE_SKIP")) : 0;
     // 2: write-through at phase ends (default).  0: after every chunk -- measured slower in the node kernel (loads
     // and stores share vmcnt and may return out of order, so every wait after a store drains it: +50 % time)
     // for a fidelity gain that shorter rounds give more cheaply
-    a.store_mode = getenv("AE_CE_STORE") ? atoi(getenv("AE_CE_STORE")) : 2;
+    a.store_mode = debug_knob("AE_CE_STORE") ? atoi(debug_knob("AE_CE_STORE")) : 2;
     // multi-GPU: the owned rows are exchanged `comm_exchanges` times per batch, after equal runs of rounds (the last
     // exchange ends the batch): remote rows are rounds / exchanges rounds old instead of a whole batch
     const uint32_t exch = o->comm ? std::min(std::max(1u, o->comm_exchanges), rounds) : 0u;
@@ -654,7 +448,6 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
             exchange_after(r);
             continue;
         }
-        if (group_kernel) { AE_DISPATCH_DIM(o->dev.dim, launch_round_fused, o, a, nodes); exchange_after(r); continue; }
         const unsigned plan_grid = blocks_for(nodes * 64, kBlock);
         if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
         else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);

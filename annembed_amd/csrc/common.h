@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -82,7 +83,6 @@ inline int32_t guard(F&& f) {
 // the stream every kernel of the library is launched on (one per process / current device)
 hipStream_t stream();
 void require_device();
-
 // stream-ordered allocations (hipMallocAsync on the library stream, default pool kept warm): for the temporaries
 // of the per-call hot functions -- a hipMalloc / hipFree pair costs a device synchronisation
 void* pool_alloc(size_t bytes);
@@ -132,6 +132,10 @@ struct DevBuf {
     void zero() { if (n) AE_HIP(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
     std::vector<T> to_host() const { std::vector<T> v(n); download(v.data(), n); return v; }
 };
+
+// Tuning / A-B switches and the profiling output are read from the environment ONLY when AE_DEBUG_KNOBS is set: a release run
+// of the library cannot be altered (numerically or otherwise) from the environment.
+inline const char* debug_knob(const char* name) { return getenv("AE_DEBUG_KNOBS") ? getenv(name) : nullptr; }
 
 inline unsigned blocks_for(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
 // grid-stride launches: cap the grid at 256 CUs x 8 workgroups (guide G11)

@@ -557,9 +557,9 @@ int32_t ae_kgraph_bruteforce_l2(const float* x, uint64_t n, uint64_t dim, uint32
         g->nbr.alloc(g->nnz);
         g->dist.alloc(g->nnz);
         // matrix-core path (knn.hip) for the usual neighbourhood sizes; AE_KNN_LEGACY=1 keeps the plain kernel (A/B)
-        if (nbng + 8 <= 64 && !getenv("AE_KNN_LEGACY")) {
+        if (nbng + 8 <= 64 && !debug_knob("AE_KNN_LEGACY")) {
             const uint64_t fell_back = knn_mfma(dx.p, n, dim, nbng, g->nbr.p, g->dist.p);
-            if (getenv("AE_CE_PROF")) fprintf(stderr, "KNN rows recomputed by the brute-force fallback: %llu of %llu\n",
+            if (debug_knob("AE_CE_PROF")) fprintf(stderr, "KNN rows recomputed by the brute-force fallback: %llu of %llu\n",
                                               (unsigned long long)fell_back, (unsigned long long)n);
         } else {
             bruteforce_knn_rows(dx.p, n, dim, nbng, nullptr, n, g->nbr.p, g->dist.p);

@@ -490,6 +490,7 @@ uint32_t embed_from_laplacian_device(ae_laplacian* lap, uint64_t asked_dim, floa
     const uint32_t real_dim = (uint32_t)std::min<uint64_t>(asked_dim, r - 1);        // :1207
     std::vector<float> nl(r);
     for (uint32_t j = 0; j < r; j++) nl[j] = s[j] / s[0];  // :1213
+    if (!has_t && r < 3) fail(AE_ERR_SVD, "the automatic diffusion time needs 3 singular values (the reference indexes out of bounds, diffmaps.rs:1216)");
     const float time = has_t ? t : std::fmin(5.0f, std::log(0.9f) / std::log(nl[2] / nl[1]));  // :1214-1217
     std::vector<float> lam_pow(real_dim);
     for (uint32_t j = 0; j < real_dim; j++) lam_pow[j] = std::pow(nl[j + 1], time);  // :1232

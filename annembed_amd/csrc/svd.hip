@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
 
 static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     const unsigned grid = grid_cap(a.nrows * 64, 256);
-    if (l % 4 == 0 && l <= 32 && !getenv("AE_SPMM_SCALAR")) {
+    if (l % 4 == 0 && l <= 32 && !debug_knob("AE_SPMM_SCALAR")) {
         hipLaunchKernelGGL(spmm_csr_vec4_kernel, dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
         check_launch("spmm_csr_vec4");
         return;
@@ -814,7 +814,7 @@ static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) 
 void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "panel width %u unsupported (max %d)", l, kMaxL);
     if (a.is_csr) { spmm(a, d_x, d_y, l); return; }
-    if (l <= 32 && !getenv("AE_NO_MFMA")) {  // matrix-core path
+    if (l <= 32 && !debug_knob("AE_NO_MFMA")) {  // matrix-core path
         constexpr int BM = 128;  // (64-row workgroups measured 5 % slower)
         const unsigned g2 = blocks_for(a.nrows, BM);
         if (a.ncols % 4 == 0)
@@ -866,7 +866,7 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
         return;
     }
     const uint64_t m = a.nrows, n = a.ncols;
-    if (l <= 32 && !getenv("AE_NO_MFMA")) {  // matrix-core path: 32-column tiles x row chunks, then a deterministic reduce
+    if (l <= 32 && !debug_knob("AE_NO_MFMA")) {  // matrix-core path: 32-column tiles x row chunks, then a deterministic reduce
         const uint64_t ctiles = (n + 127) / 128;  // strips of 128 columns
         uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, std::max<uint64_t>(1, 2048 / ctiles)));
         const uint64_t rpc = ((m + chunks - 1) / chunks + 7) & ~7ull;

@@ -108,8 +108,8 @@ enum {
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
     AE_CE_EVENT = 3,
-    /* Default.  The faithful mode that fits the problem: AE_CE_EVENT when it supports it, else AE_CE_SEQUENTIAL
-       (asked_dim in {2,3,4,8,16}, < 2^31 samples per batch), else -- and for a sharded node range, i.e. several GPUs --
+    /* Default.  AE_CE_SEQUENTIAL (exact and reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one device, < 2^31
+       samples per batch --, else AE_CE_EVENT, else (other dimensions, or a sharded node range, i.e. several GPUs)
        AE_CE_HOGWILD.  ae_entropy_optim_get_ce_mode reports the choice. */
     AE_CE_AUTO = 4
 };
@@ -355,6 +355,8 @@ int32_t ae_entropy_optim_device_coords(ae_entropy_optim *o, void **d_y, uint64_t
 /* average duration in ms of the SGD kernel launches since the last call (hipEvent on the handle's
    stream) and their count; resets the accumulators. */
 int32_t ae_entropy_optim_kernel_time(ae_entropy_optim *o, double *avg_ms, uint64_t *launches);
+/* AE_CE_SEQUENTIAL: average duration of the dataflow kernel alone (hipEvents around its launch) since the last call */
+int32_t ae_entropy_optim_dataflow_time(ae_entropy_optim *o, double *avg_ms, uint64_t *launches);
 
 /* entropy_optimize (embedder.rs:794-904) in one call: CE before, nb_grad_batch batches with
    step = grad_step * (1 - iter/nb_batch) (:875), CE after.  y: n x asked_dim out. */

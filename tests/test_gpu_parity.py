@@ -320,11 +320,12 @@ def _edge_len(indptr, nbr, y):
 
 
 def test_event_mode_statistics_match_oracle(A, oracle):
-    """The default CE mode (AE_CE_AUTO -> AE_CE_EVENT) is not reproducible sample by sample (neither is the reference's
-    rayon loop); its statistics are the sequential loop's: final cross entropy within 3 % and edge-length quantiles within
-    5 % of the oracle's sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n).
-    Kept as evidence next to it: the rounds mode (AE_CE_HOGWILD, stale partner rows) and the literal racy per-sample
-    transcription are NOT inside that envelope."""
+    """The event-ordered mode (AE_CE_EVENT) is not reproducible sample by sample (neither is the reference's rayon loop); its
+    statistics are the sequential loop's: final cross entropy within 3 % and edge-length quantiles within 5 % of the oracle's
+    sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n).  The default
+    (AE_CE_AUTO) resolves to the sequential mode and reproduces the oracle bit for bit.  Kept as evidence next to them: the
+    rounds mode (AE_CE_HOGWILD, stale partner rows) and the literal racy per-sample transcription are NOT inside that
+    envelope."""
     n = 20000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=8, seed=2, ncomp=6)
     g = A.KGraph(indptr, nbr, dist)
@@ -332,9 +333,11 @@ def test_event_mode_statistics_match_oracle(A, oracle):
     y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
     npar = A.NodeParams.from_host(g, p0, s0)
     eo = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
-    assert eo.get_ce_mode() == A.AE_CE_EVENT
-    y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
+    assert eo.get_ce_mode() == A.AE_CE_SEQUENTIAL
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 6)
+    yd, _, ced = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
+    assert np.array_equal(yd, yo) and abs(ced - oce1) < 1e-11 * oce1  # the default: the oracle's run, bit for bit
+    y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_EVENT), y0)
     assert abs(ce0 - oce0) < 1e-10 * oce0
     assert np.isfinite(y).all()
     assert abs(ce1 - oce1) < 0.03 * oce1, (ce1, oce1)
@@ -353,11 +356,12 @@ def test_event_mode_statistics_match_oracle(A, oracle):
                                          (2, 10, False, 0.8), (6, 20, True, 1.3), (8, 12, False, 1.0), (16, 10, True, 1.0), (8, 30, True, 1.0),
                                          (16, 16, False, 0.9)])
 def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
-    """Every asked_dim and row length through the default mode.  asked_dim in {2,3,4,8,16} resolves to the event-ordered
-    kernel (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours): CE within 5 %, edge-length median /
-    q90 within 8 % of the oracle's sequential run on these 4000-node graphs (the oracle's own seed spread here is ~3 %).
-    Other dimensions have no faithful kernel and resolve to the rounds mode (zero-padded to 8 / 16 / 32 columns): the
-    approximate mode's bar."""
+    """Every asked_dim and row length.  asked_dim in {2,3,4,8,16}: the default resolves to the sequential mode (the oracle's
+    run: bit for bit at b = 1, 1e-5 relative CE with the general exponent, whose pow() differs in the last bits), and the
+    event-ordered kernel (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours) lands within 5 % (CE) /
+    8 % (edge-length median and q90) of it on these 4000-node graphs (the oracle's own seed spread here is ~3 %).  Other
+    dimensions have no faithful kernel and resolve to the rounds mode (zero-padded to 8 / 16 / 32 columns): the approximate
+    mode's bar."""
     n = 4000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
     g = A.KGraph(indptr, nbr, dist)
@@ -373,20 +377,33 @@ def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc, b=b)
     assert np.isfinite(y).all() and y.shape == (n, dim)
     faithful = dim in (2, 3, 4, 8, 16)
-    assert eo.get_ce_mode() == (A.AE_CE_EVENT if faithful else A.AE_CE_HOGWILD)
-    tol_ce, tol_q = (0.05, 0.08) if faithful else (0.25, 0.2)
-    assert abs(ce1 - oce1) < tol_ce * oce1, (ce1, oce1)
+    assert eo.get_ce_mode() == (A.AE_CE_SEQUENTIAL if faithful else A.AE_CE_HOGWILD)
     src = np.repeat(np.arange(n), k)
-    lg = np.linalg.norm(y[src] - y[nbr], axis=1)
     lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
-    for q in (0.5, 0.9):
-        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < tol_q * np.quantile(lo, q), (q, np.quantile(lg, q), np.quantile(lo, q))
+
+    def close(y_, ce_, tol_ce, tol_q):
+        assert abs(ce_ - oce1) < tol_ce * oce1, (ce_, oce1)
+        lg = np.linalg.norm(y_[src] - y_[nbr], axis=1)
+        for q in (0.5, 0.9):
+            assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < tol_q * np.quantile(lo, q), (q, np.quantile(lg, q), np.quantile(lo, q))
+    if not faithful:
+        close(y, ce1, 0.25, 0.2)
+        return
+    if b == 1.0:
+        assert np.array_equal(y, yo)
+    close(y, ce1, 1e-5, 1e-4)
+    ev = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b, ce_mode=A.AE_CE_EVENT),
+                        y0, hub_counts=hubc)
+    for it in range(1, 6):
+        ev.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
+    assert np.isfinite(ev.get_embedded()).all()
+    close(ev.get_embedded(), ev.ce_compute_threaded(), 0.05, 0.08)
 
 
 def test_converged_run_matches_reference_quality(A, oracle):
     """Full schedule (dmap initialisation, 20 batches): the default mode's embedding against the oracle's sequential
     run on the reference's own yardsticks -- final cross entropy and get_quality_estimate_from_edge_length
-    (embedder.rs:620-753)."""
+    (embedder.rs:620-753); the event-ordered mode within 3-8 % on the same yardsticks."""
     n, k, nb = 10000, 10, 20
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=10, k=k, seed=7, ncomp=8)
     g = A.KGraph(indptr, nbr, dist)
@@ -394,7 +411,9 @@ def test_converged_run_matches_reference_quality(A, oracle):
     rc, y0, _ = oracle.dmap_embed_from_kgraph(indptr, nbr, dist, k, oracle.DiffusionParams(2, 5.0, 12))
     y0 = oracle.set_data_box(y0, 10.0)
     yo, _, oce = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb)
-    y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb), y0)
+    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb), y0)
+    assert np.array_equal(yd, yo) and abs(ced - oce) < 1e-11 * oce  # default mode: the oracle's run
+    y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb, ce_mode=A.AE_CE_EVENT), y0)
     assert abs(ce - oce) < 0.03 * oce, (ce, oce)
     q, qo = A.quality_estimate_from_edge_length(g, y, 30), A.quality_estimate_from_edge_length(g, yo, 30)
     assert abs(q.nb_without_match - qo.nb_without_match) < 0.05 * qo.nb_without_match
@@ -427,8 +446,10 @@ def test_hub_and_ragged_rows(A, oracle):
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
     assert rc == 0
     y0 = oracle.set_data_box(rng.normal(size=(n, 2)).astype(np.float32), 10.0)
-    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5), y0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5)
+    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5), y0)
+    assert np.array_equal(yd, yo)  # default (sequential) mode: the oracle's run, hub or not
+    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_EVENT), y0)
     assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
     assert abs(ce1 - oce1) < 0.05 * oce1, (ce1, oce1)
     src = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
@@ -730,8 +751,8 @@ def test_full_size_properties(A):
     assert cnt == 2 and ms > 0
     drawn, rounds = eo.samples_drawn()  # Poisson(nb_sample) total per batch
     assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S) and rounds == 15  # 120 samples per node and batch, 8 per round
-    # the same properties in the default (event-ordered) mode
-    ev = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0)
+    # the same properties in the event-ordered mode
+    ev = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_EVENT), y0)
     assert ev.get_ce_mode() == A.AE_CE_EVENT
     ev.gradient_iteration_threaded(S, 0.0, 1)
     assert np.array_equal(ev.get_embedded(), before)
@@ -971,7 +992,7 @@ def test_library_communicator_world_one(A, oracle, graph):
     assert abs(a.ce_compute_threaded() - b.ce_compute_threaded()) < 0.05 * b.ce_compute_threaded()  # same mode, same draws; float order of the rounds differs
     assert comm.all_reduce_sum(1.25) == 1.25
     with pytest.raises(A.AnnembedError):
-        comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # event-ordered: does not shard
+        comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # the default (sequential) mode does not shard
     with pytest.raises(A.AnnembedError):
         comm.attach(A.EntropyOptim(g, npar, par, y0, node_lo=0, node_hi=1000), 1)  # one rank must own [0, n)
     comm.close()

@@ -6,12 +6,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
 # counters: their own passes, the C2 workload only (the scale shapes instantiate the same kernel templates)
 PMCARGS="--no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd"
-rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_sq.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_write.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_sq.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_fetch.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_write.log 2>&1
 cd $OUT
 ls -R . | head -50
 python3 - <<'PY'

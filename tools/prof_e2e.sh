@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/e2eprof; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/tools/run_e2e.py > $OUT/run.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/tools/run_e2e.py > $OUT/run.log 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/t_kernel_stats.csv")))

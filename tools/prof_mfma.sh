@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/mfmaprof; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --list-avail 2>/dev/null | grep -i "Counter_Name" | grep -i "MFMA" | head -20
-rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace -d $OUT -o p -- python3 $R/tools/run_svd_dense.py > $OUT/run.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --list-avail 2>/dev/null | grep -i "Counter_Name" | grep -i "MFMA" | head -20
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace -d $OUT -o p -- python3 $R/tools/run_svd_dense.py > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)

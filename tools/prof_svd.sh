@@ -3,7 +3,7 @@
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/svdprof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/${SVDSCRIPT:-tools/run_svd_init.py} > $OUT/run.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT -o t -- python3 $R/${SVDSCRIPT:-tools/run_svd_init.py} > $OUT/run.log 2>&1
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$OUT/t_kernel_stats.csv")))

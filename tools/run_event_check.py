@@ -69,10 +69,11 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     indptr, nbr, dist = kg.get_neighbours()
     npar = A.to_proba_edges(kg, rho, 1.0)
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
+    hub = kg.hubness() if os.environ.get("FID_HUB") else None
     out = {"kind": kind, "n": n, "nb_batch": nb_batch, "runs": []}
     for mode, name in ((A.AE_CE_SEQUENTIAL, "sequential"), (A.AE_CE_EVENT, "event"), (A.AE_CE_HOGWILD, "rounds")):
         for s in range(seeds):
-            r = run(kg, npar, y0, mode, nb_batch, 1000 + s)
+            r = run(kg, npar, y0, mode, nb_batch, 1000 + s, hub=hub)
             q = edge_q(indptr, nbr, r["y"])
             out["runs"].append(dict(mode=name, seed=s, ce=r["ce"], q=q.tolist(), ms=r["wall_ms_per_batch"], drawn=r["drawn"], rounds=r["rounds"]))
             print(name, s, "ce %.0f q %s  %.2f ms/batch drawn %.4f rounds %d" % (r["ce"], np.round(q, 4), r["wall_ms_per_batch"], r["drawn"], r["rounds"]), flush=True)
