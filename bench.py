@@ -155,7 +155,9 @@ def roofline_of(run, k, d):
     launch_ms = run["dominant_ms"] if run.get("dominant_ms") else kernel_ms / lpb
     bytes_per_launch = bytes_per_sample * run["nb_sample"] / lpb
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    whole = bytes_per_sample * run["nb_sample"] / (run["ms_per_step"] * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "achieved_whole_batch": whole, "frac_whole_batch": whole / 8000.0,
             "kernel": MODE_KERNEL.get(run["mode"], "?"), "launches_per_batch": lpb, "launch_avg_ms": launch_ms, "batch_kernel_ms": kernel_ms,
             "batches_timed": run["batches_timed"], "bytes_per_sample": bytes_per_sample, "bytes_per_launch": bytes_per_launch}
 
@@ -541,7 +543,7 @@ def pmc_traffic(mode):
     (profiles/<round>/pmc_ce_*.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes).
     Not a measurement of this run: reported under its own keys, `traffic` stays null."""
     import glob
-    name = {0: "pmc_ce_round.json", 3: "pmc_ce_event.json"}.get(mode)
+    name = {0: "pmc_ce_round.json", 1: "pmc_ce_dataflow.json", 3: "pmc_ce_event.json"}.get(mode)
     if not name:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
