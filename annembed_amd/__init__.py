@@ -1,8 +1,8 @@
 """annembed_amd -- MI355X (gfx950) implementation of annembed's embedding hot path.
 
 The package is a thin host-side mirror of the reference's Rust API (KGraph / EmbedderParams /
-Embedder / DiffusionMaps / SvdApprox) over the C ABI of libannembed_hip.so.  All compute runs in
-hand-written HIP kernels; there is no CPU fallback: importing the API without the built library, or
+Embedder / DiffusionMaps / SvdApprox) over the C ABI of libannembed_hip.so.  All compute runs on the GPU
+(hand-written HIP kernels; rocPRIM sort / scan as primitives beside them); there is no CPU fallback: importing the API without the built library, or
 calling it without a GPU, fails loudly.
 """
 from ._lib import (AE_CE_AUTO, AE_CE_EVENT, AE_CE_HOGWILD, AE_CE_SAMPLE_RACY, AE_CE_SEQUENTIAL, AE_SAMPLER_ALIAS, AE_SAMPLER_ROWCDF, AnnembedError, LIB_PATH,  # noqa: F401
