@@ -26,6 +26,7 @@ AE_CE_SEQUENTIAL = 1
 AE_CE_SAMPLE_RACY = 2
 AE_CE_EVENT = 3
 AE_CE_AUTO = 4
+AE_CE_SLICED = 5
 AE_SAMPLER_ROWCDF = 0
 AE_SAMPLER_ALIAS = 1
 

@@ -165,38 +165,6 @@ struct Row {
     float v[DIM];
 };
 
-template <int DIM>
-__device__ __forceinline__ void load_row(const float* __restrict__ y, uint32_t node, float* out) {
-    const float* p = y + (uint64_t)node * DIM;
-    if constexpr (DIM == 2) {
-        float2 t = *reinterpret_cast<const float2*>(p);
-        out[0] = t.x; out[1] = t.y;
-    } else if constexpr (DIM % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 4; q++) {
-            float4 t = reinterpret_cast<const float4*>(p)[q];
-            out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) out[t] = p[t];
-    }
-}
-template <int DIM>
-__device__ __forceinline__ void store_row(float* __restrict__ y, uint32_t node, const float* in) {
-    float* p = y + (uint64_t)node * DIM;
-    if constexpr (DIM == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(in[0], in[1]);
-    } else if constexpr (DIM % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 4; q++)
-            reinterpret_cast<float4*>(p)[q] = make_float4(in[4 * q], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) p[t] = in[t];
-    }
-}
-
 // the whole sample: yi / yj are updated in place (the values the reference stores at :1301 / :1239)
 template <int DIM>
 __device__ __forceinline__ void sample_update(float* yi, float* yj, const float (*yk)[DIM], float w, double scale, double b, double grad_step) {
@@ -363,12 +331,12 @@ __global__ void df_rowptr_kernel(const uint32_t* __restrict__ keys, uint64_t nnz
 // lines instead of the ~log2(len) lines of a bisection from the ends (C3 shape: 56 ms -> see DESIGN.md).
 __global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint32_t* __restrict__ vals,
                                const uint64_t* __restrict__ rowptr, uint32_t* __restrict__ pred) {
-    const uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (idx >= S * 7) return;
+    // grid-stride: 7 S work items exceed the 2^32 a dispatch can carry from S = 6.1e8 on (the C4 shape has 6.6e8)
+    for (uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; idx < S * 7; idx += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t s = (uint32_t)(idx / 7);
     const uint32_t x = plan_nodes[idx];
     const uint64_t lo = rowptr[x], hi = rowptr[x + 1];
-    if (lo == hi) { pred[idx] = kNoPred; return; }
+    if (lo == hi) { pred[idx] = kNoPred; continue; }
     const uint32_t key = s << 1;  // first version with sample >= s: vals < key  <=>  its sample < s
     uint64_t g = lo + (uint64_t)((float)(hi - lo) * ((float)s / (float)S));
     g = min(g, hi - 1);
@@ -396,6 +364,7 @@ __global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nod
         else H = mid;
     }
     pred[idx] = L > lo ? vals[L - 1] : kNoPred;
+    }
 }
 
 // A version row is published by its stores alone: the buffer is filled with an all-ones pattern (a NaN no arithmetic
@@ -643,7 +612,11 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
         float* ver = o->df_ver.p;
         unsigned int* err = o->err.p;
         void* args[] = {&dev, &S, &pn, &pw, &pred, &ver, &step, &err, &lane_stride};
-        AE_HIP(hipMemsetAsync(ver, 0xFF, sizeof(float) * S * 2 * DIM, stream()));  // every version "unpublished"
+        {   // every version "unpublished"; in pieces of 1 GiB (one call for tens of GB was seen to leave part of the buffer unset)
+            const size_t bytes = sizeof(float) * S * 2 * DIM, piece = size_t(1) << 30;
+            for (size_t off = 0; off < bytes; off += piece)
+                AE_HIP(hipMemsetAsync(reinterpret_cast<char*>(ver) + off, 0xFF, std::min(piece, bytes - off), stream()));
+        }
         // The progress argument needs every block resident: the grid is sized from the occupancy query with a margin (the
         // query can be one block per CU high).  A plain launch: same residency as a cooperative one without its +15-19 us.
         if (o->df_events.size() >= 64) {  // nobody asks for the timings: keep the list short
@@ -683,7 +656,7 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
     sort_pairs_u32_u32(k0, k1, v0, v1, 2 * S, node_bits);
     hipLaunchKernelGGL(df_rowptr_kernel, dim3(blocks_for(o->dev.n + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)k1, 2 * S,
                        (uint64_t)o->dev.n, st.rowptr.p);
-    hipLaunchKernelGGL(df_pred_kernel, dim3(blocks_for(S * 7, 256)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
+    hipLaunchKernelGGL(df_pred_kernel, dim3(grid_cap(S * 7, 256, 1u << 22)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
                        (const uint32_t*)v1, (const uint64_t*)st.rowptr.p, st.pred.p);
     check_launch("df_pred");
 }
@@ -879,18 +852,21 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         }
         sync();
         // AE_CE_AUTO: the sequential-equivalent dataflow (exact, reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one
-        // device, < 2^31 samples per batch --, else the event-ordered kernel when IT fits, else the rounds mode
+        // device, <= 2^28 samples per batch --, else the time-sliced mode, else (sharded, other dimensions) the rounds mode
         const bool sharded = node_lo != 0 || node_hi != n;
         const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
         uint32_t mode = params->ce_mode;
-        if (mode > AE_CE_AUTO) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
+        if (mode > AE_CE_SLICED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
         if (mode == AE_CE_AUTO) {
-            if (!sharded && df_dim && params->nb_sampling_by_edge * (edge_hi - edge_lo) < (1ull << 31)) mode = AE_CE_SEQUENTIAL;
+            // exact while its scratch stays moderate (2^28 samples per batch: ~40 GB at asked_dim 8); beyond, the time-sliced mode
+            // (statistical parity, 2-2.4x faster at that size, a tenth of the memory)
+            if (!sharded && df_dim && params->nb_sampling_by_edge * (edge_hi - edge_lo) <= (1ull << 28)) mode = AE_CE_SEQUENTIAL;
             else if (sharded || !df_dim) mode = AE_CE_HOGWILD;
-            else mode = AE_CE_EVENT;  // (unsupported sizes fail at the first batch with the reason)
+            else mode = AE_CE_SLICED;
         }
         if (mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
         if (mode == AE_CE_EVENT) ce_event_prepare(o.get());
+        if (mode == AE_CE_SLICED) ce_slice_prepare(o.get());
         o->params.ce_mode = mode;
         return o.release();
     }
@@ -944,7 +920,9 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
         if (nb_sample == 0) return;
         if (nb_sample >= (1ull << 56)) fail(AE_ERR_INVALID_ARG, "too many samples");
-        if (o->params.ce_mode == AE_CE_EVENT) {
+        if (o->params.ce_mode == AE_CE_SLICED) {
+            if (const char* why = ce_slice_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: %s", why);
+        } else if (o->params.ce_mode == AE_CE_EVENT) {
             if (const char* why = ce_event_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_EVENT: %s; use AE_CE_SEQUENTIAL or AE_CE_HOGWILD", why);
         } else if (o->params.ce_mode != AE_CE_SAMPLE_RACY && o->params.ce_mode != AE_CE_SEQUENTIAL && !ce_node_supports(o)) {
             fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
@@ -968,6 +946,12 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         AE_HIP(hipEventRecord(e0, stream()));
         if (o->params.ce_mode == AE_CE_SEQUENTIAL) {
             run_sequential(o, nb_sample, grad_step, (uint32_t)iter);
+            AE_HIP(hipEventRecord(e1, stream()));
+            o->events.emplace_back(e0, e1);
+            return;
+        }
+        if (o->params.ce_mode == AE_CE_SLICED) {
+            ce_slice_gradient_iteration(o, nb_sample, grad_step, (uint32_t)iter);
             AE_HIP(hipEventRecord(e1, stream()));
             o->events.emplace_back(e0, e1);
             return;

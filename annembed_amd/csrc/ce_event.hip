@@ -82,18 +82,6 @@ __device__ __forceinline__ void slot_clear(float* p) {
     }
 }
 
-// A row of the coordinate array as the memory side has it NOW: agent-scope loads.  A plain or non-temporal load may be served
-// by this XCD's L2, whose copy of a line another XCD's owner keeps rewriting is not refreshed before the launch ends (the
-// per-XCD L2s are not coherent): negatives read that way were up to a whole window old -- measured as final CE +1 ... +3 %
-// and the shortest edge-length quantiles -3 ... -12 % against the sequential loop.
-template <int DIM>
-__device__ __forceinline__ void load_row_coherent(const float* __restrict__ y, uint32_t node, float* out) {
-    float tmp[DIM];
-    (void)df_try_load_version<DIM>(y + (uint64_t)node * DIM, 0, tmp);
-#pragma unroll
-    for (int t = 0; t < DIM; t++) out[t] = tmp[t];
-}
-
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();

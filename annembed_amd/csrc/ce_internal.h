@@ -91,6 +91,10 @@ struct ae_entropy_optim {
     int ev_npw = 0;  // nodes per wave
     uint64_t ev_resident_blocks = 0;
     DevBuf<float> ev_slots;
+    // time-sliced optimistic mode (ce_slice.hip)
+    DevBuf<uint32_t> sl_erec, sl_edge_src, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
+    DevBuf<unsigned long long> sl_done;
+    float sl_pmax = 0.f;
     // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch
     ae_comm* comm = nullptr;
     std::vector<uint64_t> comm_ranges;
@@ -108,6 +112,10 @@ bool ce_node_supports(const ae_entropy_optim* o);
 void ce_node_build_transpose(ae_entropy_optim* o);
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
 // event-ordered batch (ce_event.hip): sequentially consistent attraction steps in an i.i.d. order, `rounds` = windows
+// time-sliced optimistic batch (ce_slice.hip): exact samples on current rows, i.i.d. order, any graph size; `rounds` = slices
+void ce_slice_prepare(ae_entropy_optim* o);
+const char* ce_slice_unsupported(const ae_entropy_optim* o);
+void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
 void ce_comm_exchange(ae_entropy_optim* o);  // comm.hip: all-gather of the owned coordinate rows on the library's stream
 void ce_event_prepare(ae_entropy_optim* o);
 const char* ce_event_unsupported(const ae_entropy_optim* o);

@@ -7,6 +7,39 @@
 
 namespace ae {
 
+// whole rows of the coordinate array with the widest vector access the dimension allows
+template <int DIM>
+__device__ __forceinline__ void load_row(const float* __restrict__ y, uint32_t node, float* out) {
+    const float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        out[0] = t.x; out[1] = t.y;
+    } else if constexpr (DIM % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 4; q++) {
+            float4 t = reinterpret_cast<const float4*>(p)[q];
+            out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) out[t] = p[t];
+    }
+}
+template <int DIM>
+__device__ __forceinline__ void store_row(float* __restrict__ y, uint32_t node, const float* in) {
+    float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(in[0], in[1]);
+    } else if constexpr (DIM % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 4; q++)
+            reinterpret_cast<float4*>(p)[q] = make_float4(in[4 * q], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) p[t] = in[t];
+    }
+}
+
 // common part of the gradient coefficient, embedder.rs:1216-1222 / :1275-1281
 __device__ __forceinline__ double grad_coeff(double d_scaled, double scale, double b) {
     if (b != 1.) {
@@ -105,6 +138,18 @@ __device__ __forceinline__ void df_store_version(float* __restrict__ ver, uint64
 #pragma unroll
         for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// A row of the coordinate array as the memory side has it NOW: agent-scope loads.  A plain or non-temporal load may be served
+// by this XCD's L2, whose copy of a line another XCD's owner keeps rewriting is not refreshed before the launch ends (the
+// per-XCD L2s are not coherent): negatives read that way were up to a whole window old -- measured as final CE +1 ... +3 %
+// and the shortest edge-length quantiles -3 ... -12 % against the sequential loop.
+template <int DIM>
+__device__ __forceinline__ void load_row_coherent(const float* __restrict__ y, uint32_t node, float* out) {
+    float tmp[DIM];
+    (void)df_try_load_version<DIM>(y + (uint64_t)node * DIM, 0, tmp);
+#pragma unroll
+    for (int t = 0; t < DIM; t++) out[t] = tmp[t];
 }
 
 }  // namespace ae

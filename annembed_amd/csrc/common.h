@@ -137,7 +137,12 @@ struct DevBuf {
 // of the library cannot be altered (numerically or otherwise) from the environment.
 inline const char* debug_knob(const char* name) { return getenv("AE_DEBUG_KNOBS") ? getenv(name) : nullptr; }
 
-inline unsigned blocks_for(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
+// one thread per work item: a dispatch carries at most 2^32 - 1 work items (the AQL grid size is 32 bits) -- beyond that the
+// kernel must be a grid-stride loop launched through grid_cap()
+inline unsigned blocks_for(uint64_t work, unsigned block) {
+    if (work + block > 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "internal: a launch of %llu work items exceeds one dispatch", (unsigned long long)work);
+    return (unsigned)((work + block - 1) / block);
+}
 // grid-stride launches: cap the grid at 256 CUs x 8 workgroups (guide G11)
 inline unsigned grid_cap(uint64_t work, unsigned block, unsigned cap = 2048 * 4) {
     uint64_t b = (work + block - 1) / block;

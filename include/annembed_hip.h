@@ -108,10 +108,16 @@ enum {
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
     AE_CE_EVENT = 3,
-    /* Default.  AE_CE_SEQUENTIAL (exact and reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one device, < 2^31
-       samples per batch --, else AE_CE_EVENT, else (other dimensions, or a sharded node range, i.e. several GPUs)
+    /* Default.  AE_CE_SEQUENTIAL (exact and reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one device, <= 2^28
+       samples per batch (its scratch grows with the batch: ~40 GB there) --, else AE_CE_SLICED, else (other dimensions, or a sharded node range, i.e. several GPUs)
        AE_CE_HOGWILD.  ae_entropy_optim_get_ce_mode reports the choice. */
-    AE_CE_AUTO = 4
+    AE_CE_AUTO = 4,
+    /* Time-sliced optimistic execution (ce_slice.hip): the batch's events (the same edge-keyed Poisson process as
+       AE_CE_EVENT) are bucketed into thin time slices; inside a slice the events that hold both their rows exclusively run
+       exactly as src/embedder.rs:1207-1301 (one lane, both rows, one gradient), the others are deferred to the next pass.
+       Statistical parity like AE_CE_EVENT, throughput-bound, no limit on the graph size; asked_dim in {2,3,4,8,16}, one
+       device. */
+    AE_CE_SLICED = 5
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every

@@ -11,7 +11,7 @@ dd=(x64**2).sum(1)[:,None]+(x64[:n_small]**2).sum(1)[None,:]-2*x64@x64[:n_small]
 pn=dd.argmin(1).astype(np.uint32); pd=np.sqrt(np.maximum(dd.min(1),0)).astype(np.float32)
 pn[:n_small]=np.arange(n_small); pd[:n_small]=0
 indptr,nbr,_=large.get_neighbours()
-for name,mode in (("seq",A.AE_CE_SEQUENTIAL),("seq",A.AE_CE_SEQUENTIAL),("seq",A.AE_CE_SEQUENTIAL),("auto",A.AE_CE_AUTO),("auto",A.AE_CE_AUTO),("auto",A.AE_CE_AUTO),("rounds",A.AE_CE_HOGWILD)):
+for name,mode in (("seq",A.AE_CE_SEQUENTIAL),("seq",A.AE_CE_SEQUENTIAL),("seq",A.AE_CE_SEQUENTIAL),("sliced",A.AE_CE_SLICED),("sliced",A.AE_CE_SLICED),("sliced",A.AE_CE_SLICED),("event",A.AE_CE_EVENT),("event",A.AE_CE_EVENT),("event",A.AE_CE_EVENT),("rounds",A.AE_CE_HOGWILD)):
     par=A.EmbedderParams(asked_dim=2,nb_grad_batch=40,grad_factor=5,scale_rho=0.75,beta=1.0,grad_step=1.0,nb_sampling_by_edge=10,dmap_init=True,hubness_weighting=True,ce_mode=mode)
     emb=A.Embedder.from_hkgraph(A.KGraphProjection(small,large,pn,pd),par)
     emb.embed()

@@ -50,7 +50,7 @@ def stage_small():
     g = A.KGraph(indptr, nbr, dist)
     npar = A.to_proba_edges(g, 1.0, 1.0)
     y0 = np.random.default_rng(0).normal(size=(3000, 2)).astype(np.float32) * 3
-    for mode, name in ((A.AE_CE_EVENT, "event"), (A.AE_CE_SEQUENTIAL, "sequential")):
+    for mode, name in ((A.AE_CE_SLICED, "sliced"), (A.AE_CE_EVENT, "event"), (A.AE_CE_SEQUENTIAL, "sequential")):
         r = run(g, npar, y0, mode, 6, 4664397)
         print(name, "ce0 %.1f ce %.1f drawn %.4f rounds %d finite %s q %s wall %.2f ms/batch" % (
             r["ce0"], r["ce"], r["drawn"], r["rounds"], np.isfinite(r["y"]).all(), np.round(edge_q(indptr, nbr, r["y"]), 4), r["wall_ms_per_batch"]), flush=True)
@@ -71,7 +71,8 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
     hub = kg.hubness() if os.environ.get("FID_HUB") else None
     out = {"kind": kind, "n": n, "nb_batch": nb_batch, "runs": []}
-    for mode, name in ((A.AE_CE_SEQUENTIAL, "sequential"), (A.AE_CE_EVENT, "event"), (A.AE_CE_HOGWILD, "rounds")):
+    modes = ((A.AE_CE_SEQUENTIAL, "sequential"), (A.AE_CE_EVENT, "event"), (A.AE_CE_SLICED, "sliced"), (A.AE_CE_HOGWILD, "rounds"))
+    for mode, name in modes:
         for s in range(seeds):
             r = run(kg, npar, y0, mode, nb_batch, 1000 + s, hub=hub)
             q = edge_q(indptr, nbr, r["y"])
@@ -80,7 +81,7 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     ref = [r for r in out["runs"] if r["mode"] == "sequential"]
     mce = np.mean([r["ce"] for r in ref])
     mq = np.mean([r["q"] for r in ref], axis=0)
-    for name in ("sequential", "event", "rounds"):
+    for name in ("sequential", "event", "sliced", "rounds"):
         rs = [r for r in out["runs"] if r["mode"] == name]
         print("%-10s mean ce/seq %.4f (spread %.4f)  q/seq %s" % (name, np.mean([r["ce"] for r in rs]) / mce, np.std([r["ce"] for r in rs]) / mce,
                                                                np.round(np.mean([r["q"] for r in rs], axis=0) / mq, 3)), flush=True)
@@ -97,7 +98,7 @@ def stage_c2time(nb_batch=6):
     g = A.KGraph(indptr, nbr, dist, k)
     npar = A.to_proba_edges(g, 1.0, 1.0)
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5) * 10
-    for mode, name in ((A.AE_CE_EVENT, "event"), (A.AE_CE_HOGWILD, "rounds"), (A.AE_CE_SEQUENTIAL, "sequential")):
+    for mode, name in ((A.AE_CE_SLICED, "sliced"), (A.AE_CE_EVENT, "event"), (A.AE_CE_HOGWILD, "rounds"), (A.AE_CE_SEQUENTIAL, "sequential")):
         r = run(g, npar, y0, mode, nb_batch, 7)
         print(name, "ce %.0f q %s  wall %.3f ms/batch  kernel %.3f ms/batch drawn %.4f rounds %d" % (
             r["ce"], np.round(edge_q(indptr, nbr, r["y"]), 4), r["wall_ms_per_batch"], r["event_ms_per_batch"], r["drawn"], r["rounds"]), flush=True)
