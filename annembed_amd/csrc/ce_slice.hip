@@ -32,6 +32,9 @@ namespace {
 
 constexpr uint32_t kTagSlCount = 0xFFFF0031u, kTagSlTime = 0xFFFF0032u, kTagSlNeg = 0xFFFF0033u, kTagSlCoin = 0xFFFF0034u;
 constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
+// the pending list is kept as kSub sub-lists with a counter each: appends (one atomic per WORKGROUP) spread over kSub addresses --
+// one counter serialises at ~12 ns per atomic, which with one atomic per wave was 2/3 of a pass at the C3 shape
+constexpr int kSub = 16;
 
 struct EdgeRec {
     uint32_t j;
@@ -45,8 +48,8 @@ struct SliceArgs {
     const uint32_t* ev_edge;    // the batch segment's events sorted by slice: edge ids
     const uint32_t* sptr;       // slice s = events [sptr[s], sptr[s + 1])
     uint32_t* owner;            // [2][n]
-    uint32_t* lists;            // [3][cap]: pending event indices
-    uint32_t* counts;           // [3]
+    uint32_t* lists;            // [3][kSub][cap]: pending event indices, in kSub independent sub-lists (cap entries each)
+    uint32_t* counts;           // [3][kSub]
     uint64_t cap;
     uint32_t slice;
     uint32_t key;               // (batch << 12) | segment
@@ -54,7 +57,7 @@ struct SliceArgs {
     int src_list, dst_list, zero_list, owner_chk, owner_mark;
     int backoff;                // 1: a deferred event marks only with probability 1/2
     double step;
-    unsigned long long* done_counter;
+    unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = overflow flag
 };
 
 __device__ __forceinline__ uint32_t edge_source(const SliceArgs& a, uint32_t e) { return a.c.uniform_k ? e / a.c.uniform_k : a.edge_src[e]; }
@@ -107,24 +110,27 @@ __global__ void sl_edge_src_kernel(uint64_t n, const uint64_t* __restrict__ indp
     for (uint64_t e = indptr[i]; e < indptr[i + 1]; e++) src[e] = (uint32_t)i;
 }
 
-// start of a slice: pending list = what the previous slice left + the slice's own events; every one marks its two rows
+// start of a slice: pending list = what the previous slice left + the slice's own events; every one marks its two rows.
+// Sub-list s (blockIdx.y) takes the leftover sub-list s and every kSub-th event of the slice.
 __global__ void __launch_bounds__(256) sl_mark_kernel(SliceArgs a) {
-    const uint32_t left = a.counts[a.src_list];
+    const uint32_t sub = blockIdx.y;
+    const uint32_t left = a.counts[a.src_list * kSub + sub];
     const uint32_t f0 = a.sptr[a.slice], f1 = a.sptr[a.slice + 1];
-    const uint32_t total = left + (f1 - f0);
-    const uint32_t* src = a.lists + (uint64_t)a.src_list * a.cap;
-    uint32_t* dst = a.lists + (uint64_t)a.dst_list * a.cap;
+    const uint32_t fresh = f1 > f0 + sub ? (f1 - f0 - sub + (uint32_t)kSub - 1u) / (uint32_t)kSub : 0u;
+    const uint32_t total = left + fresh;
+    const uint32_t* src = a.lists + ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    uint32_t* dst = a.lists + ((uint64_t)a.dst_list * kSub + sub) * a.cap;
     for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
-        const uint32_t idx = t < left ? src[t] : f0 + (uint32_t)(t - left);
+        const uint32_t idx = t < left ? src[t] : f0 + sub + (uint32_t)(t - left) * (uint32_t)kSub;
         if (t < a.cap) dst[t] = idx;
         const uint32_t e = a.ev_edge[idx];
         a.owner[(uint64_t)a.owner_mark * a.c.n + edge_source(a, e)] = idx;
         a.owner[(uint64_t)a.owner_mark * a.c.n + a.erec[e].j] = idx;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.counts[a.dst_list] = total < a.cap ? total : (uint32_t)a.cap;  // (the host sizes cap so that this never truncates; flagged otherwise)
-        if (total > a.cap) atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1), 1u);
-        a.counts[a.zero_list] = 0;
+        a.counts[a.dst_list * kSub + sub] = total < a.cap ? total : (uint32_t)a.cap;  // (cap is sized so that this never truncates; flagged otherwise)
+        if (total > a.cap) atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+        a.counts[a.zero_list * kSub + sub] = 0;
     }
 }
 
@@ -132,9 +138,11 @@ __global__ void __launch_bounds__(256) sl_mark_kernel(SliceArgs a) {
 template <int DIM, int KMAX>
 __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
     const CeDev c = a.c;
-    const uint32_t total = a.counts[a.src_list];
-    const uint32_t* src = a.lists + (uint64_t)a.src_list * a.cap;
-    uint32_t* dst = a.lists + (uint64_t)a.dst_list * a.cap;
+    const uint32_t sub = blockIdx.y, dsub = (blockIdx.x + blockIdx.y) % (uint32_t)kSub;
+    const uint32_t total = a.counts[a.src_list * kSub + sub];
+    const uint32_t* src = a.lists + ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    uint32_t* dst = a.lists + ((uint64_t)a.dst_list * kSub + dsub) * a.cap;
+    __shared__ uint32_t s_wave_cnt[4], s_base;
     const uint32_t* own_chk = a.owner + (uint64_t)a.owner_chk * c.n;
     uint32_t* own_mark = a.owner + (uint64_t)a.owner_mark * c.n;
     const bool hub = c.hub_odds != nullptr;
@@ -215,37 +223,42 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
             store_row<DIM>(c.y, i, yi);                                     // :1301
             done++;
         }
-        // deferred: append to the next list (one atomic per wave), mark for the next pass
+        // deferred: append to the next list (one atomic per workgroup, on one of kSub counters), mark for the next pass
         const bool defer = have && !win;
         const unsigned long long m = __ballot(defer);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            uint32_t base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&a.counts[a.dst_list], (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (defer) {
-                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < a.cap) dst[pos] = idx;
-                else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1), 1u);
-                const bool mark = !a.backoff || (pcg_hash(idx ^ pcg_hash(a.pass_seq ^ kTagSlCoin)) & 1u);
-                if (mark) {
-                    own_mark[i] = idx;
-                    own_mark[rec.j] = idx;
-                }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            s_base = tot ? atomicAdd(&a.counts[a.dst_list * kSub + dsub], tot) : 0u;
+        }
+        __syncthreads();
+        if (defer) {
+            uint32_t before = 0;
+            for (int q = 0; q < wv; q++) before += s_wave_cnt[q];
+            const uint32_t pos = s_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < a.cap) dst[pos] = idx;
+            else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+            const bool mark = !a.backoff || (pcg_hash(idx ^ pcg_hash(a.pass_seq ^ kTagSlCoin)) & 1u);
+            if (mark) {
+                own_mark[i] = idx;
+                own_mark[rec.j] = idx;
             }
         }
+        __syncthreads();  // s_wave_cnt / s_base are reused by the next trip
     }
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
-    if ((threadIdx.x & 63) == 0 && done) atomicAdd(a.done_counter, done);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list] = 0;
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;
 }
 
 template <int DIM>
 void launch_exec(const SliceArgs& a, unsigned grid, uint32_t max_nbng) {
     if constexpr (DIM > 0) {
-        if (max_nbng <= 8) hipLaunchKernelGGL((sl_exec_kernel<DIM, 8>), dim3(grid), dim3(256), 0, stream(), a);
-        else if (max_nbng <= 16) hipLaunchKernelGGL((sl_exec_kernel<DIM, 16>), dim3(grid), dim3(256), 0, stream(), a);
-        else hipLaunchKernelGGL((sl_exec_kernel<DIM, 32>), dim3(grid), dim3(256), 0, stream(), a);
+        if (max_nbng <= 8) hipLaunchKernelGGL((sl_exec_kernel<DIM, 8>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+        else if (max_nbng <= 16) hipLaunchKernelGGL((sl_exec_kernel<DIM, 16>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+        else hipLaunchKernelGGL((sl_exec_kernel<DIM, 32>), dim3(grid, kSub), dim3(256), 0, stream(), a);
     }
 }
 
@@ -279,9 +292,9 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     o->sl_pmax = pmax;
     o->sl_owner.alloc(2 * g->n);
     AE_HIP(hipMemsetAsync(o->sl_owner.p, 0xFF, sizeof(uint32_t) * 2 * g->n, stream()));
-    o->sl_counts.alloc(8);
+    o->sl_counts.alloc(3 * kSub);
     o->sl_counts.zero();
-    o->sl_done.alloc(2);
+    o->sl_done.alloc(1025);
     o->sl_done.zero();
     if (!o->sample_counter.n) { o->sample_counter.alloc(1024); o->sample_counter.zero(); }
 }
@@ -303,11 +316,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint64_t ev_cap = (uint64_t)(seg_samples + 8.0 * std::sqrt(seg_samples) + 1024.0);
     // pending-list capacity: a slice's events (+ 8 sigma) plus what hubs may accumulate
     const double per_slice = seg_samples / n_slices;
-    const uint64_t cap = (uint64_t)(4.0 * per_slice + 16.0 * std::sqrt(per_slice) + 65536.0);
+    const uint64_t cap = (uint64_t)((4.0 * per_slice + 16.0 * std::sqrt(per_slice)) / kSub + 8192.0);  // per sub-list
     if (o->sl_cnt.n < nnz) { o->sl_cnt.alloc(nnz); o->sl_offs.alloc(nnz); }
     if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(ev_cap); o->sl_vals1.alloc(ev_cap); }
     if (o->sl_sptr.n < (uint64_t)n_slices + 2) o->sl_sptr.alloc((uint64_t)n_slices + 2);
-    if (o->sl_lists.n < 3 * cap) o->sl_lists.alloc(3 * cap);
+    if (o->sl_lists.n < 3 * (uint64_t)kSub * cap) o->sl_lists.alloc(3 * (uint64_t)kSub * cap);
     unsigned sbits = 1;
     while (sbits < 32 && (n_slices >> sbits)) sbits++;
     SliceArgs a;
@@ -320,7 +333,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     a.cap = cap;
     a.step = grad_step;
     a.done_counter = o->sl_done.p;
-    const unsigned grid_full = (unsigned)std::min<uint64_t>(blocks_for((uint64_t)(per_slice * 1.5) + 4096, 256), 65535u * 4u);
+    const unsigned grid_full = (unsigned)std::min<uint64_t>(blocks_for((uint64_t)(per_slice * 1.5 / kSub) + 512, 256), 65535u);  // per sub-list
     uint32_t pass_seq = 0;
     int cur = 0;  // list that holds what is pending
     o->sl_counts.zero();
@@ -357,14 +370,14 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             a.slice = s;
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
             a.owner_mark = 0;
-            hipLaunchKernelGGL(sl_mark_kernel, dim3(grid_full), dim3(256), 0, stream(), a);
+            hipLaunchKernelGGL(sl_mark_kernel, dim3(grid_full, kSub), dim3(256), 0, stream(), a);
             cur = (cur + 1) % 3;
             for (int p = 0; p < passes; p++) {
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;
                 a.backoff = p >= 1;
                 a.pass_seq = pass_seq++;
-                const unsigned grid = p == 0 ? grid_full : std::max(64u, grid_full >> (2 * p));
+                const unsigned grid = p == 0 ? grid_full : std::max(4u, grid_full >> (2 * p));
                 AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, grid, o->g->max_nbng);
                 cur = (cur + 1) % 3;
             }
@@ -373,33 +386,35 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         }
         // drain: passes until nothing is pending (a look at the counter every 8 passes)
         for (int guard = 0; guard < 100000; guard++) {
-            uint32_t left = 0;
-            AE_HIP(hipMemcpyAsync(&left, o->sl_counts.p + cur, 4, hipMemcpyDeviceToHost, stream()));
+            uint32_t lefts[kSub];
+            AE_HIP(hipMemcpyAsync(lefts, o->sl_counts.p + cur * kSub, 4 * kSub, hipMemcpyDeviceToHost, stream()));
             sync();
+            uint64_t left = 0;
+            for (int q = 0; q < kSub; q++) left += lefts[q];
             if (!left) break;
             if (guard == 99999) fail(AE_ERR_STATE, "AE_CE_SLICED: pending events did not drain");
             // re-mark all (owner[0]) then 8 passes
             a.slice = n_slices;  // empty range: sptr[n_slices] == sptr[n_slices + 1] is arranged below
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
             a.owner_mark = 0;
-            hipLaunchKernelGGL(sl_mark_kernel, dim3(std::max(64u, grid_full >> 2)), dim3(256), 0, stream(), a);
+            hipLaunchKernelGGL(sl_mark_kernel, dim3(std::max(4u, grid_full >> 2), kSub), dim3(256), 0, stream(), a);
             cur = (cur + 1) % 3;
             for (int p = 0; p < 8; p++) {
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;
                 a.backoff = 1;
                 a.pass_seq = pass_seq++;
-                AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, std::max(64u, grid_full >> 2), o->g->max_nbng);
+                AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, std::max(4u, grid_full >> 2), o->g->max_nbng);
                 cur = (cur + 1) % 3;
             }
         }
     }
     check_launch("ce_slice");
-    unsigned long long h[2];
-    o->sl_done.download(h, 2);
-    if (h[1]) fail(AE_ERR_STATE, "AE_CE_SLICED: pending list overflow");
+    std::vector<unsigned long long> h = o->sl_done.to_host();
+    if (h[1024]) fail(AE_ERR_STATE, "AE_CE_SLICED: pending list overflow");
     // samples executed, into the common counter
-    const unsigned long long d = h[0];
+    unsigned long long d = 0;
+    for (int q = 0; q < 1024; q++) d += h[q];
     o->sl_done.zero();
     std::vector<unsigned long long> hc = o->sample_counter.to_host();
     hc[0] += d;
