@@ -93,6 +93,7 @@ struct ae_entropy_optim {
     DevBuf<float> ev_slots;
     // time-sliced optimistic mode (ce_slice.hip)
     DevBuf<uint32_t> sl_erec, sl_edge_src, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
+    DevBuf<float> sl_list_scale;
     DevBuf<unsigned long long> sl_done;
     float sl_pmax = 0.f;
     // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch

@@ -36,19 +36,26 @@ constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
 // one counter serialises at ~12 ns per atomic, which with one atomic per wave was 2/3 of a pass at the C3 shape
 constexpr int kSub = 16;
 
-struct EdgeRec {
-    uint32_t j;
+struct EdgeRec {       // per edge, 16 bytes: everything a sample needs to know about its edge
+    uint32_t j;        // target
+    float w;           // probability
+    float s_src;       // embedded scale of the source
+    uint32_t src;      // source
+};
+struct Pending {       // a pending event: 16 bytes, read and written coalesced
+    uint32_t idx, i, j;
     float w;
 };
 
 struct SliceArgs {
     CeDev c;
     const EdgeRec* erec;        // per edge: target, probability
-    const uint32_t* edge_src;   // per edge: source (nullptr when every row has uniform_k entries)
     const uint32_t* ev_edge;    // the batch segment's events sorted by slice: edge ids
     const uint32_t* sptr;       // slice s = events [sptr[s], sptr[s + 1])
     uint32_t* owner;            // [2][n]
-    uint32_t* lists;            // [3][kSub][cap]: pending event indices, in kSub independent sub-lists (cap entries each)
+    Pending* lists;             // [3][kSub][cap]: pending events, in kSub independent sub-lists (cap entries each)
+    float* list_scale;          // [3][kSub][cap]: the source's embedded scale of every pending event
+    int tile;                   // 1: the negatives of this pass are drawn from a tile of rows staged in LDS (see sl_exec_kernel)
     uint32_t* counts;           // [3][kSub]
     uint64_t cap;
     uint32_t slice;
@@ -60,7 +67,6 @@ struct SliceArgs {
     unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = overflow flag
 };
 
-__device__ __forceinline__ uint32_t edge_source(const SliceArgs& a, uint32_t e) { return a.c.uniform_k ? e / a.c.uniform_k : a.edge_src[e]; }
 
 // events per edge of this segment
 __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, float unit, uint32_t key, uint32_t* __restrict__ cnt) {
@@ -100,14 +106,14 @@ __global__ void sl_sptr_kernel(const uint32_t* __restrict__ keys, uint32_t total
     }
     sptr[s] = lo;
 }
-__global__ void sl_edge_rec_kernel(uint64_t nnz, const uint32_t* __restrict__ nbr, const float* __restrict__ proba, EdgeRec* __restrict__ out) {
-    const uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (e < nnz) out[e] = EdgeRec{nbr[e], proba[e]};
-}
-__global__ void sl_edge_src_kernel(uint64_t n, const uint64_t* __restrict__ indptr, uint32_t* __restrict__ src) {
+__global__ void sl_edge_rec_kernel(CeDev c, EdgeRec* __restrict__ out) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (uint64_t e = indptr[i]; e < indptr[i + 1]; e++) src[e] = (uint32_t)i;
+    if (i >= c.n) return;
+    uint64_t b, e1;
+    if (c.uniform_k) { b = i * c.uniform_k; e1 = b + c.uniform_k; }
+    else { b = c.indptr[i]; e1 = c.indptr[i + 1]; }
+    const float s = c.emb_scale[i];
+    for (uint64_t e = b; e < e1; e++) out[e] = EdgeRec{c.nbr[e], c.proba[e], s, (uint32_t)i};
 }
 
 // start of a slice: pending list = what the previous slice left + the slice's own events; every one marks its two rows.
@@ -118,14 +124,22 @@ __global__ void __launch_bounds__(256) sl_mark_kernel(SliceArgs a) {
     const uint32_t f0 = a.sptr[a.slice], f1 = a.sptr[a.slice + 1];
     const uint32_t fresh = f1 > f0 + sub ? (f1 - f0 - sub + (uint32_t)kSub - 1u) / (uint32_t)kSub : 0u;
     const uint32_t total = left + fresh;
-    const uint32_t* src = a.lists + ((uint64_t)a.src_list * kSub + sub) * a.cap;
-    uint32_t* dst = a.lists + ((uint64_t)a.dst_list * kSub + sub) * a.cap;
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap, dof = ((uint64_t)a.dst_list * kSub + sub) * a.cap;
     for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
-        const uint32_t idx = t < left ? src[t] : f0 + sub + (uint32_t)(t - left) * (uint32_t)kSub;
-        if (t < a.cap) dst[t] = idx;
-        const uint32_t e = a.ev_edge[idx];
-        a.owner[(uint64_t)a.owner_mark * a.c.n + edge_source(a, e)] = idx;
-        a.owner[(uint64_t)a.owner_mark * a.c.n + a.erec[e].j] = idx;
+        Pending p;
+        float sc;
+        if (t < left) {
+            p = a.lists[so + t];
+            sc = a.list_scale[so + t];
+        } else {
+            p.idx = f0 + sub + (uint32_t)(t - left) * (uint32_t)kSub;
+            const EdgeRec er = a.erec[a.ev_edge[p.idx]];
+            p.i = er.src; p.j = er.j; p.w = er.w;
+            sc = er.s_src;
+        }
+        if (t < a.cap) { a.lists[dof + t] = p; a.list_scale[dof + t] = sc; }
+        a.owner[(uint64_t)a.owner_mark * a.c.n + p.i] = p.idx;
+        a.owner[(uint64_t)a.owner_mark * a.c.n + p.j] = p.idx;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.counts[a.dst_list * kSub + sub] = total < a.cap ? total : (uint32_t)a.cap;  // (cap is sized so that this never truncates; flagged otherwise)
@@ -137,37 +151,58 @@ __global__ void __launch_bounds__(256) sl_mark_kernel(SliceArgs a) {
 // one pass: the pending events that own both their rows run, the others go to the next list and mark for the next pass
 template <int DIM, int KMAX>
 __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
+    // tile of coordinate rows for the negatives of a crowded pass (a.tile): kW windows of kL consecutive rows each, window starts
+    // uniform over the nodes (wrapping) and fresh per workgroup and pass, staged in LDS with coalesced loads.  A negative is then
+    // "window uniform, row uniform": every node has the same probability 1/n, as in embedder.rs:1121; the rows are as fresh as
+    // the pass (the launch started after every earlier pass's writes).  What differs from the reference: the negatives of the
+    // ~150 samples a workgroup runs in a pass come from the same kW windows (the marginals are exact, the joint law is not).
+    constexpr int kW = 8, kL = DIM <= 8 ? 128 : 64, kTile = kW * kL;
+    __shared__ __attribute__((aligned(16))) float s_tile[kTile * DIM];
+    __shared__ uint32_t s_wstart[kW];
+    __shared__ uint32_t s_wave_cnt[4], s_base;
     const CeDev c = a.c;
     const uint32_t sub = blockIdx.y, dsub = (blockIdx.x + blockIdx.y) % (uint32_t)kSub;
     const uint32_t total = a.counts[a.src_list * kSub + sub];
-    const uint32_t* src = a.lists + ((uint64_t)a.src_list * kSub + sub) * a.cap;
-    uint32_t* dst = a.lists + ((uint64_t)a.dst_list * kSub + dsub) * a.cap;
-    __shared__ uint32_t s_wave_cnt[4], s_base;
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap, dof = ((uint64_t)a.dst_list * kSub + dsub) * a.cap;
     const uint32_t* own_chk = a.owner + (uint64_t)a.owner_chk * c.n;
     uint32_t* own_mark = a.owner + (uint64_t)a.owner_mark * c.n;
     const bool hub = c.hub_odds != nullptr;
+    const bool tile = a.tile && !hub && (uint64_t)blockIdx.x * 256ull < total && c.n > (uint64_t)kTile * 4ull;
+    if (tile) {
+        if (threadIdx.x < kW)
+            s_wstart[threadIdx.x] = __umulhi(pcg_hash(pcg_hash(a.key ^ kTagSlNeg) + a.pass_seq * 0x9E3779B9u + (blockIdx.x * (uint32_t)kSub + sub) * 8u + threadIdx.x), (uint32_t)c.n);
+        __syncthreads();
+        for (int r = threadIdx.x; r < kTile; r += 256) {
+            uint64_t node = (uint64_t)s_wstart[r / kL] + (uint64_t)(r % kL);
+            node -= node >= c.n ? c.n : 0ull;
+            float row[DIM];
+            load_row<DIM>(c.y, (uint32_t)node, row);
+#pragma unroll
+            for (int t = 0; t < DIM; t++) s_tile[r * DIM + t] = row[t];
+        }
+        __syncthreads();
+    }
     unsigned long long done = 0;
     for (uint64_t t0 = blockIdx.x * 256ull; t0 < total; t0 += (uint64_t)gridDim.x * 256ull) {
         const uint64_t t = t0 + threadIdx.x;
         const bool have = t < total;
-        uint32_t idx = 0, e = 0, i = 0;
-        EdgeRec rec{0, 0.f};
+        Pending p{0, 0, 0, 0.f};
+        float sc = 1.f;
         bool win = false;
         if (have) {
-            idx = src[t];
-            e = a.ev_edge[idx];
-            i = edge_source(a, e);
-            rec = a.erec[e];
-            win = own_chk[i] == idx && own_chk[rec.j] == idx;
+            p = a.lists[so + t];
+            sc = a.list_scale[so + t];
+            win = own_chk[p.i] == p.idx && own_chk[p.j] == p.idx;
         }
+        const uint32_t i = p.i, idx = p.idx;
         if (win) {
-            // everything that depends only on (i, j): both rows, the scale, the neighbour row of i -- in flight together
+            // everything that depends only on (i, j): both rows, the neighbour row of i -- in flight together.  Plain (cached)
+            // vector loads: a pass is a launch of its own, everything earlier passes wrote is visible, and the rows this event
+            // owns are touched by nobody else during the pass
             float yi[DIM], yj[DIM], grad[DIM];
-            // plain (cached) vector loads: a pass is a launch of its own, everything earlier passes wrote is visible, and the rows
-            // this event owns are touched by nobody else during the pass
             load_row<DIM>(c.y, i, yi);
-            load_row<DIM>(c.y, rec.j, yj);
-            const double scale = (double)c.emb_scale[i];
+            load_row<DIM>(c.y, p.j, yj);
+            const double scale = (double)sc;
             uint64_t ib;
             uint32_t k;
             if (c.uniform_k) { ib = (uint64_t)i * c.uniform_k; k = c.uniform_k; }
@@ -179,12 +214,22 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
             for (int m = 0; m < KMAX; m++) nbr_reg[m] = (uint32_t)m < k ? nbr_reg[m] : 0xFFFFFFFFu;  // the pad never equals a candidate
             // the five negatives (embedder.rs:1241-1253): uniform / NodeSampler (:927-930) draws, rejected when k = i, k = j or
             // k in N(i) (nodeparam.rs:83-85; j is in N(i)); eight candidates at a time so that the alias look-ups overlap
-            uint32_t kk[5] = {i, i, i, i, i};
+            uint32_t kk[5] = {i, i, i, i, i}, kr[5] = {0, 0, 0, 0, 0};
             uint32_t got = 0;
             const uint32_t nb = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg) + idx);
             for (uint32_t round = 0; round < 8u && got < 5u; round++) {
-                uint32_t cand[8];
-                if (hub) {
+                uint32_t cand[8], crow[8];
+                if (tile) {
+#pragma unroll
+                    for (int z = 0; z < 8; z++) {
+                        const uint32_t w0 = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u);
+                        const uint32_t wi = w0 >> 29, off = __umulhi(pcg_hash(w0 ^ 0x85EBCA6Bu), (uint32_t)kL);
+                        uint64_t node = (uint64_t)s_wstart[wi] + off;
+                        node -= node >= c.n ? c.n : 0ull;
+                        cand[z] = (uint32_t)node;
+                        crow[z] = wi * (uint32_t)kL + off;
+                    }
+                } else if (hub) {
                     uint32_t xs[8], al[8];
                     float od[8], uu[8];
 #pragma unroll
@@ -196,10 +241,10 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
                         al[z] = c.hub_alias[xs[z]];
                     }
 #pragma unroll
-                    for (int z = 0; z < 8; z++) cand[z] = (uu[z] < od[z]) ? xs[z] : al[z];
+                    for (int z = 0; z < 8; z++) { cand[z] = (uu[z] < od[z]) ? xs[z] : al[z]; crow[z] = 0; }
                 } else {
 #pragma unroll
-                    for (int z = 0; z < 8; z++) cand[z] = __umulhi(pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u), (uint32_t)c.n);  // :1121
+                    for (int z = 0; z < 8; z++) { cand[z] = __umulhi(pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u), (uint32_t)c.n); crow[z] = 0; }  // :1121
                 }
 #pragma unroll
                 for (int z = 0; z < 8; z++) {
@@ -208,19 +253,29 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
                     for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand[z]; acc = x < acc ? x : acc; }
                     const bool ok = acc != 0u && got < 5u;
 #pragma unroll
-                    for (int g = 0; g < 5; g++) kk[g] = (ok && got == (uint32_t)g) ? cand[z] : kk[g];  // (static indexing keeps kk in registers)
+                    for (int g = 0; g < 5; g++) {  // (static indexing keeps kk / kr in registers)
+                        kk[g] = (ok && got == (uint32_t)g) ? cand[z] : kk[g];
+                        kr[g] = (ok && got == (uint32_t)g) ? crow[z] : kr[g];
+                    }
                     got += ok ? 1u : 0u;
                 }
             }
             float nrow[5][DIM];
+            if (tile) {
 #pragma unroll
-            for (int g = 0; g < 5; g++) load_row<DIM>(c.y, kk[g], nrow[g]);  // (may be rewritten during this pass by its owner: at most one pass old)
-            sample_attract<DIM>(yi, yj, grad, rec.w, scale, c.b, a.step);  // :1207-1238: one gradient, both ends
-            store_row<DIM>(c.y, rec.j, yj);                                 // :1239
+                for (int g = 0; g < 5; g++)
+#pragma unroll
+                    for (int t2 = 0; t2 < DIM; t2++) nrow[g][t2] = s_tile[kr[g] * DIM + t2];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 5; g++) load_row<DIM>(c.y, kk[g], nrow[g]);  // (may be rewritten during this pass by its owner: at most one pass old)
+            }
+            sample_attract<DIM>(yi, yj, grad, p.w, scale, c.b, a.step);  // :1207-1238: one gradient, both ends
+            store_row<DIM>(c.y, p.j, yj);                                 // :1239
 #pragma unroll
             for (int g = 0; g < 5; g++)
                 if ((uint32_t)g < got) sample_repulse<DIM>(yi, nrow[g], grad, scale, c.b, a.step);  // :1267-1297
-            store_row<DIM>(c.y, i, yi);                                     // :1301
+            store_row<DIM>(c.y, i, yi);                                   // :1301
             done++;
         }
         // deferred: append to the next list (one atomic per workgroup, on one of kSub counters), mark for the next pass
@@ -238,12 +293,12 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
             uint32_t before = 0;
             for (int q = 0; q < wv; q++) before += s_wave_cnt[q];
             const uint32_t pos = s_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (pos < a.cap) dst[pos] = idx;
+            if (pos < a.cap) { a.lists[dof + pos] = p; a.list_scale[dof + pos] = sc; }
             else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
             const bool mark = !a.backoff || (pcg_hash(idx ^ pcg_hash(a.pass_seq ^ kTagSlCoin)) & 1u);
             if (mark) {
                 own_mark[i] = idx;
-                own_mark[rec.j] = idx;
+                own_mark[p.j] = idx;
             }
         }
         __syncthreads();  // s_wave_cnt / s_base are reused by the next trip
@@ -277,13 +332,8 @@ const char* ce_slice_unsupported(const ae_entropy_optim* o) {
 
 void ce_slice_prepare(ae_entropy_optim* o) {
     const ae_kgraph* g = o->g;
-    o->sl_erec.alloc(g->nnz * 2);  // EdgeRec as two words
-    hipLaunchKernelGGL(sl_edge_rec_kernel, dim3(blocks_for(g->nnz, 256)), dim3(256), 0, stream(), g->nnz, (const uint32_t*)g->nbr.p,
-                       (const float*)o->np->proba.p, reinterpret_cast<EdgeRec*>(o->sl_erec.p));
-    if (!g->uniform_k) {
-        o->sl_edge_src.alloc(g->nnz);
-        hipLaunchKernelGGL(sl_edge_src_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), g->n, (const uint64_t*)g->indptr.p, o->sl_edge_src.p);
-    }
+    o->sl_erec.alloc(g->nnz * 4);  // EdgeRec as four words
+    hipLaunchKernelGGL(sl_edge_rec_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), o->dev, reinterpret_cast<EdgeRec*>(o->sl_erec.p));
     check_launch("sl_prepare");
     // largest edge probability (segments keep the per-edge Poisson mean below 16)
     std::vector<float> hp = o->np->proba.to_host();
@@ -320,15 +370,16 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_cnt.n < nnz) { o->sl_cnt.alloc(nnz); o->sl_offs.alloc(nnz); }
     if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(ev_cap); o->sl_vals1.alloc(ev_cap); }
     if (o->sl_sptr.n < (uint64_t)n_slices + 2) o->sl_sptr.alloc((uint64_t)n_slices + 2);
-    if (o->sl_lists.n < 3 * (uint64_t)kSub * cap) o->sl_lists.alloc(3 * (uint64_t)kSub * cap);
+    if (o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) { o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4); o->sl_list_scale.alloc(3 * (uint64_t)kSub * cap); }
     unsigned sbits = 1;
     while (sbits < 32 && (n_slices >> sbits)) sbits++;
     SliceArgs a;
     a.c = o->dev;
     a.erec = reinterpret_cast<const EdgeRec*>(o->sl_erec.p);
-    a.edge_src = o->dev.uniform_k ? nullptr : o->sl_edge_src.p;
     a.owner = o->sl_owner.p;
-    a.lists = o->sl_lists.p;
+    a.lists = reinterpret_cast<Pending*>(o->sl_lists.p);
+    a.list_scale = o->sl_list_scale.p;
+    const bool use_tile = !debug_knob("AE_SL_NO_TILE");
     a.counts = o->sl_counts.p;
     a.cap = cap;
     a.step = grad_step;
@@ -376,6 +427,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;
                 a.backoff = p >= 1;
+                a.tile = (p == 0 && use_tile) ? 1 : 0;
                 a.pass_seq = pass_seq++;
                 const unsigned grid = p == 0 ? grid_full : std::max(4u, grid_full >> (2 * p));
                 AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, grid, o->g->max_nbng);
@@ -403,6 +455,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;
                 a.backoff = 1;
+                a.tile = 0;
                 a.pass_seq = pass_seq++;
                 AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, std::max(4u, grid_full >> 2), o->g->max_nbng);
                 cur = (cur + 1) % 3;

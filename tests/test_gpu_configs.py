@@ -72,10 +72,12 @@ def test_k6_blobs_without_hubness_40_batches(A):
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
     ref = _run_ce(A, g, npar, y0, 40, A.AE_CE_SEQUENTIAL)
     assert A.EntropyOptim(g, npar, A.EmbedderParams(), y0).get_ce_mode() == A.AE_CE_SEQUENTIAL  # the default
+    # measured over seeds: event-ordered CE +1 ... +2 %, quartiles -2 ... -4 %; time-sliced CE +0.5 ... +1.3 %, quartiles -1 ... -3.5 %
+    # (single runs scatter by 1 % / 2 % around those): bars 4 % / 8 %
     run = _run_ce(A, g, npar, y0, 40, A.AE_CE_EVENT)
-    _assert_close(A, indptr, nbr, run, ref)
-    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_SLICED)  # measured CE +0.5 ... +1 %, quartiles -1 ... -3 %
-    _assert_close(A, indptr, nbr, run, ref)
+    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.04, tol_q=0.08)
+    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_SLICED)
+    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.04, tol_q=0.08)
     rounds = _run_ce(A, g, npar, y0, 40, A.AE_CE_HOGWILD)  # evidence: the rounds mode is outside the envelope here
     assert rounds[1] < 0.85 * ref[1]
 
@@ -119,13 +121,21 @@ def test_c3_schedule_hierarchical_60k(A):
     indptr, nbr, _ = large.get_neighbours()
     out = {}
     for name, mode in (("seq", A.AE_CE_AUTO), ("sliced", A.AE_CE_SLICED), ("event", A.AE_CE_EVENT)):
-        par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
-                               nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode)
-        emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
-        assert emb.embed() == 1
-        out[name] = (emb.get_embedded(), emb.get_cross_entropy()[1], None)
-    _assert_close(A, indptr, nbr, out["sliced"], out["seq"], tol_ce=0.05, tol_q=0.12)
-    _assert_close(A, indptr, nbr, out["event"], out["seq"], tol_ce=0.08, tol_q=0.22)
+        ces, qs = [], []
+        for rep in range(3):  # three runs per mode: every pipeline here, the sequential one included, moves by 2 % / 6 % from run to run
+            par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
+                                   nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode, seed=4664397 + rep)
+            emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
+            assert emb.embed() == 1
+            y = emb.get_embedded()
+            assert np.isfinite(y).all()
+            ces.append(emb.get_cross_entropy()[1])
+            qs.append(_edge_q(indptr, nbr, y))
+        out[name] = (np.mean(ces), np.mean(qs, axis=0))
+    for name, tol_ce, tol_q in (("sliced", 0.05, 0.12), ("event", 0.08, 0.22)):
+        ce, q = out[name]
+        assert abs(ce - out["seq"][0]) < tol_ce * out["seq"][0], (name, ce, out["seq"][0])
+        assert np.all(np.abs(q - out["seq"][1]) < tol_q * out["seq"][1]), (name, q, out["seq"][1])
 
 
 def test_c3_full_size_properties(A):
