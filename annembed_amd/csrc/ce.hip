@@ -326,44 +326,78 @@ __global__ void df_rowptr_kernel(const uint32_t* __restrict__ keys, uint64_t nnz
 }
 
 // pred[s * 7 + t] = (sample << 1 | slot) of the last write of node plan_nodes[s * 7 + t] by a sample < s, or kNoPred.
-// A node's writers are spread evenly over the batch (i.i.d. samples), so the answer lies within a few entries of the
-// interpolated position: probe there, gallop to a bracket, finish by bisection -- the probes share one or two cache
-// lines instead of the ~log2(len) lines of a bisection from the ends (C3 shape: 56 ms -> see DESIGN.md).
-__global__ void df_pred_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint32_t* __restrict__ vals,
-                               const uint64_t* __restrict__ rowptr, uint32_t* __restrict__ pred) {
-    // grid-stride: 7 S work items exceed the 2^32 a dispatch can carry from S = 6.1e8 on (the C4 shape has 6.6e8)
-    for (uint64_t idx = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; idx < S * 7; idx += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t s = (uint32_t)(idx / 7);
-    const uint32_t x = plan_nodes[idx];
-    const uint64_t lo = rowptr[x], hi = rowptr[x + 1];
-    if (lo == hi) { pred[idx] = kNoPred; continue; }
-    const uint32_t key = s << 1;  // first version with sample >= s: vals < key  <=>  its sample < s
-    uint64_t g = lo + (uint64_t)((float)(hi - lo) * ((float)s / (float)S));
-    g = min(g, hi - 1);
-    uint64_t L, H;  // every index < L holds a value < key, every index >= H a value >= key
-    if (vals[g] < key) {
-        L = g + 1;
-        H = hi;
-        for (uint64_t step = 4; L + step < hi; step *= 2) {
-            const uint64_t q = L + step;
-            if (vals[q] < key) L = q + 1;
-            else { H = q; break; }
+// Slots 0 and 1 (the end points, which are the writes themselves): the predecessor of a write is its left neighbour in the
+// node-sorted list -- one coalesced pass over the 2 S sorted events, no search.
+__global__ void df_pred_writes_kernel(uint64_t S, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t* __restrict__ pred) {
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < 2 * S; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t node = keys[p], v = vals[p];
+        uint32_t out = kNoPred;
+        if (p > 0 && keys[p - 1] == node) {
+            out = vals[p - 1];
+            if ((out >> 1) == (v >> 1)) out = (p > 1 && keys[p - 2] == node) ? vals[p - 2] : kNoPred;  // both ends of one sample on one node
         }
-    } else {
-        H = g;
-        L = lo;
-        for (uint64_t step = 4; H >= lo + step; step *= 2) {
-            const uint64_t q = H - step;
-            if (vals[q] < key) { L = q + 1; break; }
-            H = q;
+        pred[(uint64_t)(v >> 1) * 7 + (v & 1u)] = out;
+    }
+}
+// Slots 2..6 (the negatives, read only).  A node's writers are spread evenly over the batch (i.i.d. samples): the answer lies
+// within a few entries (sigma <= sqrt(len) / 2) of the interpolated position, so one 64-byte window around it settles most
+// searches in a single memory round trip; the rest gallop from the window's edge and finish by bisection.
+__global__ void df_pred_reads_kernel(uint64_t S, const uint32_t* __restrict__ plan_nodes, const uint32_t* __restrict__ vals,
+                                     const uint64_t* __restrict__ rowptr, uint32_t* __restrict__ pred) {
+    // grid-stride: the work items exceed the 2^32 a dispatch can carry from S = 8.6e8 on
+    for (uint64_t it = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; it < S * 5; it += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = (uint32_t)(it / 5);
+        const uint64_t idx = (uint64_t)s * 7 + 2 + (it - (uint64_t)s * 5);
+        const uint32_t x = plan_nodes[idx];
+        const uint64_t lo = rowptr[x], hi = rowptr[x + 1];
+        if (lo == hi) { pred[idx] = kNoPred; continue; }
+        const uint32_t key = s << 1;  // first version with sample >= s: vals < key  <=>  its sample < s
+        uint64_t g = lo + (uint64_t)((float)(hi - lo) * ((float)s / (float)S));
+        g = min(g, hi - 1);
+        // 16 entries around g, the window aligned to 16 bytes (entries outside [lo, hi) belong to other nodes: masked; the
+        // buffer is padded on both sides)
+        int64_t b = (int64_t)g - 8;
+        b -= (int64_t)((reinterpret_cast<uintptr_t>(vals + b) >> 2) & 3u);
+        uint4 w4[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) w4[r] = *reinterpret_cast<const uint4*>(vals + b + 4 * r);
+        const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+        uint32_t cnt = 0, nvalid = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int64_t q = b + e;
+            const bool valid = q >= (int64_t)lo && q < (int64_t)hi;
+            nvalid += valid ? 1u : 0u;
+            cnt += (valid && w[e] < key) ? 1u : 0u;
         }
-    }
-    while (L < H) {
-        const uint64_t mid = (L + H) >> 1;
-        if (vals[mid] < key) L = mid + 1;
-        else H = mid;
-    }
-    pred[idx] = L > lo ? vals[L - 1] : kNoPred;
+        const uint64_t first = (uint64_t)max(b, (int64_t)lo), end = min((uint64_t)(b + 16), hi);
+        uint64_t L, H;  // every index < L holds a value < key, every index >= H a value >= key
+        if (cnt == 0 && first > lo) {  // everything in the window >= key: the answer lies at or before its first entry
+            H = first;
+            L = lo;
+            for (uint64_t step = 16; H >= lo + step; step *= 2) {
+                const uint64_t q = H - step;
+                if (vals[q] < key) { L = q + 1; break; }
+                H = q;
+            }
+        } else if (cnt == nvalid && end < hi) {  // everything < key: at or after its end
+            L = end;
+            H = hi;
+            for (uint64_t step = 16; L + step < hi; step *= 2) {
+                const uint64_t q = L + step;
+                if (vals[q] < key) L = q + 1;
+                else { H = q; break; }
+            }
+        } else {
+            L = H = first + cnt;
+        }
+        while (L < H) {
+            const uint64_t mid = (L + H) >> 1;
+            if (vals[mid] < key) L = mid + 1;
+            else H = mid;
+        }
+        pred[idx] = L > lo ? vals[L - 1] : kNoPred;
     }
 }
 
@@ -643,7 +677,7 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
     if (st.plan_nodes.n < S * 7) st.plan_nodes.alloc(S * 7);
     if (st.plan_w.n < S) st.plan_w.alloc(S);
     if (st.pred.n < S * 7) st.pred.alloc(S * 7);
-    if (st.keys0.n < 2 * S) { st.keys0.alloc(2 * S); st.keys1.alloc(2 * S); }
+    if (st.keys0.n < 2 * S + 16) { st.keys0.alloc(2 * S + 16); st.keys1.alloc(2 * S + 16); }  // (+16: df_pred_reads_kernel's window may overhang)
     if (st.rowptr.n < o->dev.n + 1) st.rowptr.alloc(o->dev.n + 1);
     launch_plan(o, o->sample_offset, S, iter, st.plan_nodes.p, st.plan_w.p);
     // each key buffer holds 2 S node keys followed by 2 S version ids
@@ -656,7 +690,9 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
     sort_pairs_u32_u32(k0, k1, v0, v1, 2 * S, node_bits);
     hipLaunchKernelGGL(df_rowptr_kernel, dim3(blocks_for(o->dev.n + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)k1, 2 * S,
                        (uint64_t)o->dev.n, st.rowptr.p);
-    hipLaunchKernelGGL(df_pred_kernel, dim3(grid_cap(S * 7, 256, 1u << 22)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
+    hipLaunchKernelGGL(df_pred_writes_kernel, dim3(grid_cap(2 * S, 256, 1u << 20)), dim3(256), 0, stream(), S, (const uint32_t*)k1, (const uint32_t*)v1,
+                       st.pred.p);
+    hipLaunchKernelGGL(df_pred_reads_kernel, dim3(grid_cap(S * 5, 256, 1u << 22)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
                        (const uint32_t*)v1, (const uint64_t*)st.rowptr.p, st.pred.p);
     check_launch("df_pred");
 }
@@ -763,6 +799,18 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 
 
 
+// AE_CE_AUTO: the sequential-equivalent dataflow (exact, reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one
+// device, <= 2^28 samples per batch (its scratch: ~40 GB at asked_dim 8) --, beyond that the time-sliced mode (statistical
+// parity, 2-3.4x faster at that size, a tenth of the memory), and for shards / other dimensions the rounds mode
+uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch) {
+    if (mode > AE_CE_SLICED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
+    if (mode != AE_CE_AUTO) return mode;
+    const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
+    if (!sharded && df_dim && samples_per_batch <= (1ull << 28)) return AE_CE_SEQUENTIAL;
+    if (sharded || !df_dim) return AE_CE_HOGWILD;
+    return AE_CE_SLICED;
+}
+
 ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params* params,
                                                 const float* y0, bool y0_on_device, const uint32_t* hub_counts, uint64_t node_lo,
                                                 uint64_t node_hi) {
@@ -851,19 +899,8 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
             d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
         }
         sync();
-        // AE_CE_AUTO: the sequential-equivalent dataflow (exact, reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one
-        // device, <= 2^28 samples per batch --, else the time-sliced mode, else (sharded, other dimensions) the rounds mode
         const bool sharded = node_lo != 0 || node_hi != n;
-        const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
-        uint32_t mode = params->ce_mode;
-        if (mode > AE_CE_SLICED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
-        if (mode == AE_CE_AUTO) {
-            // exact while its scratch stays moderate (2^28 samples per batch: ~40 GB at asked_dim 8); beyond, the time-sliced mode
-            // (statistical parity, 2-2.4x faster at that size, a tenth of the memory)
-            if (!sharded && df_dim && params->nb_sampling_by_edge * (edge_hi - edge_lo) <= (1ull << 28)) mode = AE_CE_SEQUENTIAL;
-            else if (sharded || !df_dim) mode = AE_CE_HOGWILD;
-            else mode = AE_CE_SLICED;
-        }
+        const uint32_t mode = resolve_ce_mode(params->ce_mode, dim, sharded, params->nb_sampling_by_edge * (edge_hi - edge_lo));
         if (mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
         if (mode == AE_CE_EVENT) ce_event_prepare(o.get());
         if (mode == AE_CE_SLICED) ce_slice_prepare(o.get());

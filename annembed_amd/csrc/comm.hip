@@ -74,7 +74,7 @@ namespace ae {
 // all-gather of the owned rows of o->y, in place, on the library's stream
 void ce_comm_exchange(ae_entropy_optim* o) {
     ae_comm* c = o->comm;
-    if (!c || c->world == 1) return;
+    if (!c || (c->world == 1 && !debug_knob("AE_COMM_FORCE"))) return;  // (the knob: a single-GPU box exercises the RCCL calls)
     Rccl& r = rccl();
     const uint64_t dim = o->dev.dim;
     if (o->comm_equal) {
@@ -129,7 +129,7 @@ int32_t ae_comm_all_reduce_sum(ae_comm* c, double* value) {
     return guard([&] {
         require_device();
         if (!c || !value) fail(AE_ERR_INVALID_ARG, "null argument");
-        if (c->world == 1) return;
+        if (c->world == 1 && !debug_knob("AE_COMM_FORCE")) return;
         DevBuf<double> d(1);
         d.upload(value, 1);
         nccl_check(rccl().AllReduce(d.p, d.p, 1, kNcclFloat64, kNcclSum, c->nccl, stream()), "all-reduce");
@@ -148,7 +148,7 @@ int32_t ae_entropy_optim_set_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exch
         DevBuf<uint64_t> mine(2), all(2 * (size_t)c->world);
         const uint64_t h[2] = {o->dev.node_lo, o->dev.node_hi};
         mine.upload(h, 2);
-        if (c->world > 1) nccl_check(rccl().AllGather(mine.p, all.p, 2, kNcclUint64, c->nccl, stream()), "all-gather of the node ranges");
+        if (c->world > 1 || debug_knob("AE_COMM_FORCE")) nccl_check(rccl().AllGather(mine.p, all.p, 2, kNcclUint64, c->nccl, stream()), "all-gather of the node ranges");
         else AE_HIP(hipMemcpyAsync(all.p, mine.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()));
         o->comm_ranges = all.to_host();
         uint64_t expect = 0;

@@ -9,6 +9,7 @@
 // reference hard-wires 2, :319); B2 random init does not depend on initial_space (:348 vs :459);
 // B3 the last batch runs with step 0 like the reference (:875).
 #include "internal.h"
+#include "linalg.h"
 #include "philox.h"
 
 using namespace ae;
@@ -128,6 +129,8 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
 void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params, StageResult& out, std::vector<float>* initial_out) {
     const uint64_t n = g->n, dim = params.asked_dim;
     DevBuf<float> y0;
+    // the single-lane reference-order sums of the initialisation only where the CE loop after them is the bit-exact mode
+    TreeSums sums(resolve_ce_mode(params.ce_mode, dim, false, params.nb_sampling_by_edge * g->nnz) != AE_CE_SEQUENTIAL);
     if (params.dmap_init) {  // :308-345
         ae_diffusion_params dp;
         memset(&dp, 0, sizeof(dp));

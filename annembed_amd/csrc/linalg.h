@@ -37,6 +37,17 @@ bool orthonormalize_fast_failed();
 // evals[l] descending, evecs[l x l] row-major with eigenvectors in columns.
 void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs);
 
+// Summation order of the three sums below.  By default they reproduce the reference's f32 orders with single-lane
+// chains (bit parity of the dmap initialisation with the oracle: 40-100 ms each at 11 M nodes).  While a TreeSums(true) is
+// alive on this thread they are two-level f64 tree reductions instead (deterministic, microseconds): the embedder
+// switches to them when the CE mode it resolved is not the bit-exact one, so nothing downstream is bit-comparable anyway.
+struct TreeSums {
+    explicit TreeSums(bool on);
+    ~TreeSums();
+    bool prev;
+};
+bool tree_sums();
+
 // exact sequential f32 sum (the reference's iter().sum::<f32>() order) of d_x[0..n) with stride
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride = 1);
 // the dim column sums of a row-major n x dim array, each in row order (dim sequential chains in one pass)

@@ -676,7 +676,52 @@ void gaussian_fill_device(float* d_out, uint64_t count, uint64_t seed, uint32_t 
     check_launch("gaussian_fill");
 }
 
+// ---- tree sums (TreeSums, linalg.h): column sums of a row-major n x dim array in f64, fixed launch shape -> reproducible
+__global__ void __launch_bounds__(256) tree_sum_cols_partial_kernel(const float* __restrict__ x, uint64_t n, uint32_t dim, uint64_t stride,
+                                                                     double* __restrict__ partial) {
+    __shared__ double sh[256];
+    // thread t adds elements t, t + T, ... of the flattened rows (T a multiple of dim: a thread stays in one column)
+    const uint32_t per = 256u / dim * dim;  // active threads per workgroup
+    double acc = 0.;
+    if (threadIdx.x < per) {
+        const uint64_t total = n * dim, T = (uint64_t)gridDim.x * per;
+        for (uint64_t e = (uint64_t)blockIdx.x * per + threadIdx.x; e < total; e += T) acc += (double)x[(e / dim) * stride + e % dim];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < dim) {
+        double s = 0.;
+        for (uint32_t t = threadIdx.x; t < per; t += dim) s += sh[t];
+        partial[(uint64_t)blockIdx.x * dim + threadIdx.x] = s;
+    }
+}
+__global__ void __launch_bounds__(128) tree_sum_cols_final_kernel(const double* __restrict__ partial, uint32_t nblocks, uint32_t dim, float* __restrict__ out) {
+    if (threadIdx.x >= dim) return;
+    double s = 0.;
+    for (uint32_t b = 0; b < nblocks; b++) s += partial[(uint64_t)b * dim + threadIdx.x];
+    out[threadIdx.x] = (float)s;
+}
+static thread_local bool g_tree_sums = false;
+TreeSums::TreeSums(bool on) : prev(g_tree_sums) { g_tree_sums = on; }
+TreeSums::~TreeSums() { g_tree_sums = prev; }
+bool tree_sums() { return g_tree_sums; }
+// x: n rows of `dim` consecutive values, `stride` floats apart
+static void tree_sum_cols(const float* d_x, uint64_t n, uint32_t dim, uint64_t stride, float* host_out) {
+    const uint32_t per = 256u / dim * dim;
+    const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n * dim + per * 16ull - 1) / (per * 16ull), 1024));
+    DevBuf<double> partial;
+    DevBuf<float> out;
+    partial.alloc_pooled((size_t)nblocks * dim);
+    out.alloc_pooled(dim);
+    hipLaunchKernelGGL(tree_sum_cols_partial_kernel, dim3(nblocks), dim3(256), 0, stream(), d_x, n, dim, stride, partial.p);
+    check_launch("tree_sum_cols_partial");
+    hipLaunchKernelGGL(tree_sum_cols_final_kernel, dim3(1), dim3(128), 0, stream(), (const double*)partial.p, nblocks, dim, out.p);
+    check_launch("tree_sum_cols_final");
+    out.download(host_out, dim);
+}
+
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride) {
+    if (tree_sums()) { float h; tree_sum_cols(d_x, n, 1, stride, &h); return h; }
     static DevBuf<float> out;
     if (!out.n) out.alloc(1);
     hipLaunchKernelGGL(seq_sum_kernel, dim3(1), dim3(1024), 0, stream(), d_x, n, stride, out.p);
@@ -745,6 +790,7 @@ __global__ void __launch_bounds__(1024) seq_sum_cols_kernel(const float* __restr
 }
 void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_out) {
     if (dim == 0 || dim > 128) fail(AE_ERR_INVALID_ARG, "seq_sum_cols: dimension %u unsupported", dim);
+    if (tree_sums()) { tree_sum_cols(d_x, n, dim, dim, host_out); return; }
     DevBuf<float> out;
     out.alloc_pooled(dim);
     hipLaunchKernelGGL(seq_sum_cols_kernel, dim3(1), dim3(1024), sizeof(float) * 2u * (6144u / dim + 8u) * dim, stream(), d_x, n, dim, out.p);
@@ -753,6 +799,7 @@ void seq_sum_cols_f32(const float* d_x, uint64_t n, uint32_t dim, float* host_ou
 }
 
 float ndarray_sum_f32(const float* d_x, uint64_t n) {
+    if (tree_sums()) { float h; tree_sum_cols(d_x, n, 1, 1, &h); return h; }
     static DevBuf<float> out;
     if (!out.n) out.alloc(1);
     hipLaunchKernelGGL(ndarray_sum_kernel, dim3(1), dim3(1024), 0, stream(), d_x, n, out.p);

@@ -166,6 +166,10 @@ class LibraryComm:
     def attach(self, entropy_optim, exchanges_per_batch=1):
         self._L.check(self._L.load().ae_entropy_optim_set_comm(entropy_optim._h, self._h, exchanges_per_batch))
 
+    def attach_none(self, entropy_optim):
+        """detach: the handle stops exchanging"""
+        self._L.check(self._L.load().ae_entropy_optim_set_comm(entropy_optim._h, None, 0))
+
     def all_reduce_sum(self, value):
         import ctypes
         v = ctypes.c_double(value)

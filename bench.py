@@ -465,15 +465,32 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
     nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
     library_comm = args.backend == "nccl"
     comm = sharded = None
+    torch_gather = None
+    comm_error = None
     if library_comm:
-        comm = LibraryComm(rank, world)
-        comm.attach(eo, args.exchanges)
+        try:
+            comm = LibraryComm(rank, world)
+            comm.attach(eo, args.exchanges)
+        except Exception as e:  # e.g. librccl.so.1 not loadable from the library: agree on the fallback below
+            comm, comm_error = None, repr(e)[:300]
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:  # every rank: the same exchange through torch's RCCL, in place, on the library stream, once per batch
+            if comm is not None:
+                comm.attach_none(eo)
+                comm.close()
+                comm = None
+            library_comm = False
+            torch_gather = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world)
     else:  # validation over gloo: ranks share a GPU, the exchange goes through torch (once per batch)
         sharded = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world)
     ce_before = eo.ce_compute_threaded()
 
     def one_step(it):
         eo.gradient_iteration_threaded(nb_sample, params.grad_step * (1.0 - it / nb_batch), it)
+        if torch_gather is not None:
+            torch_gather.all_gather()
         if sharded is not None:
             L.check(L.load().ae_synchronize())
             y_host = device_tensor(eo).cpu()
@@ -506,7 +523,7 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
     if comm is not None:
         ce_after, ce0 = comm.all_reduce_sum(ce_local), comm.all_reduce_sum(ce_before)
     else:
-        t2 = torch.tensor([ce_local, ce_before], dtype=torch.float64)
+        t2 = torch.tensor([ce_local, ce_before], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t2)
         ce_after, ce0 = float(t2[0]), float(t2[1])
@@ -531,7 +548,9 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             "data": "synthetic" if args.backend == "nccl" else "synthetic (VALIDATION RUN over gloo, ranks sharing a GPU: not a result)",
             "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * len(nbr)), "ce_mode": MODE_NAMES[0] + " -- the only mode that shards; approximate (see fidelity in the N = 1 line)",
                        "exchanges_per_batch": args.exchanges if library_comm else 1,
-                       "collective": "in-place RCCL all-gather of the owned rows inside ae_entropy_optim_gradient_iteration (library communicator)" if library_comm else "torch/gloo (validation)"},
+                       "collective": "in-place RCCL all-gather of the owned rows inside ae_entropy_optim_gradient_iteration (library communicator)" if library_comm
+                       else ("in-place RCCL all-gather through torch.distributed on the library stream (the library communicator failed: %s)" % comm_error if torch_gather is not None
+                             else "torch/gloo (validation)")},
             "roofline": roof,
             "per_rank_batch_ms_max": kernel_ms_max,
             "samples_per_s": 10 * len(nbr) * args.steps / elapsed,

@@ -679,6 +679,21 @@ def test_embedder_one_step(A, oracle, graph):
     assert np.array_equal(e.get_embedded_reindexed(perm)[perm], y)
 
 
+def test_embedder_tree_sums_initial_embedding(A, graph):
+    """The dmap initialisation under an approximate CE mode replaces the single-lane reference-order sums by f64 tree
+    sums (linalg.h TreeSums): the initial embedding moves by float rounding only."""
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    y0 = {}
+    for mode in (A.AE_CE_SEQUENTIAL, A.AE_CE_HOGWILD):
+        e = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2, ce_mode=mode))
+        assert e.embed() == 1
+        y0[mode] = e.get_initial_embedding()
+    d = np.abs(y0[A.AE_CE_SEQUENTIAL] - y0[A.AE_CE_HOGWILD]).max()
+    assert d < 1e-4 * 5.0, d
+    assert abs(np.abs(y0[A.AE_CE_HOGWILD]).max() - 5.0) < 1e-4
+
+
 def test_embedder_random_init_and_hubness(A, oracle, graph):
     indptr, nbr, dist, _ = graph
     g = A.KGraph(indptr, nbr, dist)
@@ -995,6 +1010,32 @@ def test_library_communicator_world_one(A, oracle, graph):
         comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # the default (sequential) mode does not shard
     with pytest.raises(A.AnnembedError):
         comm.attach(A.EntropyOptim(g, npar, par, y0, node_lo=0, node_hi=1000), 1)  # one rank must own [0, n)
+    comm.close()
+
+
+def test_library_communicator_rccl_calls_world_one(A, oracle, graph, monkeypatch):
+    """With the debug knob AE_COMM_FORCE the one-rank communicator does not skip its collectives: the in-place ncclAllGather of
+    the owned rows, the all-gather of the node ranges and the f64 all-reduce really go through RCCL (dlopen'ed librccl.so.1) on
+    the library stream -- the calls an 8-GPU run makes, with one participant.  Results must equal the run without them."""
+    from annembed_amd.dist import LibraryComm
+    monkeypatch.setenv("AE_DEBUG_KNOBS", "1")
+    monkeypatch.setenv("AE_COMM_FORCE", "1")
+    indptr, nbr, dist, _ = graph
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    y0 = oracle.set_data_box(np.random.default_rng(4).normal(size=(2500, 8)).astype(np.float32), 10.0)
+    comm = LibraryComm(0, 1)
+    par = A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD, asked_dim=8)
+    a, b = A.EntropyOptim(g, npar, par, y0), A.EntropyOptim(g, npar, par, y0)
+    comm.attach(a, 15)
+    for it in (1, 2):
+        a.gradient_iteration_threaded(10 * len(nbr), 0.8, it)
+        b.gradient_iteration_threaded(10 * len(nbr), 0.8, it)
+    ya = a.get_embedded()
+    assert np.isfinite(ya).all() and (np.abs(ya - y0).max(1) > 0).all()
+    assert abs(a.ce_compute_threaded() - b.ce_compute_threaded()) < 0.05 * b.ce_compute_threaded()
+    assert comm.all_reduce_sum(1.25) == 1.25
     comm.close()
 
 
