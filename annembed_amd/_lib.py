@@ -127,6 +127,7 @@ SIGNATURES = {
     "ae_entropy_optim_set_comm": [_vp, _vp, C.c_uint32],
     "ae_entropy_optim_ce": [_vp, _P(_f64)],
     "ae_entropy_optim_gradient_iteration": [_vp, _u64, _f64, _u64],
+    "ae_entropy_optim_gradient_iteration_lockstep": [_vp, C.c_uint32, _vp, _f64, _u64, C.c_uint32],
     "ae_entropy_optim_plan": [_vp, _u64, _u64, _u64, _vp, _vp],
     "ae_entropy_optim_samples_drawn": [_vp, _P(_u64), _P(_u32)],
     "ae_entropy_optim_get_scales": [_vp, _vp],

@@ -323,6 +323,14 @@ class EntropyOptim(_Handle):
     def gradient_iteration_threaded(self, nb_sample, grad_step, it):
         check(L.load().ae_entropy_optim_gradient_iteration(self._h, nb_sample, grad_step, it))
 
+    @staticmethod
+    def gradient_iteration_lockstep(shards, nb_samples, grad_step, it, exchanges_per_batch=1):
+        """one batch of the sharded protocol on one device (ae_entropy_optim_gradient_iteration_lockstep): `shards` are
+        rounds-mode handles whose node ranges tile [0, n) in order"""
+        hs = (C.c_void_p * len(shards))(*[sh._h for sh in shards])
+        ns = (C.c_uint64 * len(shards))(*[int(x) for x in nb_samples])
+        check(L.load().ae_entropy_optim_gradient_iteration_lockstep(hs, len(shards), ns, grad_step, it, exchanges_per_batch))
+
     def plan(self, s_begin, count, it):
         nodes = np.zeros((count, 7), np.uint32)
         w = np.zeros(count, np.float32)

@@ -1010,6 +1010,27 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
     });
 }
 
+int32_t ae_entropy_optim_gradient_iteration_lockstep(ae_entropy_optim* const* shards, uint32_t world, const uint64_t* nb_sample, double grad_step,
+                                                     uint64_t iter, uint32_t exchanges_per_batch) {
+    return guard([&] {
+        require_device();
+        if (!shards || !nb_sample || world == 0) fail(AE_ERR_INVALID_ARG, "null argument");
+        uint64_t expect = 0;
+        for (uint32_t q = 0; q < world; q++) {
+            ae_entropy_optim* o = shards[q];
+            if (!o) fail(AE_ERR_INVALID_ARG, "null shard");
+            if (o->params.ce_mode != AE_CE_HOGWILD) fail(AE_ERR_INVALID_ARG, "lockstep: only the rounds mode (AE_CE_HOGWILD) shards");
+            if (o->comm) fail(AE_ERR_INVALID_ARG, "lockstep: shard %u has a communicator attached", q);
+            if (o->dev.n != shards[0]->dev.n || o->dev.dim != shards[0]->dev.dim) fail(AE_ERR_INVALID_ARG, "lockstep: shards of different graphs");
+            if (o->dev.node_lo != expect || o->dev.node_hi <= o->dev.node_lo) fail(AE_ERR_INVALID_ARG, "lockstep: the node ranges must tile [0, n) in order");
+            expect = o->dev.node_hi;
+        }
+        if (expect != shards[0]->dev.n) fail(AE_ERR_INVALID_ARG, "lockstep: the node ranges must tile [0, n) in order");
+        ce_node_gradient_iteration_lockstep(shards, world, nb_sample, grad_step, (uint32_t)iter, exchanges_per_batch);
+        for (uint32_t q = 0; q < world; q++) check_err_flag(shards[q]);
+    });
+}
+
 int32_t ae_entropy_optim_plan(ae_entropy_optim* o, uint64_t s_begin, uint64_t count, uint64_t iter, uint32_t* nodes7, float* w) {
     return guard([&] {
         require_device();

@@ -112,6 +112,8 @@ namespace ae {
 bool ce_node_supports(const ae_entropy_optim* o);
 void ce_node_build_transpose(ae_entropy_optim* o);
 void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter);
+void ce_node_gradient_iteration_lockstep(ae_entropy_optim* const* shards, uint32_t world, const uint64_t* nb_sample, double grad_step,
+                                         uint32_t iter, uint32_t exchanges);
 // event-ordered batch (ce_event.hip): sequentially consistent attraction steps in an i.i.d. order, `rounds` = windows
 // time-sliced optimistic batch (ce_slice.hip): exact samples on current rows, i.i.d. order, any graph size; `rounds` = slices
 void ce_slice_prepare(ae_entropy_optim* o);

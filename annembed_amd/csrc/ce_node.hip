@@ -373,8 +373,18 @@ void ce_node_build_transpose(ae_entropy_optim* o) {
     memcpy(&o->in_weight_max, &bits, sizeof(float));
 }
 
-void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
+// what one batch of the rounds mode needs besides the handle: the kernel arguments and the number of rounds
+struct RoundsBatch {
+    NodeArgs a;
+    uint64_t nodes = 0;
+    uint32_t rounds = 0;
+    bool node_kernel = false, sharded = false;
+};
+
+static RoundsBatch rounds_prepare(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
+    RoundsBatch rb;
     const uint64_t nodes = o->dev.node_hi - o->dev.node_lo;
+    rb.nodes = nodes;
     const double per_node = (double)nb_sample / (double)nodes;  // expected samples per source node in the batch
     // rounds: keep the largest per-edge Poisson mean (p_e <= 1) below 30 so that exp(-mu) stays normal in f32
     // samples per node and round: measured trade-off between fidelity to the sequential reference (final cross
@@ -384,6 +394,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     // finish at different times, for the same fidelity.
     const bool force_legacy = debug_knob("AE_CE_UNFUSED") != nullptr;
     const bool node_kernel = node_kernel_ok(o) && !(force_legacy && legacy_dim(o->dev.dim));
+    rb.node_kernel = node_kernel;
     double per_round_target = node_kernel ? 8.0 : 12.0;
     // ... and no edge should be drawn much more than 2/3 times per round on average: two attraction steps of one edge
     // inside a round are both evaluated against the partner's round-start row, and with the reference's stiff steps
@@ -398,6 +409,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     if (!debug_knob("AE_CE_PER_ROUND"))
         rounds = std::max(rounds, (uint32_t)std::min(1000.0, std::ceil(per_node * (double)o->in_weight_max / 128.0)));
     o->rounds = rounds;
+    rb.rounds = rounds;
     if (iter >= (1u << 20) || rounds >= (1u << 10)) fail(AE_ERR_INVALID_ARG, "iteration / round index too large for the RNG key");
     const double per_round = per_node / (double)rounds;
     // plan capacity per node and round: Poisson(per_round) exceeds mean + 8 sigma + 8 with probability < 1e-14
@@ -407,7 +419,7 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
         if (o->tot.n < nodes) o->tot.alloc(nodes);
         if (o->cnt.n < o->dev.nnz) { o->cnt.alloc(o->dev.nnz); o->cnt.zero(); }
     }
-    NodeArgs a;
+    NodeArgs& a = rb.a;
     a.c = o->dev;
     a.tptr = o->tptr.p;
     a.tin = o->tin.p;
@@ -420,44 +432,56 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
     a.b = (float)o->dev.b;
     a.sample_counter = o->sample_counter.p;
     a.overflow = o->err.p;
-    static DevBuf<unsigned long long> prof_buf;
     a.prof = nullptr;
-    if (debug_knob("AE_CE_PROF")) {
-        if (!prof_buf.n) { prof_buf.alloc(12); prof_buf.zero(); }
-        a.prof = prof_buf.p;
-    }
-    const bool sharded = o->dev.shard_edges != o->dev.nnz;
+    rb.sharded = o->dev.shard_edges != o->dev.nnz;
     a.skip = debug_knob("AE_CE_SKIP") ? atoi(debug_knob("AE_CE_SKIP")) : 0;
     // 2: write-through at phase ends (default).  0: after every chunk -- measured slower in the node kernel (loads
     // and stores share vmcnt and may return out of order, so every wait after a store drains it: +50 % time)
     // for a fidelity gain that shorter rounds give more cheaply
     a.store_mode = debug_knob("AE_CE_STORE") ? atoi(debug_knob("AE_CE_STORE")) : 2;
+    a.round_key = iter << 10;
+    return rb;
+}
+
+static void rounds_launch(ae_entropy_optim* o, RoundsBatch& rb, uint32_t r) {
+    NodeArgs& a = rb.a;
+    a.round_key = (a.round_key & ~0x3FFu) | r;
+    if (rb.node_kernel) {
+        if (legacy_dim(o->dev.dim)) launch_round_node_exact(o, a, rb.nodes);
+        else launch_round_node_padded(o, a, rb.nodes);
+        return;
+    }
+    const unsigned plan_grid = blocks_for(rb.nodes * 64, kBlock);
+    if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
+    else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
+    if (rb.sharded) hipLaunchKernelGGL(ce_count_remote_kernel, dim3(grid_cap(o->dev.nnz, kBlock)), dim3(kBlock), 0, stream(), a);
+    hipLaunchKernelGGL(ce_sum_tot_kernel, dim3(1), dim3(1024), 0, stream(), (const uint32_t*)o->tot.p, rb.nodes, o->sample_counter.p);
+    AE_DISPATCH_DIM(o->dev.dim, launch_apply_group, o, a, rb.nodes);
+}
+
+// true when an exchange of the owned rows follows round r: `exch` exchanges per batch after equal runs of rounds, the last
+// one ending the batch
+static bool exchange_follows(uint32_t r, uint32_t rounds, uint32_t exch) {
+    if (!exch) return false;
+    return (uint32_t)(((uint64_t)(r + 1) * exch) / rounds) != (uint32_t)(((uint64_t)r * exch) / rounds);
+}
+
+void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
+    RoundsBatch rb = rounds_prepare(o, nb_sample, grad_step, iter);
+    static DevBuf<unsigned long long> prof_buf;
+    if (debug_knob("AE_CE_PROF")) {
+        if (!prof_buf.n) { prof_buf.alloc(12); prof_buf.zero(); }
+        rb.a.prof = prof_buf.p;
+    }
     // multi-GPU: the owned rows are exchanged `comm_exchanges` times per batch, after equal runs of rounds (the last
     // exchange ends the batch): remote rows are rounds / exchanges rounds old instead of a whole batch
-    const uint32_t exch = o->comm ? std::min(std::max(1u, o->comm_exchanges), rounds) : 0u;
-    auto exchange_after = [&](uint32_t r) {
-        if (!exch) return;
-        const uint32_t before = (uint32_t)(((uint64_t)r * exch) / rounds), after = (uint32_t)(((uint64_t)(r + 1) * exch) / rounds);
-        if (after != before) ce_comm_exchange(o);
-    };
-    for (uint32_t r = 0; r < rounds; r++) {
-        a.round_key = (iter << 10) | r;
-        if (node_kernel) {
-            if (legacy_dim(o->dev.dim)) launch_round_node_exact(o, a, nodes);
-            else launch_round_node_padded(o, a, nodes);
-            exchange_after(r);
-            continue;
-        }
-        const unsigned plan_grid = blocks_for(nodes * 64, kBlock);
-        if (a.c.hub_odds) hipLaunchKernelGGL((ce_plan_node_kernel<true>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
-        else hipLaunchKernelGGL((ce_plan_node_kernel<false>), dim3(plan_grid), dim3(kBlock), 0, stream(), a);
-        if (sharded) hipLaunchKernelGGL(ce_count_remote_kernel, dim3(grid_cap(o->dev.nnz, kBlock)), dim3(kBlock), 0, stream(), a);
-        hipLaunchKernelGGL(ce_sum_tot_kernel, dim3(1), dim3(1024), 0, stream(), (const uint32_t*)o->tot.p, nodes, o->sample_counter.p);
-        AE_DISPATCH_DIM(o->dev.dim, launch_apply_group, o, a, nodes);
-        exchange_after(r);
+    const uint32_t exch = o->comm ? std::min(std::max(1u, o->comm_exchanges), rb.rounds) : 0u;
+    for (uint32_t r = 0; r < rb.rounds; r++) {
+        rounds_launch(o, rb, r);
+        if (exchange_follows(r, rb.rounds, exch)) ce_comm_exchange(o);
     }
     check_launch("ce_node");
-    if (a.prof) {
+    if (rb.a.prof) {
         unsigned long long h[12];
         prof_buf.download(h, 12);
         if (h[6]) fprintf(stderr, "CEPROF waves=%llu per-wave cycles: A %.0f | B prepare %.0f replay %.0f | C scan %.0f park %.0f count+gather %.0f replay %.0f | total %.0f\n", h[6],
@@ -465,6 +489,35 @@ void ce_node_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double 
                           (double)h[4] / h[6], (double)h[5] / h[6]);
         prof_buf.zero();
     }
+}
+
+// One batch of `world` shard handles of one graph in lockstep on THIS device: round r of every shard, then, where an
+// exchange follows, every shard's owned rows copied into the other shards' arrays -- the protocol of `world` processes with
+// a communicator attached, without RCCL (validation of the sharded protocol on a single GPU; ae_..._lockstep in the ABI).
+void ce_node_gradient_iteration_lockstep(ae_entropy_optim* const* shards, uint32_t world, const uint64_t* nb_sample, double grad_step,
+                                         uint32_t iter, uint32_t exchanges) {
+    std::vector<RoundsBatch> rb;
+    for (uint32_t q = 0; q < world; q++) rb.push_back(rounds_prepare(shards[q], nb_sample[q], grad_step, iter));
+    uint32_t rounds = 0;
+    for (uint32_t q = 0; q < world; q++) rounds = std::max(rounds, rb[q].rounds);
+    for (uint32_t q = 0; q < world; q++)
+        if (rb[q].rounds != rounds) {  // every shard must cut the batch alike
+            fail(AE_ERR_INVALID_ARG, "lockstep: shard %u would run %u rounds, another %u (unequal shards?)", q, rb[q].rounds, rounds);
+        }
+    const uint32_t exch = std::min(std::max(1u, exchanges), rounds);
+    const uint64_t dim = shards[0]->dev.dim;
+    for (uint32_t r = 0; r < rounds; r++) {
+        for (uint32_t q = 0; q < world; q++) rounds_launch(shards[q], rb[q], r);
+        if (!exchange_follows(r, rounds, exch)) continue;
+        for (uint32_t q = 0; q < world; q++) {  // owner q -> every other shard
+            const uint64_t lo = shards[q]->dev.node_lo, hi = shards[q]->dev.node_hi;
+            for (uint32_t t = 0; t < world; t++)
+                if (t != q)
+                    AE_HIP(hipMemcpyAsync(shards[t]->y.p + lo * dim, shards[q]->y.p + lo * dim, sizeof(float) * (hi - lo) * dim,
+                                          hipMemcpyDeviceToDevice, stream()));
+        }
+    }
+    check_launch("ce_node lockstep");
 }
 
 }  // namespace ae

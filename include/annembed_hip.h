@@ -336,6 +336,14 @@ int32_t ae_comm_init(int32_t rank, int32_t world, const uint8_t *id128, ae_comm 
 int32_t ae_comm_destroy(ae_comm *c);
 int32_t ae_comm_all_reduce_sum(ae_comm *c, double *value);
 int32_t ae_entropy_optim_set_comm(ae_entropy_optim *o, ae_comm *c, uint32_t exchanges_per_batch);
+/* The sharded protocol on ONE device (validation; no reference counterpart): one batch of `world` rounds-mode handles of
+ * the same graph whose node ranges tile [0, n) in order, run in lockstep -- round r of every shard, then, at the exchange
+ * points, every shard's owned rows copied into the other shards' coordinate arrays.  Kernel for kernel and exchange for
+ * exchange what `world` processes with a communicator attached do, so the fidelity of the sharded CE loop (shards x
+ * exchanges_per_batch) can be measured against the un-sharded run where only one GPU is at hand.  nb_sample[q] = samples of
+ * shard q (nb_sampling_by_edge x its own edges). */
+int32_t ae_entropy_optim_gradient_iteration_lockstep(ae_entropy_optim *const *shards, uint32_t world, const uint64_t *nb_sample,
+                                                     double grad_step, uint64_t iter, uint32_t exchanges_per_batch);
 /* the AE_CE_* mode the handle runs (AE_CE_AUTO resolved at create) */
 int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim *o, uint32_t *ce_mode);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */

@@ -1039,6 +1039,43 @@ def test_library_communicator_rccl_calls_world_one(A, oracle, graph, monkeypatch
     comm.close()
 
 
+def test_sharded_protocol_lockstep_four_shards(A, oracle, graph):
+    """The sharded CE protocol with several exchanges per batch, on one GPU: four rounds-mode shard handles run in lockstep
+    (ae_entropy_optim_gradient_iteration_lockstep -- round for round and exchange for exchange what four processes with a
+    communicator attached run).  After every batch the four replicas are identical; every row moved; the final cross entropy
+    is compared with the UN-SHARDED SEQUENTIAL ORACLE.  The rounds mode is approximate and sharding adds to it: measured on
+    this graph 0.69x / 0.85x / 0.91x at 1 / 4 / every-round exchanges (six batches from a random start); the bars below only
+    keep the protocol from drifting further.  The 60 k-point measurements (1-8 shards, two graph families) are in
+    profiles/r02/shard_fidelity_*.json (tools/run_shard_fidelity.py) and DESIGN 5."""
+    from annembed_amd.dist import shard_range
+    indptr, nbr, dist, _ = graph
+    n = len(indptr) - 1
+    g = A.KGraph(indptr, nbr, dist)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    npar = A.NodeParams.from_host(g, p0, s0)
+    y0 = oracle.set_data_box(np.random.default_rng(4).normal(size=(n, 2)).astype(np.float32), 10.0)
+    nb_batch = 6
+    yo, _, oce = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb_batch, grad_step=1.0)
+    par = A.EmbedderParams(nb_grad_batch=nb_batch, ce_mode=A.AE_CE_HOGWILD)
+    ratios = {}
+    for exch in (1, 4, 1000):
+        shards = [A.EntropyOptim(g, npar, par, y0, node_lo=shard_range(n, 4, r)[0], node_hi=shard_range(n, 4, r)[1]) for r in range(4)]
+        ns = [10 * sh.get_nb_edges() for sh in shards]
+        assert sum(ns) == 10 * len(nbr)
+        for it in range(1, nb_batch + 1):
+            A.EntropyOptim.gradient_iteration_lockstep(shards, ns, 1.0 - it / nb_batch, it, exch)
+            ys = [sh.get_embedded() for sh in shards]
+            assert all(np.array_equal(y, ys[0]) for y in ys[1:]), (exch, it)
+        assert np.isfinite(ys[0]).all() and (np.abs(ys[0] - y0).max(1) > 0).all()
+        ratios[exch] = sum(sh.ce_compute_threaded() for sh in shards) / oce
+        assert 0.55 < ratios[exch] < 1.25, ratios
+    with pytest.raises(A.AnnembedError):  # ranges that do not tile [0, n)
+        A.EntropyOptim.gradient_iteration_lockstep(shards[:3], ns[:3], 0.5, 1, 1)
+    with pytest.raises(A.AnnembedError):  # a faithful-mode handle does not shard
+        A.EntropyOptim.gradient_iteration_lockstep([A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0)], [10 * len(nbr)], 0.5, 1, 1)
+    assert ratios[1000] > 0.8 and ratios[4] > 0.7, ratios
+
+
 def test_sharded_ce_hip_backend_two_ranks_one_gpu(A, oracle, graph, tmp_path):
     """Two processes (gloo; both on this box's one GPU) each run the HIP library on their shard of the source nodes and exchange
     the owned rows once per batch.  Checked against the UN-SHARDED SEQUENTIAL ORACLE, not against an emulation of the protocol:
