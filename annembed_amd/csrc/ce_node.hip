@@ -440,6 +440,7 @@ static RoundsBatch rounds_prepare(ae_entropy_optim* o, uint64_t nb_sample, doubl
     // for a fidelity gain that shorter rounds give more cheaply
     a.store_mode = debug_knob("AE_CE_STORE") ? atoi(debug_knob("AE_CE_STORE")) : 2;
     a.round_key = iter << 10;
+    a.tile = debug_knob("AE_CE_NO_TILE") ? 0 : 1;
     return rb;
 }
 

@@ -71,6 +71,7 @@ struct NodeArgs {
     unsigned long long* prof;  // debug: per-section cycle sums [stage, fetch-issue, compute, store, in-phase, total]
     int skip;        // debug: 1 skip out-phase, 2 skip in-phase
     int store_mode;  // 0: write-through store after every sample, 1: plain store after every sample, 2: write-through at phase ends
+    int tile;        // 1: negatives of the uniform sampler from an LDS tile of consecutive rows (ce_node_round.h)
 };
 
 // PCG-RXS-M-XS 32 output hash: the fast mode's stream for the negative draws (the exact Philox stream

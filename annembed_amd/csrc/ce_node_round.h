@@ -195,6 +195,70 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
     else { ib = c.indptr[v]; k = (uint32_t)(c.indptr[v + 1] - ib); }
     const uint32_t rk = round_hash_key(a.round_key, c.seed);
     const float step2 = 2.0f * a.step;
+    // ---- tile negatives (uniform sampler only): the 5 negatives of every sample of this wave are drawn from T consecutive
+    // rows starting at a random node (per wave and round; the start is uniform over the nodes and the tile wraps around, so
+    // every node is equally likely -- the marginal law of embedder.rs:1121), read ONCE, coalesced, into the LDS buffer that
+    // stage C uses later.  A negative then costs an LDS read instead of a 128-byte line fetched for a 4 DIM-byte row: at the
+    // C4 shape 5 of the 6 partner rows of a sample, ~70 % of the kernel's memory traffic.
+    constexpr int T = EC, TL = T * DIM / 64;
+    const bool tile_on = a.tile != 0 && c.hub_odds == nullptr && c.n >= 2ull * (uint64_t)T;  // wave-uniform
+    const uint32_t tbase = __umulhi(pcg_hash(rk ^ pcg_hash((uint32_t)blockIdx.x + 0x51ED270Bu)), (uint32_t)c.n);
+    float tile_raw[TL];
+    auto tile_loads = [&] {
+        if constexpr (!PAD && DIM % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < TL / 4; i++) {
+                const uint32_t e = (uint32_t)(i * 64 + lane) * 4u, row = e / (uint32_t)DIM, col = e % (uint32_t)DIM;
+                uint32_t node = tbase + row;
+                node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+                const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(c.y + (uint64_t)node * DIM + col));
+                tile_raw[4 * i] = t.x; tile_raw[4 * i + 1] = t.y; tile_raw[4 * i + 2] = t.z; tile_raw[4 * i + 3] = t.w;
+            }
+        } else if constexpr (!PAD && DIM == 2) {
+            using f2 = __attribute__((ext_vector_type(2))) float;
+#pragma unroll
+            for (int i = 0; i < TL / 2; i++) {
+                uint32_t node = tbase + (uint32_t)(i * 64 + lane);
+                node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+                const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(c.y + (uint64_t)node * 2u));
+                tile_raw[2 * i] = t.x; tile_raw[2 * i + 1] = t.y;
+            }
+        } else {  // odd or padded rows: element-wise, consecutive lanes on consecutive floats
+            const uint32_t cd = PAD ? c.dim : (uint32_t)DIM;
+#pragma unroll
+            for (int i = 0; i < TL; i++) {
+                const uint32_t e = (uint32_t)(i * 64 + lane), row = e / cd, col = e % cd;
+                uint32_t node = tbase + (row < (uint32_t)T ? row : 0u);
+                node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+                tile_raw[i] = __builtin_nontemporal_load(c.y + (uint64_t)node * cd + col);
+            }
+        }
+    };
+    auto tile_store = [&] {
+        if constexpr (!PAD && DIM % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < TL / 4; i++) {
+                f4 t; t.x = tile_raw[4 * i]; t.y = tile_raw[4 * i + 1]; t.z = tile_raw[4 * i + 2]; t.w = tile_raw[4 * i + 3];
+                *reinterpret_cast<f4*>(&s_in_row[(uint32_t)(i * 64 + lane) * 4u]) = t;
+            }
+        } else if constexpr (!PAD && DIM == 2) {
+#pragma unroll
+            for (int i = 0; i < TL / 2; i++) { s_in_row[(uint32_t)(i * 64 + lane) * 2u] = tile_raw[2 * i]; s_in_row[(uint32_t)(i * 64 + lane) * 2u + 1u] = tile_raw[2 * i + 1]; }
+        } else {
+            const uint32_t cd = PAD ? c.dim : (uint32_t)DIM;
+            if constexpr (PAD) {
+#pragma unroll
+                for (int i = 0; i < TL; i++) s_in_row[i * 64 + lane] = 0.f;  // the columns beyond asked_dim
+                wave_lds_sync();
+            }
+#pragma unroll
+            for (int i = 0; i < TL; i++) {
+                const uint32_t e = (uint32_t)(i * 64 + lane), row = e / cd, col = e % cd;
+                if (row < (uint32_t)T) s_in_row[row * (uint32_t)DIM + col] = tile_raw[i];
+            }
+        }
+        wave_lds_sync();
+    };
     unsigned long long tk0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull, tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_begin = tk0;
 #define AE_TICK(i) if (a.prof) { const unsigned long long tk1 = __builtin_amdgcn_s_memtime(); tk_acc[i] += tk1 - tk0; tk0 = tk1; }
@@ -231,6 +295,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         s_v = c.emb_scale[v];
     };
     if constexpr (LATE_RECS) { row_loads(); own_loads(); }
+    if (tile_on) tile_loads();
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
     // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
     const uint64_t t_begin = a.tptr[v0], t_end = a.tptr[v0 + n_here];
@@ -320,6 +385,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         }
     };
     const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
+    if (tile_on) tile_store();
     AE_TICK(0)
     // ---- stage B.  prepare(t0): node sets of samples t0 .. t0+S-1 and their 6 S gathers;  replay(): the
     // dependent updates.  The gathers of chunk i+1 are in flight while chunk i is replayed.
@@ -327,6 +393,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         float rows[S][6][DIM];
         float ws[S];
         uint32_t act;
+        uint32_t slot[S][6];  // tile negatives: LDS slot of negative g (rows[s][1..5] unused then)
     };
     struct ChunkPlan {  // node sets of S samples: idx[s][0] = sampled neighbour j, idx[s][1..5] = negatives
         uint32_t idx[S][6];
@@ -337,9 +404,20 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
     // still wanted; reject k = i or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85; the sampled j is in N(i)):
     // min over xors is 0
     auto draw_pass = [&](auto hub_tag, uint32_t t0, uint32_t attempt, ChunkPlan& pl, uint32_t& need) {
-        constexpr bool HUB = decltype(hub_tag)::value;
-        uint32_t cands[S][6];
-        if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930: the 10 S table look-ups are issued together
+        constexpr int MODE = decltype(hub_tag)::value;  // 0 uniform (gathered), 1 hubness alias table, 2 uniform from the LDS tile
+        constexpr bool HUB = MODE == 1;
+        uint32_t cands[S][6], slots[S][6] = {};
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int g = 1; g <= 5; g++) {
+                    slots[s][g] = __umulhi(pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt), (uint32_t)T);
+                    uint32_t node = tbase + slots[s][g];
+                    node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+                    cands[s][g] = node;
+                }
+        } else if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930: the 10 S table look-ups are issued together
             uint32_t xs[S][6], al[S][6];
             float od[S][6], uu[S][6];
 #pragma unroll
@@ -375,7 +453,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
                 for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand; acc = x < acc ? x : acc; }
                 const uint32_t bit = 1u << (8 * s + g);
                 const bool mine = (need & bit) != 0u;
-                pl.idx[s][g] = (mine || attempt == 0u) ? cand : pl.idx[s][g];
+                pl.idx[s][g] = (mine || attempt == 0u) ? (MODE == 2 ? slots[s][g] : cand) : pl.idx[s][g];
                 need = (mine && acc != 0u) ? (need & ~bit) : need;
             }
         }
@@ -407,17 +485,26 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 #pragma nounroll
         for (uint32_t attempt = 1; attempt < 16u && __any(need != 0u); attempt++) draw_pass(hub_tag, t0, attempt, pl, need);  // rare
     };
-    auto issue = [&](const ChunkPlan& pl, Chunk& ck) {  // the 6 S gathers of a planned chunk
+    auto issue = [&](auto mode_tag, const ChunkPlan& pl, Chunk& ck) {  // the 6 S gathers of a planned chunk (tile negatives: the S positive ones)
+        constexpr int MODE = decltype(mode_tag)::value;
         ck.act = pl.act;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool act = (pl.act >> s) & 1u;
             ck.ws[s] = pl.ws[s];
 #pragma unroll
-            for (int g = 0; g < 6; g++) ldg(pl.idx[s][g], act, ck.rows[s][g]);
+            for (int g = 0; g < 6; g++) {
+                if constexpr (MODE == 2) {
+                    if (g == 0) ldg(pl.idx[s][g], act, ck.rows[s][g]);
+                    else ck.slot[s][g] = pl.idx[s][g];
+                } else {
+                    ldg(pl.idx[s][g], act, ck.rows[s][g]);
+                }
+            }
         }
     };
-    auto replay = [&](Chunk& ck) {
+    auto replay = [&](auto mode_tag, Chunk& ck) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool act = (ck.act >> s) & 1u;
@@ -432,17 +519,35 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 #pragma unroll
                 for (int q = 0; q < DIM; q++) { grad[q] = (ck.rows[s][0][q] - yv[q]) * cij; yv[q] -= grad[q]; }
             }
+            float tneg[5][DIM];
+            if constexpr (MODE == 2) {  // the five rows out of the tile, read together ahead of the dependent chain
+#pragma unroll
+                for (int g = 1; g <= 5; g++) {
+                    const float* tp = &s_in_row[ck.slot[s][g] * (uint32_t)DIM];
+                    if constexpr (DIM % 4 == 0) {
+#pragma unroll
+                        for (int q = 0; q < DIM / 4; q++) {
+                            const f4 t = *reinterpret_cast<const f4*>(tp + 4 * q);
+                            tneg[g - 1][4 * q] = t.x; tneg[g - 1][4 * q + 1] = t.y; tneg[g - 1][4 * q + 2] = t.z; tneg[g - 1][4 * q + 3] = t.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < DIM; q++) tneg[g - 1][q] = tp[q];
+                    }
+                }
+            }
 #pragma unroll
             for (int g = 1; g <= 5; g++) {  // 5 repulsions, :1267-1297
-                untangle(ck.rows[s][g]);
+                if constexpr (MODE != 2) untangle(ck.rows[s][g]);
+                const float* rg = MODE == 2 ? tneg[g - 1] : ck.rows[s][g];
                 float dk = 0.f;
 #pragma unroll
-                for (int q = 0; q < DIM; q++) { const float df = yv[q] - ck.rows[s][g][q]; dk += df * df; }
+                for (int q = 0; q < DIM; q++) { const float df = yv[q] - rg[q]; dk += df * df; }
                 const float cik = repulse_coeff<DIM, B1>(dk, inv_s2, step2, a.step, a.b);
                 const bool upd = dk > 0.f;  // else `gradient` keeps its previous value (reference quirk B4)
 #pragma unroll
                 for (int q = 0; q < DIM; q++) {
-                    const float gn = (ck.rows[s][g][q] - yv[q]) * cik;
+                    const float gn = (rg[q] - yv[q]) * cik;
                     grad[q] = upd ? gn : grad[q];
                     yv[q] -= act ? grad[q] : 0.f;
                 }
@@ -456,7 +561,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
             Chunk cA = {}, cB = {};  // zeroed once: a row that is not requested keeps finite content
             if (nmax) {
                 plan_chunk(hub_tag, 0u, pl, [] {});
-                issue(pl, cA);
+                issue(hub_tag, pl, cA);
                 late_recs();
                 if ((uint32_t)S < nmax) plan_chunk(hub_tag, (uint32_t)S, pl, [] {});
             } else late_recs();
@@ -464,9 +569,9 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
                 const bool has1 = t0 + S < nmax, has2 = t0 + 2 * S < nmax;
-                if (has1) issue(pl, cB);
-                if (has2) plan_chunk(hub_tag, t0 + 2 * S, pl, [&] { replay(cA); });
-                else replay(cA);
+                if (has1) issue(hub_tag, pl, cB);
+                if (has2) plan_chunk(hub_tag, t0 + 2 * S, pl, [&] { replay(hub_tag, cA); });
+                else replay(hub_tag, cA);
                 if (a.store_mode == 0 && valid && cA.act) st(v, yv);  // optional write-through after every chunk (AE_CE_STORE=0)
                 if (has1) cA = cB;
                 AE_TICK(2)
@@ -477,14 +582,15 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 #pragma nounroll
             for (uint32_t t0 = 0; t0 < nmax; t0 += S) {
                 plan_chunk(hub_tag, t0, pl, [] {});
-                issue(pl, cA);
-                replay(cA);
+                issue(hub_tag, pl, cA);
+                replay(hub_tag, cA);
                 if (a.store_mode == 0 && valid && cA.act) st(v, yv);
             }
         }
     };
-    if (hub) stage_b(std::true_type{});
-    else stage_b(std::false_type{});
+    if (hub) stage_b(std::integral_constant<int, 1>{});
+    else if (tile_on) stage_b(std::integral_constant<int, 2>{});
+    else stage_b(std::integral_constant<int, 0>{});
     if constexpr (COOP) { if (a.store_mode == 2) st_rows(); }
     else if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
     // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,

@@ -86,7 +86,8 @@ def test_k6_blobs_without_hubness_40_batches(A):
 def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
     """configs[0] / configs[1] shapes -- 60 000 x 784 MNIST-shaped points, k = 6 / 30 batches (examples/mnist_digits.rs:92-109)
     and k = 12 / 25 batches (examples/mnist_fashion.rs:92-110): Embedder::embed() in the event-ordered mode against the same
-    call in the default mode (sequential; same dmap initialisation, checked equal)."""
+    call in the default mode (sequential; same dmap initialisation up to the summation order of its means -- reference-order
+    single-lane sums under the bit-exact mode, f64 tree sums under the others: equal to float rounding)."""
     g, indptr, nbr = _mnist_shaped_graph(A, 60000, k)
     out = {}
     for name, mode in (("seq", A.AE_CE_AUTO), ("auto", A.AE_CE_EVENT), ("sliced", A.AE_CE_SLICED)):
@@ -95,7 +96,7 @@ def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
         e = A.Embedder(g, par)
         assert e.embed() == 1
         out[name] = (e.get_embedded(), e.get_cross_entropy()[1], e.get_initial_embedding())
-    assert np.array_equal(out["seq"][2], out["auto"][2])
+    assert np.abs(out["seq"][2] - out["auto"][2]).max() < 1e-4 * 5.0 and np.array_equal(out["auto"][2], out["sliced"][2])
     assert abs(np.abs(out["auto"][2]).max() - 5.0) < 1e-4
     _assert_close(A, indptr, nbr, out["auto"][:2] + (None,), out["seq"][:2] + (None,))
     _assert_close(A, indptr, nbr, out["sliced"][:2] + (None,), out["seq"][:2] + (None,))

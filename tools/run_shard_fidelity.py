@@ -16,6 +16,7 @@ from tools.run_event_check import blobs, edge_q  # noqa: E402
 
 
 def main():
+    out_path = sys.argv[4] if len(sys.argv) > 4 else None
     kind = sys.argv[1] if len(sys.argv) > 1 else "blobs6"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 60000
     nb_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 40
@@ -63,8 +64,8 @@ def main():
         r["ce_vs_sequential"] = r["ce"] / ref["ce"]
         r["q_vs_sequential"] = (np.array(r["q"]) / np.array(ref["q"])).tolist()
         print("world %d exchanges %4d: ce / sequential %.3f   quantiles / sequential %s" % (r["world"], r["exchanges"], r["ce_vs_sequential"], np.round(r["q_vs_sequential"], 3)))
-    if len(sys.argv) > 4:
-        json.dump(out, open(sys.argv[4], "w"), indent=1)
+    if out_path:
+        json.dump(out, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":

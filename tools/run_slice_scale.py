@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_650_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-indptr, nbr, dst = bench.lattice_graph(n, k, seed=7, permute=True)
+indptr, nbr, dst = bench.lattice_graph(n, k, seed=7, permute=os.environ.get("NO_PERMUTE") is None)
 kg = A.KGraph(indptr, nbr, dst, k)
 y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
 npar = A.to_proba_edges(kg, 1.0, 1.0)
