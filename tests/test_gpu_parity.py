@@ -654,6 +654,33 @@ def test_gpu_svd_sparse_vs_oracle(A, oracle):
     assert np.max(np.abs(r.u.T @ r.u - np.eye(20))) < 1e-4
 
 
+@pytest.mark.parametrize("dim,nbng", [(2, 6), (2, 50), (3, 12), (2, 200)])
+def test_quality_estimate_grid_equals_brute_force(A, monkeypatch, dim, nbng):
+    """The radius of the quality estimate (distance to the nbng-th nearest embedded point) through the uniform grid (2 / 3
+    embedded dimensions, n >= 4096) against the O(n^2) brute-force graph of the embedded points: every per-node quantity
+    identical (the two paths compute the same f32 sums; the grid's stopping rule is exact).  Embedding: tight clusters of very
+    different densities plus duplicates and a sparse background -- the cases a uniform grid handles worst."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    centers = rng.normal(size=(12, dim)) * 4
+    lab = rng.integers(0, 12, n)
+    y = (centers[lab] + rng.normal(size=(n, dim)) * (0.002 + 0.5 * rng.random(12))[lab][:, None]).astype(np.float32)
+    y[:500] = (rng.random((500, dim)) * 60 - 30).astype(np.float32)   # sparse background
+    y[500:900] = y[900:1300]                                           # exact duplicates
+    k = 5
+    nbr = rng.integers(0, n, size=(n, k)).astype(np.uint32)
+    nbr[nbr == np.arange(n, dtype=np.uint32)[:, None]] = 1
+    g = A.KGraph(np.arange(n + 1, dtype=np.uint64) * np.uint64(k), nbr.reshape(-1), np.sort(rng.random((n, k)).astype(np.float32), axis=1).reshape(-1), k)
+    a = A.quality_estimate_from_edge_length(g, y, nbng)
+    monkeypatch.setenv("AE_DEBUG_KNOBS", "1")
+    monkeypatch.setenv("AE_QUALITY_BRUTE", "1")
+    b = A.quality_estimate_from_edge_length(g, y, nbng)
+    assert np.array_equal(a.ratio_by_node, b.ratio_by_node) and np.array_equal(a.first_dist, b.first_dist)
+    assert np.array_equal(a.radii_quantiles, b.radii_quantiles) and np.array_equal(a.ratio_quantiles, b.ratio_quantiles)
+    assert a.nb_without_match == b.nb_without_match and a.mean_nbmatch == b.mean_nbmatch
+    assert abs(a.mean_ratio - b.mean_ratio) <= 1e-12 * abs(b.mean_ratio)  # (a sum of f64 atomics: the order varies)
+
+
 # ------------------------------------------------------------------------------------------------
 # Embedder
 # ------------------------------------------------------------------------------------------------

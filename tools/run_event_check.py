@@ -72,6 +72,8 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     hub = kg.hubness() if os.environ.get("FID_HUB") else None
     out = {"kind": kind, "n": n, "nb_batch": nb_batch, "runs": []}
     modes = ((A.AE_CE_SEQUENTIAL, "sequential"), (A.AE_CE_EVENT, "event"), (A.AE_CE_SLICED, "sliced"), (A.AE_CE_HOGWILD, "rounds"))
+    if os.environ.get("FID_MODES"):
+        modes = tuple(m for m in modes if m[1] in os.environ["FID_MODES"].split(","))
     for mode, name in modes:
         for s in range(seeds):
             r = run(kg, npar, y0, mode, nb_batch, 1000 + s, hub=hub)
@@ -83,6 +85,8 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     mq = np.mean([r["q"] for r in ref], axis=0)
     for name in ("sequential", "event", "sliced", "rounds"):
         rs = [r for r in out["runs"] if r["mode"] == name]
+        if not rs:
+            continue
         print("%-10s mean ce/seq %.4f (spread %.4f)  q/seq %s" % (name, np.mean([r["ce"] for r in rs]) / mce, np.std([r["ce"] for r in rs]) / mce,
                                                                np.round(np.mean([r["q"] for r in rs], axis=0) / mq, 3)), flush=True)
     return out
