@@ -96,7 +96,8 @@ def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
         e = A.Embedder(g, par)
         assert e.embed() == 1
         out[name] = (e.get_embedded(), e.get_cross_entropy()[1], e.get_initial_embedding())
-    assert np.abs(out["seq"][2] - out["auto"][2]).max() < 1e-4 * 5.0 and np.array_equal(out["auto"][2], out["sliced"][2])
+    # (run to run the initialisation itself moves by an ulp in an element or two: the Gram of the CholeskyQR is a sum of f64 atomics)
+    assert np.abs(out["seq"][2] - out["auto"][2]).max() < 1e-4 * 5.0 and np.abs(out["auto"][2] - out["sliced"][2]).max() < 1e-6 * 5.0
     assert abs(np.abs(out["auto"][2]).max() - 5.0) < 1e-4
     _assert_close(A, indptr, nbr, out["auto"][:2] + (None,), out["seq"][:2] + (None,))
     _assert_close(A, indptr, nbr, out["sliced"][:2] + (None,), out["seq"][:2] + (None,))
