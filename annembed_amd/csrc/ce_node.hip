@@ -34,6 +34,8 @@ void rowptr_from_sorted_keys(const uint64_t* d_keys, uint64_t nnz, uint64_t nrow
 // ce_node_round_exact.hip / ce_node_round_pad.hip
 void launch_round_node_exact(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes);
 void launch_round_node_padded(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes);
+void launch_round_node_exact_tile(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes);
+void launch_round_node_padded_tile(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes);
 }  // namespace ae
 
 namespace {
@@ -448,8 +450,12 @@ static void rounds_launch(ae_entropy_optim* o, RoundsBatch& rb, uint32_t r) {
     NodeArgs& a = rb.a;
     a.round_key = (a.round_key & ~0x3FFu) | r;
     if (rb.node_kernel) {
-        if (legacy_dim(o->dev.dim)) launch_round_node_exact(o, a, rb.nodes);
-        else launch_round_node_padded(o, a, rb.nodes);
+        const bool exact = legacy_dim(o->dev.dim);
+        const uint32_t d = o->dev.dim;
+        const uint32_t tile_rows = exact ? (d <= 4 ? 1024u : (d <= 8 ? 256u : 128u)) : (d <= 8 ? 256u : 128u);  // node_kernel_tile_rows of the instantiated width
+        const bool tile = a.tile != 0 && a.c.hub_odds == nullptr && a.c.n >= 2ull * tile_rows;
+        if (exact) { if (tile) launch_round_node_exact_tile(o, a, rb.nodes); else launch_round_node_exact(o, a, rb.nodes); }
+        else { if (tile) launch_round_node_padded_tile(o, a, rb.nodes); else launch_round_node_padded(o, a, rb.nodes); }
         return;
     }
     const unsigned plan_grid = blocks_for(rb.nodes * 64, kBlock);

@@ -111,8 +111,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int DIM, bool PAD, bool B1, int KMAX>
-__global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(NodeArgs a) {  // d = 8: two waves per SIMD (10 registers spilled; the kernel otherwise lands on 267 registers, i.e. one wave, and the C4 shape is latency-bound)
+// TILE: the negatives of the uniform sampler come from an LDS tile (below); a kernel of its own, not a run-time branch -- the
+// registers of a kernel are those of its hungriest path, and the tile path does without the 5 S gathered rows per chunk
+template <int DIM, bool PAD, bool B1, int KMAX, bool TILE>
+__global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(NodeArgs a) {  // d = 8: two waves per SIMD (gathered negatives: 10 registers spilled, the kernel otherwise lands on 267 registers, i.e. one wave, and the C4 shape is latency-bound; tile negatives: 236 registers, nothing spilled).  d = 16 with tile negatives needs 338 registers: one wave (two with 83 spilled: 4 % slower)
     using Cfg = NodeKernelCfg<DIM>;
     constexpr int LS = 65, S = Cfg::S, CH = Cfg::CH, NQ = Cfg::NQ, EC = Cfg::EC, KP = KMAX / 4;
     __shared__ uint32_t s_nbr[KMAX * LS];
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
     // stage C uses later.  A negative then costs an LDS read instead of a 128-byte line fetched for a 4 DIM-byte row: at the
     // C4 shape 5 of the 6 partner rows of a sample, ~70 % of the kernel's memory traffic.
     constexpr int T = EC, TL = T * DIM / 64;
-    const bool tile_on = a.tile != 0 && c.hub_odds == nullptr && c.n >= 2ull * (uint64_t)T;  // wave-uniform
+    constexpr bool tile_on = TILE;  // (the launcher checks: uniform sampler, n >= 2 T)
     const uint32_t tbase = __umulhi(pcg_hash(rk ^ pcg_hash((uint32_t)blockIdx.x + 0x51ED270Bu)), (uint32_t)c.n);
     float tile_raw[TL];
     auto tile_loads = [&] {
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         s_v = c.emb_scale[v];
     };
     if constexpr (LATE_RECS) { row_loads(); own_loads(); }
-    if (tile_on) tile_loads();
+    if constexpr (tile_on) tile_loads();
     // ---- stage C prologue: the first in-edge records of the wave are requested now, their latency overlaps
     // stages A and B.  Lane l holds the NQ consecutive records cb + l NQ .. cb + l NQ + NQ - 1.
     const uint64_t t_begin = a.tptr[v0], t_end = a.tptr[v0 + n_here];
@@ -385,7 +387,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         }
     };
     const uint32_t node_base = pcg_hash(pcg_hash((uint32_t)c.seed ^ a.round_key) + v);
-    if (tile_on) tile_store();
+    if constexpr (tile_on) tile_store();
     AE_TICK(0)
     // ---- stage B.  prepare(t0): node sets of samples t0 .. t0+S-1 and their 6 S gathers;  replay(): the
     // dependent updates.  The gathers of chunk i+1 are in flight while chunk i is replayed.
@@ -588,9 +590,11 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
             }
         }
     };
-    if (hub) stage_b(std::integral_constant<int, 1>{});
-    else if (tile_on) stage_b(std::integral_constant<int, 2>{});
-    else stage_b(std::integral_constant<int, 0>{});
+    if constexpr (TILE) stage_b(std::integral_constant<int, 2>{});
+    else {
+        if (hub) stage_b(std::integral_constant<int, 1>{});
+        else stage_b(std::integral_constant<int, 0>{});
+    }
     if constexpr (COOP) { if (a.store_mode == 2) st_rows(); }
     else if (a.store_mode == 2 && valid && nv) st(v, yv);  // mode 3: one store at the very end only
     // ---- stage C: the y_j halves of :1238-1239, replayed by the target.  Per pass of CH in-edges: counts,
@@ -741,22 +745,25 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 }
 
 
-template <int DIM, bool PAD, int KMAX>
+// rows of the LDS tile of the TILE kernels (= EC of NodeKernelCfg); the launcher needs n >= 2 x this
+inline uint32_t node_kernel_tile_rows(int DIM) { return DIM <= 4 ? 1024u : (DIM <= 8 ? 256u : 128u); }
+
+template <int DIM, bool PAD, int KMAX, bool TILE>
 void launch_round_node_k(const NodeArgs& a, uint64_t nodes) {
     const unsigned grid = blocks_for(nodes, 64);
-    if (a.b == 1.0f) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, true, KMAX>), dim3(grid), dim3(64), 0, stream(), a);
-    else if constexpr (KMAX == 16 || KMAX == 32) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, false, KMAX>), dim3(grid), dim3(64), 0, stream(), a);
+    if (a.b == 1.0f) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, true, KMAX, TILE>), dim3(grid), dim3(64), 0, stream(), a);
+    else if constexpr (KMAX == 16 || KMAX == 32) hipLaunchKernelGGL((ce_round_node_kernel<DIM, PAD, false, KMAX, TILE>), dim3(grid), dim3(64), 0, stream(), a);
     else fail(AE_ERR_INVALID_ARG, "ce_round_node_kernel: b != 1 is instantiated for KMAX 16 / 32 only");
 }
 // rows of <= 8 / 12 / 16 / 24 / 32 neighbours (the exponent b != 1 only for 16 / 32: its powf code is large)
-template <int DIM, bool PAD>
+template <int DIM, bool PAD, bool TILE>
 void launch_round_node_dim(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
     const uint32_t k = o->g->max_nbng;
     const bool b1 = a.b == 1.0f;
-    if (k <= 8 && b1) launch_round_node_k<DIM, PAD, 8>(a, nodes);
-    else if (k <= 12 && b1) launch_round_node_k<DIM, PAD, 12>(a, nodes);
-    else if (k <= 16) launch_round_node_k<DIM, PAD, 16>(a, nodes);
-    else if (k <= 24 && b1) launch_round_node_k<DIM, PAD, 24>(a, nodes);
-    else launch_round_node_k<DIM, PAD, 32>(a, nodes);
+    if (k <= 8 && b1) launch_round_node_k<DIM, PAD, 8, TILE>(a, nodes);
+    else if (k <= 12 && b1) launch_round_node_k<DIM, PAD, 12, TILE>(a, nodes);
+    else if (k <= 16) launch_round_node_k<DIM, PAD, 16, TILE>(a, nodes);
+    else if (k <= 24 && b1) launch_round_node_k<DIM, PAD, 24, TILE>(a, nodes);
+    else launch_round_node_k<DIM, PAD, 32, TILE>(a, nodes);
 }
 }  // namespace ae

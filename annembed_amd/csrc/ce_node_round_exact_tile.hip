@@ -1,0 +1,15 @@
+// ce_node_round_exact_tile.hip -- ce_round_node_kernel with tile negatives for the dimensions with a vector-load instantiation
+#include "ce_node_round.h"
+
+namespace ae {
+void launch_round_node_exact_tile(ae_entropy_optim* o, const NodeArgs& a, uint64_t nodes) {
+    switch (o->dev.dim) {
+        case 2: launch_round_node_dim<2, false, true>(o, a, nodes); break;
+        case 3: launch_round_node_dim<3, false, true>(o, a, nodes); break;
+        case 4: launch_round_node_dim<4, false, true>(o, a, nodes); break;
+        case 8: launch_round_node_dim<8, false, true>(o, a, nodes); break;
+        case 16: launch_round_node_dim<16, false, true>(o, a, nodes); break;
+        default: fail(AE_ERR_INVALID_ARG, "launch_round_node_exact_tile: dimension without an exact instantiation");
+    }
+}
+}  // namespace ae
