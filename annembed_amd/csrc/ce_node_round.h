@@ -396,11 +396,13 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         float ws[S];
         uint32_t act;
         uint32_t slot[S][6];  // tile negatives: LDS slot of negative g (rows[s][1..5] unused then)
+        uint32_t bad;         // bit 8 s + g: no admissible negative found for draw (s, g) in 16 attempts -- that repulsion is skipped
     };
     struct ChunkPlan {  // node sets of S samples: idx[s][0] = sampled neighbour j, idx[s][1..5] = negatives
         uint32_t idx[S][6];
         float ws[S];
         uint32_t act;
+        uint32_t bad;
     };
     // one attempt of all 5 S draws (embedder.rs:1241-1253), branch-free: `need` has bit 8 s + g set while draw (s, g) is
     // still wanted; reject k = i or k in N(i) (NodeParam::get_edge, nodeparam.rs:83-85; the sampled j is in N(i)):
@@ -486,10 +488,12 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         overlap();
 #pragma nounroll
         for (uint32_t attempt = 1; attempt < 16u && __any(need != 0u); attempt++) draw_pass(hub_tag, t0, attempt, pl, need);  // rare
+        pl.bad = need;  // (the reference loops until it finds one, embedder.rs:1241-1253: P[16 rejections] < ((k + 2) / n)^16)
     };
     auto issue = [&](auto mode_tag, const ChunkPlan& pl, Chunk& ck) {  // the 6 S gathers of a planned chunk (tile negatives: the S positive ones)
         constexpr int MODE = decltype(mode_tag)::value;
         ck.act = pl.act;
+        ck.bad = pl.bad;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool act = (pl.act >> s) & 1u;
@@ -546,12 +550,13 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
 #pragma unroll
                 for (int q = 0; q < DIM; q++) { const float df = yv[q] - rg[q]; dk += df * df; }
                 const float cik = repulse_coeff<DIM, B1>(dk, inv_s2, step2, a.step, a.b);
-                const bool upd = dk > 0.f;  // else `gradient` keeps its previous value (reference quirk B4)
+                const bool live = act && ((ck.bad >> (8 * s + g)) & 1u) == 0u;
+                const bool upd = dk > 0.f && live;  // else `gradient` keeps its previous value (reference quirk B4)
 #pragma unroll
                 for (int q = 0; q < DIM; q++) {
                     const float gn = (rg[q] - yv[q]) * cik;
                     grad[q] = upd ? gn : grad[q];
-                    yv[q] -= act ? grad[q] : 0.f;
+                    yv[q] -= live ? grad[q] : 0.f;
                 }
             }
         }
