@@ -221,3 +221,38 @@ def test_c4_shape_single_gpu_properties(A):
     assert abs(drawn - S) < 6 * np.sqrt(S) and rounds >= 15
     assert np.isfinite(y).all() and np.abs(y).max() < 1e3
     assert (np.abs(y - y0).max(1) > 0).mean() > 0.999
+
+
+def test_c5_shape_one_shard_properties(A):
+    """configs[4] shape, one GPU's share of it: the full 50 M-node graph (k = 10, ring lattice with randomly PERMUTED node ids)
+    and the full 50 M x 16 coordinate replica on the device, this rank owning the first eighth of the nodes (6.25 M sources,
+    62.5 M edges, 625 M samples per batch).  AE_CE_AUTO resolves to the rounds mode for a sharded range (the d = 16 node
+    kernel with tile negatives); one batch keeps its invariants: samples drawn within 6 sigma of the shard's nb_sample,
+    finite rows, every owned row moved, NO row outside the shard touched (owner computes), the box stays bounded."""
+    n, k, d, world = 50_000_000, 10, 16, 8
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(n).astype(np.int64)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    nbr = np.empty((n, k), np.uint32)
+    for c, o in enumerate((1, 2, 3, 4, 5, -1, -2, -3, -4, -5)):
+        nbr[:, c] = perm[(inv + o) % n]
+    del perm, inv
+    dist = np.sort(rng.random((n, k), dtype=np.float32) + 0.05, axis=1).reshape(-1)
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    g = A.KGraph(indptr, nbr.reshape(-1), dist, k)
+    del nbr, dist
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(rng.standard_normal((n, d), dtype=np.float32), 10.0)
+    hi = n // world
+    h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d), y0, node_lo=0, node_hi=hi)
+    assert h.get_ce_mode() == A.AE_CE_HOGWILD
+    S = 10 * h.get_nb_edges()
+    assert S == 10 * hi * k
+    h.gradient_iteration_threaded(S, 0.5, 1)
+    drawn, rounds = h.samples_drawn()
+    assert abs(drawn - S) < 6 * np.sqrt(S) and rounds >= 8
+    y = h.get_embedded()
+    assert np.isfinite(y).all() and np.abs(y).max() < 50
+    assert (np.abs(y[:hi] - y0[:hi]).max(1) > 0).all()
+    assert np.array_equal(y[hi:], y0[hi:])
