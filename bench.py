@@ -381,6 +381,8 @@ def main():
         scale_shapes = {
             "c3_shape": scale_shape(A, L, "c3", 1_650_000, 6, 2, 6, with_sequential=True),
             "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 4, with_sequential=True),
+            # configs[4]: one GPU's eighth of the 50 M nodes as a graph of its own (k = 10, 16-D)
+            "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 4, with_sequential=False),
         }
 
     roof = roofline_of(head, k, d)
