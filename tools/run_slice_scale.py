@@ -18,7 +18,7 @@ indptr, nbr, dst = bench.lattice_graph(n, k, seed=7, permute=os.environ.get("NO_
 kg = A.KGraph(indptr, nbr, dst, k)
 y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
 npar = A.to_proba_edges(kg, 1.0, 1.0)
-modes = [("sliced", A.AE_CE_SLICED), ("rounds", A.AE_CE_HOGWILD)]
+modes = [("sliced", A.AE_CE_SLICED)] if os.environ.get("ONLY_SLICED") else [("sliced", A.AE_CE_SLICED), ("rounds", A.AE_CE_HOGWILD)]
 if os.environ.get("WITH_SEQ", "1") == "1":
     modes.append(("sequential", A.AE_CE_SEQUENTIAL))
 for name, mode in modes:
