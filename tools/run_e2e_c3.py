@@ -73,7 +73,7 @@ def main():
                            nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True)
     if exact:
         par.ce_mode = A.AE_CE_SEQUENTIAL
-    res["ce_mode"] = "sequential" if exact else "hogwild"
+    res["ce_mode"] = "sequential" if exact else "auto (the sequential-equivalent dataflow at both stages of this size)"
     proj = A.KGraphProjection(small, large, pn, pd)
     emb = A.Embedder.from_hkgraph(proj, par)
     sync()
