@@ -555,6 +555,9 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
                              else "torch/gloo (validation)")},
             "roofline": roof,
             "per_rank_batch_ms_max": kernel_ms_max,
+            "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the bit-exact mode (its `value` is NOT the one-GPU point of this series); "
+                                 "the same graph and mode as here on ONE GPU is its key scale_shapes.c4_shape.rounds_mode (points_per_s, ms_per_step)"
+                                 if not args.weak else "the --gpus 1 line's key rounds_mode (same shape and mode on one GPU)"),
             "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
             "ce_before": ce0, "ce_after": ce_after,
         }
