@@ -386,6 +386,9 @@ def main():
         }
 
     roof = roofline_of(head, k, d)
+    if head["mode"] == 1:
+        roof["latency_bound_note"] = ("the batch is a dependency chain, not a stream: 4 305 levels deep on this graph (tools/dependency_depth.py), "
+                                      "%.2f us per level in this run; DESIGN.md 4.4" % (roof["launch_avg_ms"] * 1e3 / 4305.0))
     replay = pmc_traffic(head["mode"])
     if replay:
         roof.update(replay)
