@@ -221,7 +221,8 @@ def main():
                     help="N = 1 scale runs: ring-lattice kNN graph (node ids permuted) with --points-per-gpu nodes instead of the MNIST-shaped points")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling on 60 k MNIST-shaped points per GPU (round-1 arrangement) instead of the strong-scaling configs[3] shape")
     ap.add_argument("--scale-nodes", type=int, default=11_000_000, help="N > 1 strong scaling: nodes of the fixed graph (k = 6, asked_dim 8)")
-    ap.add_argument("--exchanges", type=int, default=4, help="N > 1: all-gathers of the owned rows per CE batch")
+    ap.add_argument("--exchanges", type=int, default=1, help="N > 1: all-gathers of the owned rows per CE batch (1 = the north star's once per batch; more often "
+                    "costs ~1 ms per exchange at the C4 size and does not buy fidelity: DESIGN 5)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the communicator path with world size 1 (validation)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend used for rendezvous, barriers and timing reductions (gloo: validation runs with several "
