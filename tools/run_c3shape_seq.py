@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
 import annembed_amd as A
 from annembed_amd import _lib as L
