@@ -453,7 +453,10 @@ static void rounds_launch(ae_entropy_optim* o, RoundsBatch& rb, uint32_t r) {
         const bool exact = legacy_dim(o->dev.dim);
         const uint32_t d = o->dev.dim;
         const uint32_t tile_rows = exact ? (d <= 4 ? 1024u : (d <= 8 ? 256u : 128u)) : (d <= 8 ? 256u : 128u);  // node_kernel_tile_rows of the instantiated width
-        const bool tile = a.tile != 0 && a.c.hub_odds == nullptr && a.c.n >= 2ull * tile_rows;
+        // uniform sampler: always (n >= 2 T).  Hubness-weighted sampler (a tile of alias-table draws): from 2^20 nodes on, where
+        // the gathered negatives are what bounds the kernel (C4 shape 360 -> 60 ms per batch, same CE); on small graphs the
+        // gathered form costs nothing and was measured closer to the reference
+        const bool tile = a.tile != 0 && a.c.n >= 2ull * tile_rows && (a.c.hub_odds == nullptr || a.c.n >= (1ull << 20));
         if (exact) { if (tile) launch_round_node_exact_tile(o, a, rb.nodes); else launch_round_node_exact(o, a, rb.nodes); }
         else { if (tile) launch_round_node_padded_tile(o, a, rb.nodes); else launch_round_node_padded(o, a, rb.nodes); }
         return;

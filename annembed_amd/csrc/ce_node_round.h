@@ -202,11 +202,18 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
     // every node is equally likely -- the marginal law of embedder.rs:1121), read ONCE, coalesced, into the LDS buffer that
     // stage C uses later.  A negative then costs an LDS read instead of a 128-byte line fetched for a 4 DIM-byte row: at the
     // C4 shape 5 of the 6 partner rows of a sample, ~70 % of the kernel's memory traffic.
-    constexpr int T = EC, TL = T * DIM / 64;
-    constexpr bool tile_on = TILE;  // (the launcher checks: uniform sampler, n >= 2 T)
+    // Hubness-weighted sampler (NodeSampler, embedder.rs:915-930): a run of consecutive rows cannot carry the weights, so the
+    // tile is T rows DRAWN from the alias table (every slot an independent draw of the reference's law: picking a slot
+    // uniformly afterwards is again a draw of that law), their ids kept beside them for the rejection test -- 3 T random
+    // accesses per wave and round (two table entries and a row per slot) instead of 3 per negative (C4 shape, ~20 samples
+    // per lane and batch ... 360 -> 70 ms per batch).
+    constexpr int T = EC, TL = T * DIM / 64, TPL = T / 64;  // TPL: slots drawn per lane in the hubness variant
+    constexpr bool tile_on = TILE;  // (the launcher checks n >= 2 T)
     const uint32_t tbase = __umulhi(pcg_hash(rk ^ pcg_hash((uint32_t)blockIdx.x + 0x51ED270Bu)), (uint32_t)c.n);
+    uint32_t* s_tile_id = reinterpret_cast<uint32_t*>(s_in_a);  // hubness variant: node id of every slot (stage C reuses the buffer later)
     float tile_raw[TL];
     auto tile_loads = [&] {
+        if (hub) return;  // (drawn and loaded in tile_store: nothing is held in registers across stage A)
         if constexpr (!PAD && DIM % 4 == 0) {
 #pragma unroll
             for (int i = 0; i < TL / 4; i++) {
@@ -237,6 +244,33 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
         }
     };
     auto tile_store = [&] {
+        if (hub) {
+            uint32_t node[TPL], hx[TPL], hal[TPL];
+            float hod[TPL], hu[TPL];
+#pragma unroll
+            for (int i = 0; i < TPL; i++) {  // the alias look-ups of this lane's slots, all in flight together
+                const uint32_t w0 = pcg_hash(rk ^ pcg_hash((uint32_t)blockIdx.x * (uint32_t)T + (uint32_t)(i * 64 + lane) + 0x51ED270Bu));
+                hx[i] = __umulhi(w0, (uint32_t)c.n);
+                hu[i] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                hod[i] = c.hub_odds[hx[i]];
+                hal[i] = c.hub_alias[hx[i]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TPL; i++) {
+                node[i] = (hu[i] < hod[i]) ? hx[i] : hal[i];  // NodeSampler::sample, embedder.rs:927-930
+                ld(node[i], &tile_raw[i * DIM]);
+            }
+#pragma unroll
+            for (int i = 0; i < TPL; i++) {
+                const uint32_t slot = (uint32_t)(i * 64 + lane);
+                s_tile_id[slot] = node[i];
+#pragma unroll
+                for (int t = 0; t < DIM; t++) s_in_row[slot * (uint32_t)DIM + (uint32_t)t] = tile_raw[i * DIM + t];
+            }
+            wave_lds_sync();
+            return;
+        }
         if constexpr (!PAD && DIM % 4 == 0) {
 #pragma unroll
             for (int i = 0; i < TL / 4; i++) {
@@ -419,7 +453,7 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
                     slots[s][g] = __umulhi(pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt), (uint32_t)T);
                     uint32_t node = tbase + slots[s][g];
                     node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
-                    cands[s][g] = node;
+                    cands[s][g] = hub ? s_tile_id[slots[s][g]] : node;
                 }
         } else if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930: the 10 S table look-ups are issued together
             uint32_t xs[S][6], al[S][6];

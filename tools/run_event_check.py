@@ -70,6 +70,8 @@ def stage_fidelity(kind="blobs6", n=20000, nb_batch=40, seeds=3):
     npar = A.to_proba_edges(kg, rho, 1.0)
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
     hub = kg.hubness() if os.environ.get("FID_HUB") else None
+    if os.environ.get("FID_HUB") == "ones":  # the weighted sampler with equal weights: the uniform law through the alias tables
+        hub = np.ones(n, np.uint32)
     out = {"kind": kind, "n": n, "nb_batch": nb_batch, "runs": []}
     modes = ((A.AE_CE_SEQUENTIAL, "sequential"), (A.AE_CE_EVENT, "event"), (A.AE_CE_SLICED, "sliced"), (A.AE_CE_HOGWILD, "rounds"))
     if os.environ.get("FID_MODES"):
