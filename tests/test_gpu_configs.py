@@ -221,6 +221,16 @@ def test_c4_shape_single_gpu_properties(A):
     assert abs(drawn - S) < 6 * np.sqrt(S) and rounds >= 15
     assert np.isfinite(y).all() and np.abs(y).max() < 1e3
     assert (np.abs(y - y0).max(1) > 0).mean() > 0.999
+    # hubness-weighted negatives at this size come from a tile of alias-table draws.  Every node of the lattice has in-degree 6,
+    # so the weighted law IS the uniform one: the batch must land where the uniform sampler's batch did
+    ce_uniform = eo.ce_compute_threaded()
+    del eo
+    eh = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_HOGWILD, hubness_weighting=True), y0, hub_counts=g.hubness())
+    eh.gradient_iteration_threaded(S, 0.5, 1)
+    yh = eh.get_embedded()
+    drawn, _ = eh.samples_drawn()
+    assert abs(drawn - S) < 6 * np.sqrt(S) and np.isfinite(yh).all() and (np.abs(yh - y0).max(1) > 0).mean() > 0.999
+    assert abs(eh.ce_compute_threaded() - ce_uniform) < 0.01 * ce_uniform
 
 
 def test_c5_shape_one_shard_properties(A):
