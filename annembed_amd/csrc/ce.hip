@@ -83,7 +83,8 @@ __device__ __forceinline__ bool make_plan(const CeDev& c, uint64_t s, uint32_t i
         if (c.hub_odds) {  // NodeSampler::sample, :927-930
             uint64_t x = st.index(c.n);
             float u = st.f32();
-            k = (u < c.hub_odds[x]) ? (uint32_t)x : c.hub_alias[x];
+            const uint2 he = c.hub_tab[x];
+            k = (u < __uint_as_float(he.x)) ? (uint32_t)x : he.y;
         } else {
             k = (uint32_t)st.index(c.n);  // :1121
         }
@@ -143,7 +144,8 @@ __device__ __forceinline__ bool make_plan_rows(const CeDev& c, uint64_t s, uint3
         if (c.hub_odds) {
             uint64_t xx = st.index(c.n);
             float uu = st.f32();
-            k = (uu < c.hub_odds[xx]) ? (uint32_t)xx : c.hub_alias[xx];
+            const uint2 he = c.hub_tab[xx];
+            k = (uu < __uint_as_float(he.x)) ? (uint32_t)xx : he.y;
         } else {
             k = (uint32_t)st.index(c.n);
         }
@@ -896,7 +898,11 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
             o->hub_odds.alloc(n); o->hub_odds.upload(odds.data(), n);
             o->hub_alias.alloc(n); o->hub_alias.upload(alias.data(), n);
             sync();
-            d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p;
+            std::vector<uint2> tab(n);
+            for (uint64_t i = 0; i < n; i++) { uint32_t bits; memcpy(&bits, &odds[i], 4); tab[i] = make_uint2(bits, alias[i]); }
+            o->hub_tab.alloc(n); o->hub_tab.upload(tab.data(), n);
+            sync();
+            d.hub_odds = o->hub_odds.p; d.hub_alias = o->hub_alias.p; d.hub_tab = o->hub_tab.p;
         }
         sync();
         const bool sharded = node_lo != 0 || node_hi != n;

@@ -311,8 +311,9 @@ __global__ void __launch_bounds__(64) ce_event_window_kernel(EventArgs a) {
                         const uint32_t w0 = neg_candidate(i, round * 8u + (uint32_t)z);
                         xs[z] = __umulhi(w0, (uint32_t)c.n);
                         uu[z] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                        od[z] = c.hub_odds[xs[z]];
-                        al[z] = c.hub_alias[xs[z]];
+                        const uint2 he = c.hub_tab[xs[z]];
+                        od[z] = __uint_as_float(he.x);
+                        al[z] = he.y;
                     }
 #pragma unroll
                     for (int z = 0; z < 8; z++) cand[z] = (uu[z] < od[z]) ? xs[z] : al[z];
@@ -372,7 +373,8 @@ __global__ void __launch_bounds__(64) ce_event_window_kernel(EventArgs a) {
             uint32_t x = __umulhi(w0, (uint32_t)c.n);
             if (hub) {
                 const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                x = (uu < c.hub_odds[x]) ? x : c.hub_alias[x];
+                const uint2 he = c.hub_tab[x];
+                x = (uu < __uint_as_float(he.x)) ? x : he.y;
             }
             kk[g] = x;
         }

@@ -20,8 +20,9 @@ struct CeDev {
     const float* edge_odds;
     const uint32_t* edge_alias;
     const uint32_t* edge_src;
-    const float* hub_odds;
+    const float* hub_odds;       // non-null = hubness-weighted negative sampling (NodeSampler, embedder.rs:915-930)
     const uint32_t* hub_alias;
+    const uint2* hub_tab;        // the same alias table, one 8-byte entry per node {odds bits, alias}: one random access per draw
 };
 
 // one in-edge (u -> v) of the transposed graph: everything thread v needs to replay the sample's
@@ -57,6 +58,7 @@ struct ae_entropy_optim {
     DevBuf<float> y, emb_scale;
     DevBuf<float> edge_odds, hub_odds;
     DevBuf<uint32_t> edge_alias, edge_src, hub_alias;
+    DevBuf<uint2> hub_tab;
     DevBuf<double> partial;
     DevBuf<unsigned int> err;
     // sequential-mode scratch

@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(kBlock) ce_plan_node_kernel(NodeArgs a) {
                     if constexpr (HUB) {  // NodeSampler::sample, embedder.rs:927-930
                         const uint32_t x = __umulhi(w0, (uint32_t)c.n);
                         const float u = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                        cand = (u < c.hub_odds[x]) ? x : c.hub_alias[x];
+                        const uint2 he = c.hub_tab[x];
+                        cand = (u < __uint_as_float(he.x)) ? x : he.y;
                     } else {
                         cand = __umulhi(w0, (uint32_t)c.n);  // :1121
                     }

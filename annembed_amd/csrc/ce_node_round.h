@@ -252,8 +252,9 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
                 const uint32_t w0 = pcg_hash(rk ^ pcg_hash((uint32_t)blockIdx.x * (uint32_t)T + (uint32_t)(i * 64 + lane) + 0x51ED270Bu));
                 hx[i] = __umulhi(w0, (uint32_t)c.n);
                 hu[i] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                hod[i] = c.hub_odds[hx[i]];
-                hal[i] = c.hub_alias[hx[i]];
+                const uint2 he = c.hub_tab[hx[i]];
+                hod[i] = __uint_as_float(he.x);
+                hal[i] = he.y;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -465,8 +466,9 @@ __global__ void __launch_bounds__(64, (DIM == 8 ? 2 : 1)) ce_round_node_kernel(N
                     const uint32_t w0 = pcg_hash(node_base + (t0 + (uint32_t)s) * 128u + (uint32_t)g * 16u + attempt);
                     xs[s][g] = __umulhi(w0, (uint32_t)c.n);
                     uu[s][g] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                    od[s][g] = c.hub_odds[xs[s][g]];
-                    al[s][g] = c.hub_alias[xs[s][g]];
+                    const uint2 he = c.hub_tab[xs[s][g]];
+                    od[s][g] = __uint_as_float(he.x);
+                    al[s][g] = he.y;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -237,8 +237,9 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
                         const uint32_t w0 = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u);
                         xs[z] = __umulhi(w0, (uint32_t)c.n);
                         uu[z] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                        od[z] = c.hub_odds[xs[z]];
-                        al[z] = c.hub_alias[xs[z]];
+                        const uint2 he = c.hub_tab[xs[z]];
+                        od[z] = __uint_as_float(he.x);
+                        al[z] = he.y;
                     }
 #pragma unroll
                     for (int z = 0; z < 8; z++) { cand[z] = (uu[z] < od[z]) ? xs[z] : al[z]; crow[z] = 0; }
