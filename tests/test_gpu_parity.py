@@ -358,8 +358,8 @@ def test_event_mode_statistics_match_oracle(A, oracle):
 def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     """Every asked_dim and row length.  asked_dim in {2,3,4,8,16}: the default resolves to the sequential mode (the oracle's
     run: bit for bit at b = 1, 1e-5 relative CE with the general exponent, whose pow() differs in the last bits), and the
-    event-ordered kernel (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours) lands within 5 % (CE) /
-    8 % (edge-length median and q90) of it on these 4000-node graphs (the oracle's own seed spread here is ~3 %).  Other
+    event-ordered and the time-sliced kernels (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours) land
+    within 5 % (CE) / 8 % (edge-length median and q90) of it on these 4000-node graphs (the oracle's own seed spread here is ~3 %).  Other
     dimensions have no faithful kernel and resolve to the rounds mode (zero-padded to 8 / 16 / 32 columns): the approximate
     mode's bar."""
     n = 4000
@@ -398,6 +398,13 @@ def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
         ev.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
     assert np.isfinite(ev.get_embedded()).all()
     close(ev.get_embedded(), ev.ce_compute_threaded(), 0.05, 0.08)
+    # ... and so does the time-sliced mode (every dimension / row length / sampler / exponent it is instantiated for)
+    sl = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b, ce_mode=A.AE_CE_SLICED),
+                        y0, hub_counts=hubc)
+    for it in range(1, 6):
+        sl.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
+    assert np.isfinite(sl.get_embedded()).all()
+    close(sl.get_embedded(), sl.ce_compute_threaded(), 0.05, 0.08)
 
 
 def test_converged_run_matches_reference_quality(A, oracle):
