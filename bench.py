@@ -267,9 +267,11 @@ def main():
             torch.cuda.synchronize()
 
     if use_dist:
-        multi_gpu(args, A, L, dist, torch, rank, world, fence)
+        line = multi_gpu(args, A, L, dist, torch, rank, world, fence)
         dist.barrier()
         dist.destroy_process_group()
+        if line is not None:  # the ONE JSON line, after everything that might still write to stdout (RCCL's banner, teardown)
+            print(json.dumps(line), flush=True)
         return
 
     # =============================== N = 1 ===============================
@@ -565,10 +567,10 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
             "ce_before": ce0, "ce_after": ce_after,
         }
-        print(json.dumps(out))
     if comm is not None:
         del eo
         comm.close()
+    return out if rank == 0 else None
 
 
 def pmc_traffic(mode):
