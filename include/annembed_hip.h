@@ -90,7 +90,10 @@ enum {
        target is v against the other rows as they were when the round started; per-edge sample counts are Poisson with
        the means of the reference's i.i.d. edge draw.  f32 arithmetic.  A throughput mode: it is NOT inside the
        reference's own run-to-run envelope (stale partner rows change what the stiff attraction step converges to: final
-       cross entropy 0.6-0.9x the sequential loop's).  asked_dim <= 32 and rows of <= 32 neighbours
+       cross entropy 0.6-1.07x the sequential loop's).  The five negatives of a sample are read from an LDS
+       tile of rows the wave loads once per round: T consecutive rows from a uniform random start (uniform sampler; every
+       node equally likely, as embedder.rs:1121), T alias-table draws (hubness-weighted sampler, from 2^20 nodes on).
+       The only mode that shards over devices.  asked_dim <= 32 and rows of <= 32 neighbours
        (longer rows: asked_dim in {2,3,4,8,16}); anything else fails with AE_ERR_INVALID_ARG. */
     AE_CE_HOGWILD = 0,
     /* Deterministic: the result of executing samples 0,1,2,... of the reference's `gradient_iteration`
