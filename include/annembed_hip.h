@@ -68,7 +68,10 @@ int32_t ae_get_stream(void **stream);
 /* EmbedderParams, src/embedparams.rs:77-103 (field for field) + build extras */
 typedef struct ae_embedder_params {
     uint64_t asked_dim;           /* :79  default 2  */
-    uint8_t dmap_init;            /* :81  default 1  */
+    uint8_t dmap_init;            /* :81  default 1.  The diffusion-map initialisation comes from a rank-20 SVD
+                                     (graphlaplace.rs:97-125), i.e. at most 19 coordinates: with dmap_init and
+                                     asked_dim > 19, embed() fails with AE_ERR_EMBED (the reference hard-wires a 2-D
+                                     initialisation, embedder.rs:319; here it has asked_dim columns) */
     double beta;                  /* :83  default 1. */
     double b;                     /* :85  default 1. */
     double scale_rho;             /* :87  default 1. */
