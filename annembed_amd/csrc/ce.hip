@@ -190,48 +190,6 @@ __device__ __forceinline__ void apply_sample(const CeDev& c, const Plan& p, doub
     store_row<DIM>(c.y, p.i, yi);  // :1301
 }
 
-// runtime-dimension fallback (dim <= 64), same arithmetic
-__device__ void apply_sample_dyn(const CeDev& c, const Plan& p, double grad_step) {
-    constexpr int MAXD = 64;
-    const uint32_t dim = c.dim;
-    float yi[MAXD], yj[MAXD], grad[MAXD];
-    float* Yi = c.y + (uint64_t)p.i * dim;
-    float* Yj = c.y + (uint64_t)p.j * dim;
-    for (uint32_t t = 0; t < dim; t++) { yi[t] = Yi[t]; yj[t] = Yj[t]; grad[t] = 0.f; }
-    const double weight = (double)p.w;
-    const double scale = (double)c.emb_scale[p.i];
-    const double b = c.b;
-    float acc = 0.f;
-    for (uint32_t t = 0; t < dim; t++) { float df = yi[t] - yj[t]; acc += df * df; }
-    const double d_ij_scaled = (double)acc / (scale * scale);
-    const double coeff = grad_coeff(d_ij_scaled, scale, b);
-    if (d_ij_scaled > 0.) {
-        const double alfa = (double)(1.0f / kProbaMin);
-        const double coeff_repulsion = 1. / fmax(d_ij_scaled * d_ij_scaled, alfa);
-        const double coeff_ij = fmax(grad_step * coeff * (-weight + (1. - weight) * coeff_repulsion), -0.49);
-        const float cf = (float)coeff_ij;
-        for (uint32_t t = 0; t < dim; t++) grad[t] = (yj[t] - yi[t]) * cf;
-    }
-    for (uint32_t t = 0; t < dim; t++) { yi[t] -= grad[t]; yj[t] += grad[t]; }
-    for (uint32_t t = 0; t < dim; t++) Yj[t] = yj[t];
-    for (int g = 0; g < 5; g++) {
-        const float* Yk = c.y + (uint64_t)p.k[g] * dim;
-        float ak = 0.f;
-        for (uint32_t t = 0; t < dim; t++) { float df = yi[t] - Yk[t]; ak += df * df; }
-        const double d_ik = (double)ak;
-        const double d_ik_scaled = d_ik / (scale * scale);
-        const double cf2 = grad_coeff(d_ik_scaled, scale, b);
-        if (d_ik > 0.) {
-            const double coeff_repulsion = 1. / fmax(d_ik_scaled * d_ik_scaled, 1. / 16.);
-            const double coeff_ik = fmin(grad_step * cf2 * coeff_repulsion, 2.);
-            const float cf = (float)coeff_ik;
-            for (uint32_t t = 0; t < dim; t++) grad[t] = (Yk[t] - yi[t]) * cf;
-        }
-        for (uint32_t t = 0; t < dim; t++) yi[t] -= grad[t];
-    }
-    for (uint32_t t = 0; t < dim; t++) Yi[t] = yi[t];
-}
-
 template <int DIM>
 __global__ void __launch_bounds__(256) ce_sgd_hogwild_kernel(CeDev c, uint64_t s_begin, uint64_t nb_sample, double grad_step,
                                                              uint32_t iter, unsigned int* err) {
@@ -239,8 +197,7 @@ __global__ void __launch_bounds__(256) ce_sgd_hogwild_kernel(CeDev c, uint64_t s
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nb_sample; s += stride) {
         Plan p;
         if (!make_plan(c, s_begin + s, iter, p)) { atomicOr(err, 1u); continue; }
-        if constexpr (DIM == 0) apply_sample_dyn(c, p, grad_step);
-        else apply_sample<DIM>(c, p, grad_step);
+        apply_sample<DIM>(c, p, grad_step);
     }
 }
 
@@ -284,8 +241,7 @@ __global__ void __launch_bounds__(256) ce_sgd_planned_kernel(CeDev c, const uint
     p.i = o[0]; p.j = o[1];
     for (int g = 0; g < 5; g++) p.k[g] = o[2 + g];
     p.w = plan_w[s];
-    if constexpr (DIM == 0) apply_sample_dyn(c, p, grad_step);
-    else apply_sample<DIM>(c, p, grad_step);
+    apply_sample<DIM>(c, p, grad_step);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -410,6 +366,10 @@ template <int DIM>
 __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
                                                           const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
                                                           float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err, uint32_t lane_stride) {
+    // rows of more than 16 columns (asked_dim 17 ... 64): only the two end points are held in registers, a negative's row is
+    // taken when its repulsion is due (7 x 64 registers do not exist); same arithmetic, same order
+    constexpr bool WIDE = DIM > 16;
+    constexpr int NR = WIDE ? 2 : 7;
     // only every lane_stride-th lane carries samples: a wave's trip through the loop below costs the poll round trip plus
     // the arithmetic of whichever lanes advance, and a blocked lane moves once per trip -- fewer passengers, shorter trips
     const uint64_t gtid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -421,7 +381,7 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
         const uint64_t s = k * nthreads + tid;
         bool finished = !carrier || s >= S;
         uint32_t node[7], pr[7];
-        float rows[7][DIM];
+        float rows[NR][DIM];
         float w = 0.f;
         uint32_t pending = 0;  // bit t: row t not gathered yet
         if (!finished) {
@@ -429,8 +389,10 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
             for (int t = 0; t < 7; t++) {
                 node[t] = plan_nodes[s * 7 + t];
                 pr[t] = pred[s * 7 + t];
-                if (pr[t] == kNoPred) load_row<DIM>(c.y, node[t], rows[t]);  // the batch's initial row: c.y is read-only here
-                else pending |= 1u << t;
+                if (t < NR) {
+                    if (pr[t] == kNoPred) load_row<DIM>(c.y, node[t], rows[t]);  // the batch's initial row: c.y is read-only here
+                    else pending |= 1u << t;
+                }
             }
             w = plan_w[s];
         }
@@ -445,7 +407,7 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
         while (!__all(finished)) {
             if (!finished) {
 #pragma unroll
-                for (int t = 0; t < 7; t++) {
+                for (int t = 0; t < NR; t++) {
                     if ((pending >> t) & 1u) {
                         float tmp[DIM];
                         if (df_try_load_version<DIM>(ver, pr[t], tmp)) {
@@ -460,18 +422,31 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                     df_store_version<DIM>(ver, s * 2 + 1, rows[1]);
                     stage = 1;
                 }
-                // one code path for the five repulsions: the row is selected by the stage, lanes leave when they block
-                while (stage >= 1 && stage <= 5 && ((pending >> (1 + stage)) & 1u) == 0u) {
-                    float yk[DIM];
+                if constexpr (!WIDE) {
+                    // one code path for the five repulsions: the row is selected by the stage, lanes leave when they block
+                    while (stage >= 1 && stage <= 5 && ((pending >> (1 + stage)) & 1u) == 0u) {
+                        float yk[DIM];
 #pragma unroll
-                    for (int q = 0; q < DIM; q++) {
-                        float v = rows[2][q];
+                        for (int q = 0; q < DIM; q++) {
+                            float v = rows[NR > 2 ? 2 : 0][q];
 #pragma unroll
-                        for (int g = 2; g <= 5; g++) v = stage == g ? rows[1 + g][q] : v;
-                        yk[q] = v;
+                            for (int g = 2; g <= 5; g++) v = stage == g ? rows[NR > 2 ? 1 + g : 0][q] : v;
+                            yk[q] = v;
+                        }
+                        sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
+                        stage++;
                     }
-                    sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
-                    stage++;
+                } else {
+                    while (stage >= 1 && stage <= 5) {
+                        uint32_t nk = node[2], pk = pr[2];
+#pragma unroll
+                        for (int g = 2; g <= 5; g++) { nk = stage == g ? node[1 + g] : nk; pk = stage == g ? pr[1 + g] : pk; }
+                        float yk[DIM];
+                        if (pk == kNoPred) load_row<DIM>(c.y, nk, yk);
+                        else if (!df_try_load_version<DIM>(ver, pk, yk)) break;  // not published yet: next trip
+                        sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
+                        stage++;
+                    }
                 }
                 if (stage == 6) {
                     df_store_version<DIM>(ver, s * 2, rows[0]);
@@ -494,8 +469,9 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
 // the last version of every node written in the batch becomes its row in the coordinate array
 template <int DIM>
 __global__ void df_commit_kernel(uint64_t n, const uint64_t* __restrict__ rowptr, const uint32_t* __restrict__ vals,
-                                 const float* __restrict__ ver, float* __restrict__ y) {
+                                 const float* __restrict__ ver, float* __restrict__ y, const unsigned int* __restrict__ err) {
     const uint64_t x = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (*err & 8u) return;  // the dataflow kernel gave up (poll budget): its rows are not results, the coordinates stay as they were
     if (x >= n || rowptr[x + 1] == rowptr[x]) return;
     const uint32_t pv = vals[rowptr[x + 1] - 1];
 #pragma unroll
@@ -614,7 +590,7 @@ static void check_err_flag(ae_entropy_optim* o) {
 
 template <int DIM>
 static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
-    if constexpr (DIM > 0) {
+    {
         static int blocks_per_cu = 0, cus = 0;
         if (!blocks_per_cu) {
             int dev = 0;
@@ -626,8 +602,11 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
         const unsigned bs = debug_knob("AE_DF_BLOCK") ? (unsigned)atoi(debug_knob("AE_DF_BLOCK")) : 128u;
         int bpc = 0;
         AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, (int)bs, 0));
-        blocks_per_cu = std::max(1, std::min(bpc, 8));
-        const uint64_t blocks_cap = (uint64_t)((double)blocks_per_cu * cus * 0.9);
+        // The progress argument needs EVERY block resident (a sample of sweep k + 1 in block 0 may wait on a sample of sweep k
+        // in the last block).  The occupancy query can be one block per CU higher than what the hardware admits (SGPR
+        // granularity, MI355X_MICROARCH.md "Residency"): the grid is capped one full block per CU below it.
+        blocks_per_cu = std::max(1, std::min(bpc, 8) - 1);
+        const uint64_t blocks_cap = (uint64_t)blocks_per_cu * cus;
         // The run is bound by the dependency chain: per hop one trip of the carrying wave through its loop (poll round
         // trip + the f64 arithmetic of the lanes that advance).  Enough carrier lanes to keep every chain moving
         // (~512 samples per carrier, at least 16 K carriers), spread thinly over the waves (every 8th lane) while the
@@ -653,8 +632,7 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
             for (size_t off = 0; off < bytes; off += piece)
                 AE_HIP(hipMemsetAsync(reinterpret_cast<char*>(ver) + off, 0xFF, std::min(piece, bytes - off), stream()));
         }
-        // The progress argument needs every block resident: the grid is sized from the occupancy query with a margin (the
-        // query can be one block per CU high).  A plain launch: same residency as a cooperative one without its +15-19 us.
+        // A plain launch: same residency as a cooperative one without its +15-19 us (the cap above is the check).
         if (o->df_events.size() >= 64) {  // nobody asks for the timings: keep the list short
             (void)hipEventDestroy(o->df_events.front().first);
             (void)hipEventDestroy(o->df_events.front().second);
@@ -669,7 +647,7 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
         AE_HIP(hipEventRecord(e1, stream()));
         o->df_events.emplace_back(e0, e1);
         hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
-                           (const float*)ver, o->dev.y);
+                           (const float*)ver, o->dev.y, (const unsigned int*)o->err.p);
     }
 }
 
@@ -714,25 +692,24 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
     df_prepare_set(o, st, S, iter);
     const double t1 = now();
     uint32_t* v1 = reinterpret_cast<uint32_t*>(st.keys1.p) + 2 * S;
-    if (dim == 2) launch_dataflow<2>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
-    else if (dim == 3) launch_dataflow<3>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
-    else if (dim == 4) launch_dataflow<4>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
-    else if (dim == 8) launch_dataflow<8>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
-    else if (dim == 16) launch_dataflow<16>(o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    AE_DISPATCH_DIM(dim, launch_dataflow, o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
     check_launch("ce_dataflow");
     sync();
     if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan + sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
                       (unsigned long long)S, (t1 - t0) * 1e3, (now() - t1) * 1e3);
     unsigned int h = 0;
     o->err.download(&h, 1);
-    if (h & 8u) fail(AE_ERR_STATE, "sequential dataflow kernel: poll budget exceeded (scheduling invariant violated)");
+    if (h & 8u) {
+        o->err.zero();  // reported once: the flag does not poison later calls on the handle
+        sync();
+        fail(AE_ERR_STATE, "sequential dataflow kernel: poll budget exceeded (not every workgroup was resident -- is another process using this GPU? -- or the scheduling invariant was violated); the coordinates are those of the batch's start");
+    }
     check_err_flag(o);
 }
 
 static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
-    // device-scheduled form for the instantiated dimensions; AE_CE_SEQ_LEVELS=1 keeps the host level schedule (A/B)
-    const uint32_t d = o->dev.dim;
-    if ((d == 2 || d == 3 || d == 4 || d == 8 || d == 16) && !debug_knob("AE_CE_SEQ_LEVELS")) {
+    // device-scheduled form; AE_CE_SEQ_LEVELS=1 (debug knob) keeps the host level schedule for A/B
+    if (!debug_knob("AE_CE_SEQ_LEVELS")) {
         run_sequential_dataflow(o, nb_sample, step, iter);
         return;
     }
@@ -801,15 +778,24 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 
 
 
-// AE_CE_AUTO: the sequential-equivalent dataflow (exact, reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one
-// device, <= 2^28 samples per batch (its scratch: ~40 GB at asked_dim 8) --, beyond that the time-sliced mode (statistical
-// parity, 2-3.4x faster at that size, a tenth of the memory), and for shards / other dimensions the rounds mode
-uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch) {
+// AE_CE_AUTO never resolves to a mode whose output is not the reference's: the sequential-equivalent dataflow (exact,
+// reproducible) for batches up to kAutoSequentialSamples samples -- there it is also the fastest faithful mode --, beyond that
+// the time-sliced mode on conflict-free matchings (statistical parity, throughput-bound, a tenth of the memory).  Every
+// asked_dim in [1, 64] has both (rows are stored zero-padded, ce_internal.h).  A sharded node range has no faithful schedule:
+// AUTO refuses it -- the caller asks for the approximate rounds mode (AE_CE_HOGWILD) by name.
+constexpr uint64_t kAutoSequentialSamples = 1ull << 25;
+uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
+    (void)dim;
     if (mode > AE_CE_SLICED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;
-    const bool df_dim = dim == 2 || dim == 3 || dim == 4 || dim == 8 || dim == 16;
-    if (!sharded && df_dim && samples_per_batch <= (1ull << 28)) return AE_CE_SEQUENTIAL;
-    if (sharded || !df_dim) return AE_CE_HOGWILD;
+    if (sharded)
+        fail(AE_ERR_INVALID_ARG, "AE_CE_AUTO does not shard: no schedule over several devices reproduces the reference's loop "
+                                 "(DESIGN 5); ask for the approximate rounds mode by name (ce_mode = AE_CE_HOGWILD) or run the whole graph on one device");
+    const bool sliced_ok = max_nbng <= 32 && nnz < 0xFFFFFFFFull;
+    if (samples_per_batch <= kAutoSequentialSamples || !sliced_ok) {
+        if (samples_per_batch >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "no faithful CE mode fits: rows of more than 32 neighbours or >= 2^32 edges with >= 2^31 samples per batch");
+        return AE_CE_SEQUENTIAL;
+    }
     return AE_CE_SLICED;
 }
 
@@ -827,10 +813,11 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         o->g = g;
         o->np = np;
         o->params = *params;
-        const uint64_t n = g->n, dim = params->asked_dim;
+        const uint64_t n = g->n, adim = params->asked_dim, dim = ae_pad_dim(adim);  // dim: the row stride (ce_internal.h)
         o->y.alloc(n * dim);
-        if (y0_on_device) AE_HIP(hipMemcpyAsync(o->y.p, y0, sizeof(float) * n * dim, hipMemcpyDeviceToDevice, stream()));
-        else o->y.upload(y0, n * dim);
+        if (dim != adim) o->y.zero();
+        AE_HIP(hipMemcpy2DAsync(o->y.p, sizeof(float) * dim, y0, sizeof(float) * adim, sizeof(float) * adim, n,
+                                y0_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
         // embedded scales: mean of the initial scales as the reference's sequential f32 sum (:1358)
         std::vector<float> hscale = np->scale.to_host();
         float ssum = 0.f;
@@ -906,7 +893,7 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         }
         sync();
         const bool sharded = node_lo != 0 || node_hi != n;
-        const uint32_t mode = resolve_ce_mode(params->ce_mode, dim, sharded, params->nb_sampling_by_edge * (edge_hi - edge_lo));
+        const uint32_t mode = resolve_ce_mode(params->ce_mode, dim, sharded, params->nb_sampling_by_edge * (edge_hi - edge_lo), g->max_nbng, g->nnz);
         if (mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
         if (mode == AE_CE_EVENT) ce_event_prepare(o.get());
         if (mode == AE_CE_SLICED) ce_slice_prepare(o.get());
@@ -1115,7 +1102,9 @@ int32_t ae_entropy_optim_get_scales(const ae_entropy_optim* o, float* emb_scale)
 int32_t ae_entropy_optim_get_embedded(const ae_entropy_optim* o, float* y) {
     return guard([&] {
         if (!o || !y) fail(AE_ERR_INVALID_ARG, "null argument");
-        o->y.download(y, o->dev.n * o->dev.dim);
+        AE_HIP(hipMemcpy2DAsync(y, sizeof(float) * o->params.asked_dim, o->y.p, sizeof(float) * o->dev.dim, sizeof(float) * o->params.asked_dim,
+                                o->dev.n, hipMemcpyDeviceToHost, stream()));
+        sync();
     });
 }
 int32_t ae_entropy_optim_device_coords(ae_entropy_optim* o, void** d_y, uint64_t* n, uint64_t* dim) {

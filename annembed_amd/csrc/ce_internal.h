@@ -38,6 +38,18 @@ struct InEdge {
 
 using namespace ae;  // internal header: the handle below is declared at global scope for the C ABI
 
+// Coordinate rows are stored with a row stride of pad_dim(asked_dim) floats, the columns beyond asked_dim exactly zero: a zero
+// column adds +0 to every squared distance and never moves (its gradient component is (0 - 0) * c), so every kernel is
+// instantiated for the strides below only and still computes the reference's arithmetic for ANY asked_dim in [1, 64]
+// (the reference is generic in the dimension and publishes 15-D runs, src/embedder.rs:604-618).
+inline uint32_t ae_pad_dim(uint64_t d) {
+    if (d <= 2) return 2;
+    if (d <= 4) return (uint32_t)d;
+    if (d <= 8) return 8;
+    if (d <= 16) return 16;
+    if (d <= 32) return 32;
+    return 64;
+}
 #define AE_DISPATCH_DIM(dim, FN, ...)          \
     switch (dim) {                             \
         case 2: FN<2>(__VA_ARGS__); break;     \
@@ -45,7 +57,9 @@ using namespace ae;  // internal header: the handle below is declared at global 
         case 4: FN<4>(__VA_ARGS__); break;     \
         case 8: FN<8>(__VA_ARGS__); break;     \
         case 16: FN<16>(__VA_ARGS__); break;   \
-        default: FN<0>(__VA_ARGS__); break;    \
+        case 32: FN<32>(__VA_ARGS__); break;   \
+        case 64: FN<64>(__VA_ARGS__); break;   \
+        default: ::ae::fail(AE_ERR_INVALID_ARG, "internal: row stride %u is not instantiated", (unsigned)(dim)); \
     }
 
 struct ae_comm;
@@ -98,6 +112,12 @@ struct ae_entropy_optim {
     DevBuf<float> sl_list_scale;
     DevBuf<unsigned long long> sl_done;
     float sl_pmax = 0.f;
+    DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
+    DevBuf<float> sl_node_ov;                   // per node: probability mass of its overflow edges
+    DevBuf<float> sl_srec;                      // per node: static record {embedded scale, neighbour ids, edge probabilities}
+    uint32_t sl_srec_floats = 16;
+    uint32_t sl_classes = 0, sl_color_rounds = 0;
+    double sl_ov_frac = 1.;                     // share of the edge probability mass in the overflow class
     // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch
     ae_comm* comm = nullptr;
     std::vector<uint64_t> comm_ranges;

@@ -76,7 +76,7 @@ struct NodeArgs {
 
 // PCG-RXS-M-XS 32 output hash: the fast mode's stream for the negative draws (the exact Philox stream
 // of the oracle is used by AE_CE_SEQUENTIAL; this mode is validated statistically)
-__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+__host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
     uint32_t s = x * 747796405u + 2891336453u;
     uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;

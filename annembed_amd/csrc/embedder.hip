@@ -113,9 +113,11 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
         rc_check(ae_entropy_optim_ce(o, &out.ce_after));  // :885
         void* dy = nullptr;
 
-        rc_check(ae_entropy_optim_device_coords(o, &dy, nullptr, nullptr));
+        uint64_t stride = 0;  // rows are stored zero-padded to a stride of 2, 3, 4, 8, 16, 32 or 64 floats
+        rc_check(ae_entropy_optim_device_coords(o, &dy, nullptr, &stride));
         out.y.alloc(g->n * params.asked_dim);
-        AE_HIP(hipMemcpyAsync(out.y.p, dy, sizeof(float) * g->n * params.asked_dim, hipMemcpyDeviceToDevice, stream()));
+        AE_HIP(hipMemcpy2DAsync(out.y.p, sizeof(float) * params.asked_dim, dy, sizeof(float) * stride, sizeof(float) * params.asked_dim, g->n,
+                                hipMemcpyDeviceToDevice, stream()));
         sync();
         out.hubness = std::move(hub);
     } catch (...) {
@@ -130,7 +132,7 @@ void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params,
     const uint64_t n = g->n, dim = params.asked_dim;
     DevBuf<float> y0;
     // the single-lane reference-order sums of the initialisation only where the CE loop after them is the bit-exact mode
-    TreeSums sums(resolve_ce_mode(params.ce_mode, dim, false, params.nb_sampling_by_edge * g->nnz) != AE_CE_SEQUENTIAL);
+    TreeSums sums(resolve_ce_mode(params.ce_mode, dim, false, params.nb_sampling_by_edge * g->nnz, g->max_nbng, g->nnz) != AE_CE_SEQUENTIAL);
     if (params.dmap_init) {  // :308-345
         ae_diffusion_params dp;
         memset(&dp, 0, sizeof(dp));

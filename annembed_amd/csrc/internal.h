@@ -15,5 +15,5 @@ ae_entropy_optim* entropy_optim_create_impl(const ae_kgraph* g, const ae_node_pa
                                             const float* y0, bool y0_on_device, const uint32_t* hub_counts, uint64_t node_lo,
                                             uint64_t node_hi);
 // the mode ae_embedder_params.ce_mode stands for on a given problem (AE_CE_AUTO resolved; see include/annembed_hip.h)
-uint32_t resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch);
+uint32_t resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz);
 }  // namespace ae

@@ -152,13 +152,21 @@ class LibraryComm:
         from . import _lib as L
         self._L, self.rank, self.world = L, rank, world
         ident = (ctypes.c_uint8 * 128)()
+        failure = None
         if rank == 0:
-            L.check(L.load().ae_comm_unique_id(ident))
+            try:
+                L.check(L.load().ae_comm_unique_id(ident))
+            except Exception as e:  # RCCL not loadable on rank 0: the other ranks must not be left waiting in the broadcast
+                failure = e
         if world > 1:
             import torch.distributed as dist
-            box = [bytes(ident)]
+            box = [b"" if failure is not None else bytes(ident)]  # an empty id is the failure sentinel: every rank raises together
             dist.broadcast_object_list(box, src=0)
+            if len(box[0]) != 128:
+                raise RuntimeError("LibraryComm: rank 0 could not create an RCCL unique id" + (": %s" % failure if failure is not None else ""))
             ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        elif failure is not None:
+            raise failure
         h = ctypes.c_void_p()
         L.check(L.load().ae_comm_init(rank, world, ident, ctypes.byref(h)))
         self._h = h

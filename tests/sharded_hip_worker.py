@@ -24,7 +24,7 @@ def main():
     lo, hi = shard_range(n, world, rank)
     g = A.KGraph(indptr, nbr, dst)
     npar = A.NodeParams.from_host(g, proba, scale)
-    eo = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=nb_batch), y0, node_lo=lo, node_hi=hi)  # AE_CE_AUTO -> rounds mode for a shard
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=nb_batch, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=lo, node_hi=hi)  # the rounds mode, by name: AE_CE_AUTO refuses a shard
     assert eo.get_ce_mode() == A.AE_CE_HOGWILD
 
     y_dev = device_tensor(eo)

@@ -255,7 +255,7 @@ def test_c5_shape_one_shard_properties(A):
     npar = A.to_proba_edges(g, 1.0, 1.0)
     y0 = A.set_data_box(rng.standard_normal((n, d), dtype=np.float32), 10.0)
     hi = n // world
-    h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d), y0, node_lo=0, node_hi=hi)
+    h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=0, node_hi=hi)  # (AE_CE_AUTO refuses a shard)
     assert h.get_ce_mode() == A.AE_CE_HOGWILD
     S = 10 * h.get_nb_edges()
     assert S == 10 * hi * k
