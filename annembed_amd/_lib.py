@@ -119,9 +119,10 @@ SIGNATURES = {
     "ae_entropy_optim_get_nb_edges": [_vp, _P(_u64)],
     "ae_entropy_optim_get_ce_mode": [_vp, _P(C.c_uint32)],
     "ae_entropy_optim_dataflow_time": [_vp, _P(C.c_double), _P(_u64)],
-    "ae_projection_init": [_vp, _vp, _u64, _u64, _vp],
+    "ae_projection_init": [_vp, _vp, _u64, _u64, _u64, _vp],
     "ae_comm_unique_id": [_vp],
     "ae_comm_init": [C.c_int32, C.c_int32, _vp, _P(_vp)],
+    "ae_comm_init_hostmem": [C.c_int32, C.c_int32, C.c_char_p, _u64, _P(_vp)],
     "ae_comm_destroy": [_vp],
     "ae_comm_all_reduce_sum": [_vp, _P(C.c_double)],
     "ae_entropy_optim_set_comm": [_vp, _vp, C.c_uint32],
@@ -138,6 +139,7 @@ SIGNATURES = {
     "ae_embedder_new": [_vp, _P(CEmbedderParams), _P(_vp)],
     "ae_embedder_from_hkgraph": [_vp, _P(CEmbedderParams), _P(_vp)],
     "ae_embedder_destroy": [_vp],
+    "ae_embedder_set_comm": [_vp, _vp, C.c_uint32],
     "ae_embedder_embed": [_vp],
     "ae_embedder_get_nb_nodes": [_vp, _P(_u64)],
     "ae_embedder_get_embedded": [_vp, _vp],

@@ -237,9 +237,11 @@ class KGraphProjection(_Handle):
     def projection_init(self, y_small, seed=4664397):
         """the initial embedding h_embed gives the large graph (src/embedder.rs:245-269)"""
         y_small = _f32(y_small)
+        if y_small.ndim != 2 or y_small.shape[0] != self.small.get_nb_nodes():
+            raise ValueError("y_small must have one row per node of the small graph (%d), got shape %s" % (self.small.get_nb_nodes(), y_small.shape))
         n_large = self.large.get_nb_nodes()
         y0 = np.zeros((n_large, y_small.shape[1]), np.float32)
-        check(L.load().ae_projection_init(self._h, ptr(y_small), y_small.shape[1], seed, ptr(y0)))
+        check(L.load().ae_projection_init(self._h, ptr(y_small), y_small.shape[0], y_small.shape[1], seed, ptr(y0)))
         return y0
 
     def get_large_graph(self):
@@ -573,6 +575,12 @@ class Embedder(_Handle):
         h = C.c_void_p()
         check(L.load().ae_embedder_new(kgraph.handle, C.byref(parameters.c()), C.byref(h)))
         super().__init__(h)
+
+    def set_comm(self, comm, exchanges_per_batch=1):
+        """multi-GPU embedding: this process is one rank of `comm` (annembed_amd.dist.LibraryComm / HostMemComm); embed() then
+        shards the CE loop over the ranks (ae_embedder_set_comm).  parameters.ce_mode must be AE_CE_HOGWILD."""
+        self._comm = comm  # keep the communicator alive
+        check(L.load().ae_embedder_set_comm(self._h, comm._h if comm is not None else None, exchanges_per_batch))
 
     @classmethod
     def from_hkgraph(cls, graph_projection, parameters):

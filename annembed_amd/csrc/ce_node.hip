@@ -388,7 +388,13 @@ static RoundsBatch rounds_prepare(ae_entropy_optim* o, uint64_t nb_sample, doubl
     RoundsBatch rb;
     const uint64_t nodes = o->dev.node_hi - o->dev.node_lo;
     rb.nodes = nodes;
-    const double per_node = (double)nb_sample / (double)nodes;  // expected samples per source node in the batch
+    // expected samples per source node in the batch.  A shard derives it from GRAPH-wide quantities -- samples per edge x edges per
+    // node of the whole graph, which is also the reference's law (edges are drawn in proportion to p_e over the whole graph:
+    // every node sends nb_sample_total / n samples on average whatever its own degree): every rank then cuts the batch into the
+    // same number of rounds (the collectives of a batch match) and evaluates remote pushes with the source rank's Poisson means
+    const bool is_shard = o->dev.shard_edges != o->dev.nnz;
+    const double per_node = is_shard ? (double)nb_sample / (double)o->dev.shard_edges * (double)o->dev.nnz / (double)o->dev.n
+                                     : (double)nb_sample / (double)nodes;
     // rounds: keep the largest per-edge Poisson mean (p_e <= 1) below 30 so that exp(-mu) stays normal in f32
     // samples per node and round: measured trade-off between fidelity to the sequential reference (final cross
     // entropy within ~10-15 %, edge-length quantiles within ~7 %) and per-round fixed costs.  The

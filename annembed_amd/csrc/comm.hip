@@ -11,6 +11,15 @@
 // and the library carries no link-time dependency on it.  A process that has already loaded an RCCL (PyTorch ships one
 // under the same soname) gets that copy -- one RCCL per process.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 
 #include "ce_internal.h"
 
@@ -62,21 +71,128 @@ void nccl_check(int rc, const char* what) {
     if (rc != 0) fail(AE_ERR_NO_DEVICE, "RCCL %s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
 }
 
+// Second transport, for validation and for hosts where RCCL cannot be loaded: the ranks of ONE machine exchange through a POSIX
+// shared-memory segment (device -> segment -> device, a sense-reversing barrier of two atomics in the segment).  Same
+// collectives, same call sites; several ranks may share one GPU (RCCL refuses that), which is how the multi-process path is
+// exercised end to end on a single-GPU box.  Not a performance path.
+struct HostMem {
+    int fd = -1;
+    char name[96] = {0};
+    uint8_t* base = nullptr;
+    size_t bytes = 0, data_bytes = 0;
+    uint32_t sense = 0;
+    struct Header {
+        std::atomic<uint32_t> arrived;
+        std::atomic<uint32_t> generation;
+        std::atomic<uint32_t> ready;  // set by rank 0 once the segment is sized
+    };
+    Header* hdr() { return reinterpret_cast<Header*>(base); }
+    uint8_t* slot(int rank) { return base + 64 + (size_t)rank * 64; }
+    uint8_t* data(int world) { return base + 64 + (size_t)world * 64; }
+    void barrier(int world) {
+        Header* h = hdr();
+        const uint32_t gen = h->generation.load(std::memory_order_acquire);
+        if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+            h->arrived.store(0, std::memory_order_relaxed);
+            h->generation.store(gen + 1, std::memory_order_release);
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (h->generation.load(std::memory_order_acquire) == gen) {
+                sched_yield();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(AE_ERR_STATE, "host-memory communicator: a rank did not reach the barrier within 120 s");
+            }
+        }
+    }
+};
+
 }  // namespace
 
 struct ae_comm {
     nccl_comm_t nccl = nullptr;
+    std::unique_ptr<HostMem> host;  // non-null: the shared-memory transport
     int rank = 0, world = 1;
 };
 
 namespace ae {
 
+static bool comm_active(const ae_comm* c) { return c && (c->world > 1 || debug_knob("AE_COMM_FORCE")); }  // (the knob: a single-GPU box exercises the RCCL calls)
+
+int comm_rank(const ae_comm* c) { return c ? c->rank : 0; }
+int comm_world(const ae_comm* c) { return c ? c->world : 1; }
+
+// `count` floats at device pointer p: root's content on every rank afterwards (library stream; returns when it is there)
+void comm_broadcast_f32(ae_comm* c, float* p, uint64_t count, int root) {
+    if (!comm_active(c)) return;
+    if (c->host) {
+        HostMem& h = *c->host;
+        if (count * sizeof(float) > h.data_bytes) fail(AE_ERR_INVALID_ARG, "host-memory communicator: broadcast of %llu bytes exceeds the segment", (unsigned long long)(count * 4));
+        if (c->rank == root) { sync(); AE_HIP(hipMemcpy(h.data(c->world), p, count * sizeof(float), hipMemcpyDeviceToHost)); }
+        h.barrier(c->world);
+        if (c->rank != root) AE_HIP(hipMemcpy(p, h.data(c->world), count * sizeof(float), hipMemcpyHostToDevice));
+        h.barrier(c->world);
+        return;
+    }
+    nccl_check(rccl().Broadcast(p, p, count, kNcclFloat32, root, c->nccl, stream()), "broadcast");
+    sync();
+}
+
+// every rank's two words, in rank order
+static std::vector<uint64_t> comm_all_gather_u64x2(ae_comm* c, const uint64_t (&mine)[2]) {
+    std::vector<uint64_t> all(2 * (size_t)c->world);
+    if (!comm_active(c)) { all[0] = mine[0]; all[1] = mine[1]; return all; }
+    if (c->host) {
+        HostMem& h = *c->host;
+        memcpy(h.slot(c->rank), mine, 16);
+        h.barrier(c->world);
+        for (int q = 0; q < c->world; q++) memcpy(&all[2 * q], h.slot(q), 16);
+        h.barrier(c->world);
+        return all;
+    }
+    DevBuf<uint64_t> d_mine(2), d_all(2 * (size_t)c->world);
+    d_mine.upload(mine, 2);
+    nccl_check(rccl().AllGather(d_mine.p, d_all.p, 2, kNcclUint64, c->nccl, stream()), "all-gather of the node ranges");
+    return d_all.to_host();
+}
+
+double comm_all_reduce_sum(ae_comm* c, double value) {
+    if (!comm_active(c)) return value;
+    if (c->host) {
+        HostMem& h = *c->host;
+        memcpy(h.slot(c->rank), &value, 8);
+        h.barrier(c->world);
+        double s = 0.;
+        for (int q = 0; q < c->world; q++) { double v; memcpy(&v, h.slot(q), 8); s += v; }  // rank order: the same sum on every rank
+        h.barrier(c->world);
+        return s;
+    }
+    DevBuf<double> d(1);
+    d.upload(&value, 1);
+    nccl_check(rccl().AllReduce(d.p, d.p, 1, kNcclFloat64, kNcclSum, c->nccl, stream()), "all-reduce");
+    d.download(&value, 1);
+    return value;
+}
+
 // all-gather of the owned rows of o->y, in place, on the library's stream
 void ce_comm_exchange(ae_entropy_optim* o) {
     ae_comm* c = o->comm;
-    if (!c || (c->world == 1 && !debug_knob("AE_COMM_FORCE"))) return;  // (the knob: a single-GPU box exercises the RCCL calls)
-    Rccl& r = rccl();
+    if (!comm_active(c)) return;
     const uint64_t dim = o->dev.dim;
+    if (c->host) {
+        HostMem& h = *c->host;
+        if (o->dev.n * dim * sizeof(float) > h.data_bytes) fail(AE_ERR_INVALID_ARG, "host-memory communicator: the coordinate array exceeds the segment (max_bytes of ae_comm_init_hostmem)");
+        float* seg = reinterpret_cast<float*>(h.data(c->world));
+        sync();
+        AE_HIP(hipMemcpy(seg + o->dev.node_lo * dim, o->y.p + o->dev.node_lo * dim, (o->dev.node_hi - o->dev.node_lo) * dim * sizeof(float), hipMemcpyDeviceToHost));
+        h.barrier(c->world);
+        for (int q = 0; q < c->world; q++) {
+            if (q == c->rank) continue;
+            const uint64_t lo = o->comm_ranges[2 * q], hi = o->comm_ranges[2 * q + 1];
+            AE_HIP(hipMemcpy(o->y.p + lo * dim, seg + lo * dim, (hi - lo) * dim * sizeof(float), hipMemcpyHostToDevice));
+        }
+        h.barrier(c->world);
+        return;
+    }
+    Rccl& r = rccl();
     if (o->comm_equal) {
         const uint64_t rows = o->comm_ranges[1] - o->comm_ranges[0];
         nccl_check(r.AllGather(o->y.p + o->dev.node_lo * dim, o->y.p, rows * dim, kNcclFloat32, c->nccl, stream()), "all-gather");
@@ -88,6 +204,27 @@ void ce_comm_exchange(ae_entropy_optim* o) {
         }
         nccl_check(r.GroupEnd(), "group end");
     }
+}
+
+// attaches the communicator to a shard handle: the ranks' node ranges must tile [0, n) in rank order
+void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchanges_per_batch) {
+    if (!c) { o->comm = nullptr; return; }
+    if (o->params.ce_mode != AE_CE_HOGWILD)
+        fail(AE_ERR_INVALID_ARG, "only the rounds mode (AE_CE_HOGWILD) shards over devices; this handle runs mode %u", o->params.ce_mode);
+    const uint64_t h[2] = {o->dev.node_lo, o->dev.node_hi};
+    o->comm_ranges = comm_all_gather_u64x2(c, h);  // every rank learns every rank's node range
+    uint64_t expect = 0;
+    bool equal = true;
+    for (int q = 0; q < c->world; q++) {
+        if (o->comm_ranges[2 * q] != expect || o->comm_ranges[2 * q + 1] <= o->comm_ranges[2 * q])
+            fail(AE_ERR_INVALID_ARG, "the ranks' node ranges must tile [0, n) in rank order");
+        expect = o->comm_ranges[2 * q + 1];
+        equal = equal && (o->comm_ranges[2 * q + 1] - o->comm_ranges[2 * q]) == (o->comm_ranges[1] - o->comm_ranges[0]);
+    }
+    if (expect != o->dev.n) fail(AE_ERR_INVALID_ARG, "the ranks' node ranges must tile [0, n) in rank order");
+    o->comm_equal = equal;
+    o->comm = c;
+    o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
 }
 
 }  // namespace ae
@@ -117,10 +254,59 @@ int32_t ae_comm_init(int32_t rank, int32_t world, const uint8_t* id128, ae_comm*
     });
 }
 
+int32_t ae_comm_init_hostmem(int32_t rank, int32_t world, const char* name, uint64_t max_bytes, ae_comm** out) {
+    return guard([&] {
+        require_device();
+        if (!name || !out || world < 1 || rank < 0 || rank >= world || strlen(name) == 0 || strlen(name) > 80) fail(AE_ERR_INVALID_ARG, "bad argument");
+        std::unique_ptr<ae_comm> c(new ae_comm);
+        c->rank = rank;
+        c->world = world;
+        c->host.reset(new HostMem);
+        HostMem& h = *c->host;
+        snprintf(h.name, sizeof(h.name), "/%s", name);
+        h.data_bytes = (size_t)max_bytes;
+        h.bytes = 64 + (size_t)world * 64 + h.data_bytes;
+        if (rank == 0) {
+            shm_unlink(h.name);  // a stale segment of a crashed run
+            h.fd = shm_open(h.name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (h.fd < 0 || ftruncate(h.fd, (off_t)h.bytes) != 0) fail(AE_ERR_STATE, "host-memory communicator: cannot create the segment %s (%s)", h.name, strerror(errno));
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {  // until rank 0 has created and sized it
+                h.fd = shm_open(h.name, O_RDWR, 0600);
+                struct stat st;
+                if (h.fd >= 0 && fstat(h.fd, &st) == 0 && (size_t)st.st_size >= h.bytes) break;
+                if (h.fd >= 0) { close(h.fd); h.fd = -1; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(AE_ERR_STATE, "host-memory communicator: rank 0 did not create the segment %s within 120 s", h.name);
+                usleep(2000);
+            }
+        }
+        void* m = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, h.fd, 0);
+        if (m == MAP_FAILED) fail(AE_ERR_OOM, "host-memory communicator: mmap of %zu bytes failed", h.bytes);
+        h.base = static_cast<uint8_t*>(m);
+        if (rank == 0) {  // (a fresh segment is zero-filled: arrived = generation = 0)
+            h.hdr()->ready.store(1, std::memory_order_release);
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (h.hdr()->ready.load(std::memory_order_acquire) != 1) {
+                usleep(1000);
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(AE_ERR_STATE, "host-memory communicator: segment never became ready");
+            }
+        }
+        h.barrier(world);
+        *out = c.release();
+    });
+}
+
 int32_t ae_comm_destroy(ae_comm* c) {
     return guard([&] {
         if (!c) return;
         if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+        if (c->host) {
+            if (c->host->base) munmap(c->host->base, c->host->bytes);
+            if (c->host->fd >= 0) close(c->host->fd);
+            if (c->rank == 0) shm_unlink(c->host->name);
+        }
         delete c;
     });
 }
@@ -129,11 +315,7 @@ int32_t ae_comm_all_reduce_sum(ae_comm* c, double* value) {
     return guard([&] {
         require_device();
         if (!c || !value) fail(AE_ERR_INVALID_ARG, "null argument");
-        if (c->world == 1 && !debug_knob("AE_COMM_FORCE")) return;
-        DevBuf<double> d(1);
-        d.upload(value, 1);
-        nccl_check(rccl().AllReduce(d.p, d.p, 1, kNcclFloat64, kNcclSum, c->nccl, stream()), "all-reduce");
-        d.download(value, 1);
+        *value = comm_all_reduce_sum(c, *value);
     });
 }
 
@@ -141,28 +323,7 @@ int32_t ae_entropy_optim_set_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exch
     return guard([&] {
         require_device();
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
-        if (!c) { o->comm = nullptr; return; }
-        if (o->params.ce_mode != AE_CE_HOGWILD)
-            fail(AE_ERR_INVALID_ARG, "only the rounds mode (AE_CE_HOGWILD) shards over devices; this handle runs mode %u", o->params.ce_mode);
-        // every rank learns every rank's node range
-        DevBuf<uint64_t> mine(2), all(2 * (size_t)c->world);
-        const uint64_t h[2] = {o->dev.node_lo, o->dev.node_hi};
-        mine.upload(h, 2);
-        if (c->world > 1 || debug_knob("AE_COMM_FORCE")) nccl_check(rccl().AllGather(mine.p, all.p, 2, kNcclUint64, c->nccl, stream()), "all-gather of the node ranges");
-        else AE_HIP(hipMemcpyAsync(all.p, mine.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream()));
-        o->comm_ranges = all.to_host();
-        uint64_t expect = 0;
-        bool equal = true;
-        for (int q = 0; q < c->world; q++) {
-            if (o->comm_ranges[2 * q] != expect || o->comm_ranges[2 * q + 1] <= o->comm_ranges[2 * q])
-                fail(AE_ERR_INVALID_ARG, "the ranks' node ranges must tile [0, n) in rank order");
-            expect = o->comm_ranges[2 * q + 1];
-            equal = equal && (o->comm_ranges[2 * q + 1] - o->comm_ranges[2 * q]) == (o->comm_ranges[1] - o->comm_ranges[0]);
-        }
-        if (expect != o->dev.n) fail(AE_ERR_INVALID_ARG, "the ranks' node ranges must tile [0, n) in rank order");
-        o->comm_equal = equal;
-        o->comm = c;
-        o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
+        entropy_optim_attach_comm(o, c, exchanges_per_batch);
     });
 }
 

@@ -75,9 +75,18 @@ struct ae_embedder {
     std::vector<float> embedding, initial_embedding;
     std::vector<uint32_t> hubness;
     double ce_before = 0., ce_after = 0.;
+    ae_comm* comm = nullptr;       // multi-GPU: this process is one rank of the embedding (ae_embedder_set_comm)
+    uint32_t comm_exchanges = 1;
 };
 
 namespace {
+
+// the multi-GPU context of one embed() call
+struct Dist {
+    ae_comm* comm = nullptr;
+    uint32_t exchanges = 1;
+    bool active() const { return comm_world(comm) > 1; }
+};
 
 struct StageResult {
     DevBuf<float> y;  // n x dim final embedding (device)
@@ -89,17 +98,35 @@ void rc_check(int32_t rc) {
     if (rc != AE_OK) throw Error(rc, ae_last_error_message());
 }
 
-// entropy_optimize, embedder.rs:794-904, from a device-resident initial embedding
-void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params& params, const float* d_y0,
-                             StageResult& out) {
+// entropy_optimize, embedder.rs:794-904, from a device-resident initial embedding.  Multi-GPU (no reference counterpart): the
+// initial embedding is rank 0's on every rank (broadcast: the replicas start bit-identical), this rank optimises its contiguous
+// share of the source nodes, the coordinate rows are all-gathered inside ae_entropy_optim_gradient_iteration, the cross entropies
+// are sums over the ranks; after the last batch every rank holds the whole embedding.
+void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const ae_embedder_params& params, float* d_y0,
+                             StageResult& out, const Dist& dist) {
     std::vector<uint32_t> hub;
     if (params.hubness_weighting) {  // :810-834
         hub.resize(g->n);
         rc_check(ae_kgraph_hubness(g, hub.data()));
     }
-    ae_entropy_optim* o = entropy_optim_create_impl(g, np, &params, d_y0, true, hub.empty() ? nullptr : hub.data(), 0, g->n);
+    uint64_t lo = 0, hi = g->n;
+    if (dist.active()) {
+        if (params.ce_mode != AE_CE_HOGWILD)
+            fail(AE_ERR_INVALID_ARG, "a multi-GPU embedding runs the rounds mode, whose output is not the reference's (DESIGN 5): ask for it by name "
+                                     "(ce_mode = AE_CE_HOGWILD); every faithful mode needs the whole graph on one device");
+        const uint64_t world = (uint64_t)comm_world(dist.comm), rank = (uint64_t)comm_rank(dist.comm);
+        if (g->n < world * ((uint64_t)g->max_nbng + 8)) fail(AE_ERR_INVALID_ARG, "graph too small for %llu ranks", (unsigned long long)world);
+        const uint64_t base = g->n / world, rem = g->n % world;  // contiguous ranges, the remainder spread over the first ranks
+        lo = rank * base + std::min(rank, rem);
+        hi = lo + base + (rank < rem ? 1 : 0);
+        comm_broadcast_f32(dist.comm, d_y0, g->n * params.asked_dim, 0);
+    }
+    ae_entropy_optim* o = entropy_optim_create_impl(g, np, &params, d_y0, true, hub.empty() ? nullptr : hub.data(), lo, hi);
     try {
-        rc_check(ae_entropy_optim_ce(o, &out.ce_before));  // :846
+        if (dist.active()) entropy_optim_attach_comm(o, dist.comm, dist.exchanges);
+        double ce = 0.;
+        rc_check(ae_entropy_optim_ce(o, &ce));  // :846
+        out.ce_before = comm_all_reduce_sum(dist.comm, ce);
         uint64_t nnz = 0;
         rc_check(ae_entropy_optim_get_nb_edges(o, &nnz));
         const uint64_t nb_sample = params.nb_sampling_by_edge * nnz;  // :858
@@ -110,9 +137,9 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
         double ms;
         uint64_t cnt;
         rc_check(ae_entropy_optim_kernel_time(o, &ms, &cnt));
-        rc_check(ae_entropy_optim_ce(o, &out.ce_after));  // :885
+        rc_check(ae_entropy_optim_ce(o, &ce));  // :885
+        out.ce_after = comm_all_reduce_sum(dist.comm, ce);
         void* dy = nullptr;
-
         uint64_t stride = 0;  // rows are stored zero-padded to a stride of 2, 3, 4, 8, 16, 32 or 64 floats
         rc_check(ae_entropy_optim_device_coords(o, &dy, nullptr, &stride));
         out.y.alloc(g->n * params.asked_dim);
@@ -128,11 +155,11 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
 }
 
 // one_step_embed, embedder.rs:298-371.  Returns the device embedding; initial embedding optionally copied out.
-void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params, StageResult& out, std::vector<float>* initial_out) {
+void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params, StageResult& out, std::vector<float>* initial_out, const Dist& dist) {
     const uint64_t n = g->n, dim = params.asked_dim;
     DevBuf<float> y0;
     // the single-lane reference-order sums of the initialisation only where the CE loop after them is the bit-exact mode
-    TreeSums sums(resolve_ce_mode(params.ce_mode, dim, false, params.nb_sampling_by_edge * g->nnz, g->max_nbng, g->nnz) != AE_CE_SEQUENTIAL);
+    TreeSums sums(dist.active() || resolve_ce_mode(params.ce_mode, dim, false, params.nb_sampling_by_edge * g->nnz, g->max_nbng, g->nnz) != AE_CE_SEQUENTIAL);
     if (params.dmap_init) {  // :308-345
         ae_diffusion_params dp;
         memset(&dp, 0, sizeof(dp));
@@ -156,18 +183,19 @@ void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params,
     }
     ae_node_params np;
     to_proba_edges_device(g, (float)params.scale_rho, (float)params.beta, &np);  // :351-355
+    if (dist.active()) comm_broadcast_f32(dist.comm, y0.p, n * dim, 0);  // (before it is reported: get_initial_embedding is rank 0's everywhere)
     if (initial_out) { initial_out->resize(n * dim); y0.download(initial_out->data(), n * dim); }
-    entropy_optimize_device(g, &np, params, y0.p, out);  // :356
+    entropy_optimize_device(g, &np, params, y0.p, out, dist);  // :356
 }
 
 // h_embed, embedder.rs:194-295
-void h_embed_device(const ae_kgraph_projection* proj, const ae_embedder_params& params, StageResult& out, std::vector<float>* initial_out) {
+void h_embed_device(const ae_kgraph_projection* proj, const ae_embedder_params& params, StageResult& out, std::vector<float>* initial_out, const Dist& dist) {
     ae_embedder_params first = params;
     first.nb_grad_batch = params.grad_factor * params.nb_grad_batch;  // :204-205
     first.grad_step = 1.;                                             // :207
     first.hierarchy_layer = 0;                                        // :208
     StageResult res1;
-    one_step_embed_device(proj->small_graph, first, res1, nullptr);  // :213
+    one_step_embed_device(proj->small_graph, first, res1, nullptr, dist);  // :213
     const ae_kgraph* large = proj->large_graph;
     ae_node_params np;
     to_proba_edges_device(large, (float)params.scale_rho, (float)params.beta, &np);  // :226-230
@@ -177,7 +205,7 @@ void h_embed_device(const ae_kgraph_projection* proj, const ae_embedder_params& 
                        (uint32_t)dim, proj->proj_node.p, proj->proj_dist.p, proj->median_dist, params.seed, y0.p);  // :245-269
     check_launch("projection_init");
     if (initial_out) { initial_out->resize(n_large * dim); y0.download(initial_out->data(), n_large * dim); }
-    entropy_optimize_device(large, &np, params, y0.p, out);  // :275
+    entropy_optimize_device(large, &np, params, y0.p, out, dist);  // :275
 }
 
 }  // namespace
@@ -186,11 +214,12 @@ extern "C" {
 
 // stage-level entry of the projection initialisation (embedder.rs:245-269): the first n_small rows are y_small, every other
 // node starts at its projection's row plus clip(N(0,1) sqrt(proj_dist / median / dim), 2).  Host arrays in, host array out.
-int32_t ae_projection_init(const ae_kgraph_projection* proj, const float* y_small, uint64_t dim, uint64_t seed, float* y0) {
+int32_t ae_projection_init(const ae_kgraph_projection* proj, const float* y_small, uint64_t n_small_rows, uint64_t dim, uint64_t seed, float* y0) {
     return guard([&] {
         require_device();
-        if (!proj || !y_small || !y0 || dim == 0) fail(AE_ERR_INVALID_ARG, "bad argument");
+        if (!proj || !y_small || !y0 || dim == 0 || dim > 64) fail(AE_ERR_INVALID_ARG, "bad argument (dim must be in [1, 64])");
         const uint64_t n_small = proj->small_graph->n, n_large = proj->large_graph->n;
+        if (n_small_rows != n_small) fail(AE_ERR_INVALID_ARG, "y_small has %llu rows, the small graph %llu nodes", (unsigned long long)n_small_rows, (unsigned long long)n_small);
         DevBuf<float> ys(n_small * dim), out(n_large * dim);
         ys.upload(y_small, n_small * dim);
         hipLaunchKernelGGL(projection_init_kernel, dim3(blocks_for(n_large * dim, 256)), dim3(256), 0, stream(), (const float*)ys.p, n_small,
@@ -224,14 +253,27 @@ int32_t ae_embedder_destroy(ae_embedder* e) {
     return guard([&] { delete e; });
 }
 
+// Multi-GPU embedding (no reference counterpart; SURVEY 8b "8-GPU entry point"): every rank of the communicator builds the same
+// graph, creates the same Embedder and calls embed(); see include/annembed_hip.h
+int32_t ae_embedder_set_comm(ae_embedder* e, ae_comm* comm, uint32_t exchanges_per_batch) {
+    return guard([&] {
+        if (!e) fail(AE_ERR_INVALID_ARG, "null argument");
+        e->comm = comm;
+        e->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
+    });
+}
+
 int32_t ae_embedder_embed(ae_embedder* e) {
     int32_t rc = guard([&] {
         require_device();
         if (!e) fail(AE_ERR_INVALID_ARG, "null argument");
         if (e->params.asked_dim == 0 || e->params.asked_dim > 64) fail(AE_ERR_INVALID_ARG, "asked_dim must be in [1,64]");
         StageResult res;
-        if (e->g) one_step_embed_device(e->g, e->params, res, &e->initial_embedding);  // :184-186
-        else h_embed_device(e->proj, e->params, res, &e->initial_embedding);           // :187-190
+        Dist dist;
+        dist.comm = e->comm;
+        dist.exchanges = e->comm_exchanges;
+        if (e->g) one_step_embed_device(e->g, e->params, res, &e->initial_embedding, dist);  // :184-186
+        else h_embed_device(e->proj, e->params, res, &e->initial_embedding, dist);           // :187-190
         e->embedding.resize(e->n * e->params.asked_dim);
         res.y.download(e->embedding.data(), e->embedding.size());
         e->hubness = std::move(res.hubness);

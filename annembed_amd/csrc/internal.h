@@ -3,6 +3,7 @@
 #include "objects.h"
 
 struct ae_entropy_optim;
+struct ae_comm;
 
 namespace ae {
 void to_proba_edges_device(const ae_kgraph* g, float scale_rho, float beta, ae_node_params* np);
@@ -16,4 +17,10 @@ ae_entropy_optim* entropy_optim_create_impl(const ae_kgraph* g, const ae_node_pa
                                             uint64_t node_hi);
 // the mode ae_embedder_params.ce_mode stands for on a given problem (AE_CE_AUTO resolved; see include/annembed_hip.h)
 uint32_t resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz);
+// communicator (comm.hip): RCCL or the shared-memory transport; a null or one-rank communicator makes every call a no-op
+int comm_rank(const ae_comm* c);
+int comm_world(const ae_comm* c);
+void comm_broadcast_f32(ae_comm* c, float* d_ptr, uint64_t count, int root);
+double comm_all_reduce_sum(ae_comm* c, double value);
+void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchanges_per_batch);
 }  // namespace ae

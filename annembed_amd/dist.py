@@ -188,3 +188,16 @@ class LibraryComm:
         if self._h:
             self._L.check(self._L.load().ae_comm_destroy(self._h))
             self._h = None
+
+
+class HostMemComm(LibraryComm):
+    """The library's communicator over a POSIX shared-memory segment (ae_comm_init_hostmem): ranks of one machine, several may
+    share a GPU.  Needs no torch and no RCCL; validation of the multi-process path, and the fallback where RCCL cannot load."""
+
+    def __init__(self, rank, world, name, max_bytes):
+        import ctypes
+        from . import _lib as L
+        self._L, self.rank, self.world = L, rank, world
+        h = ctypes.c_void_p()
+        L.check(L.load().ae_comm_init_hostmem(rank, world, name.encode(), int(max_bytes), ctypes.byref(h)))
+        self._h = h

@@ -114,15 +114,20 @@ enum {
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
     AE_CE_EVENT = 3,
-    /* Default.  AE_CE_SEQUENTIAL (exact and reproducible) when it fits -- asked_dim in {2,3,4,8,16}, one device, <= 2^28
-       samples per batch (its scratch grows with the batch: ~40 GB there) --, else AE_CE_SLICED, else (other dimensions, or a sharded node range, i.e. several GPUs)
-       AE_CE_HOGWILD.  ae_entropy_optim_get_ce_mode reports the choice. */
+    /* Default: never a mode whose output is not the reference's.  AE_CE_SEQUENTIAL (exact and reproducible) for batches of up to
+       2^25 samples -- there it is also the fastest faithful mode --, AE_CE_SLICED beyond (statistical parity, throughput-bound, a
+       tenth of the memory).  Every asked_dim in [1, 64] has both: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or
+       64 columns (a zero column adds +0 to every distance and never moves).  A sharded node range (several GPUs) has no faithful
+       schedule: AE_CE_AUTO refuses it with AE_ERR_INVALID_ARG -- ask for AE_CE_HOGWILD by name.  ae_entropy_optim_get_ce_mode
+       reports the choice. */
     AE_CE_AUTO = 4,
-    /* Time-sliced optimistic execution (ce_slice.hip): the batch's events (the same edge-keyed Poisson process as
-       AE_CE_EVENT) are bucketed into thin time slices; inside a slice the events that hold both their rows exclusively run
-       exactly as src/embedder.rs:1207-1301 (one lane, both rows, one gradient), the others are deferred to the next pass.
-       Statistical parity like AE_CE_EVENT, throughput-bound, no limit on the graph size; asked_dim in {2,3,4,8,16}, one
-       device. */
+    /* Time-sliced execution on conflict-free matchings (ce_slice.hip): the batch's events (the same edge-keyed Poisson process
+       as AE_CE_EVENT) are cut into thin time slices; the graph's edges are coloured once (a proper edge colouring: every class is
+       a matching), and a step = the events of one class in one slice is one launch in which no two samples share a row: every
+       lane applies its sample exactly as src/embedder.rs:1207-1301 (both rows, one gradient), class order drawn afresh per slice.
+       Edges without a colour (hubs) and, on graphs of a few million edges, all of them run optimistically instead: an event that
+       holds both its rows exclusively runs, the others are deferred to the next pass.  Scalar arithmetic in f32.  Statistical
+       parity like AE_CE_EVENT, throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes, one device. */
     AE_CE_SLICED = 5
 };
 enum {
@@ -212,8 +217,10 @@ int32_t ae_kgraph_projection_create(const ae_kgraph *small, const ae_kgraph *lar
                                     const uint32_t *proj_node, const float *proj_dist,
                                     ae_kgraph_projection **out);
 int32_t ae_kgraph_projection_destroy(ae_kgraph_projection *p);
-/* h_embed's projection initialisation alone (src/embedder.rs:245-269): y_small [n_small x dim] -> y0 [n_large x dim], host arrays */
-int32_t ae_projection_init(const ae_kgraph_projection *proj, const float *y_small, uint64_t dim, uint64_t seed, float *y0);
+/* h_embed's projection initialisation alone (src/embedder.rs:245-269): y_small [n_small x dim] -> y0 [n_large x dim], host arrays.
+   n_small states the rows of y_small and must be the small graph's node count (checked: the library reads n_small x dim floats);
+   dim in [1, 64]. */
+int32_t ae_projection_init(const ae_kgraph_projection *proj, const float *y_small, uint64_t n_small, uint64_t dim, uint64_t seed, float *y0);
 
 /* ------------------------------------------------------------------------------------------- */
 /* a2. to_proba_edges -- src/tools/kdumap.rs:26-116, 132-235                                    */
@@ -334,11 +341,16 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * EntropyOptim created on this rank's node range [node_lo, node_hi) -- the ranges of the ranks must tile [0, n) in rank
  * order -- makes ae_entropy_optim_gradient_iteration exchange the owned coordinate rows itself: in place, on the library's
  * stream, `exchanges_per_batch` times per batch at equal runs of rounds (1 = once per batch, at its end).  Only the rounds
- * mode (AE_CE_HOGWILD, what AE_CE_AUTO resolves to for a sharded range) shards.  The final cross entropy is the sum of the
+ * mode (AE_CE_HOGWILD, asked for by name: AE_CE_AUTO refuses a sharded range) shards.  The final cross entropy is the sum of the
  * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
 typedef struct ae_comm ae_comm;
 int32_t ae_comm_unique_id(uint8_t *id128);
 int32_t ae_comm_init(int32_t rank, int32_t world, const uint8_t *id128, ae_comm **out);
+/* The same communicator over a POSIX shared-memory segment instead of RCCL (ranks of ONE machine; device -> segment -> device):
+ * for validation -- several ranks may share one GPU, which RCCL refuses -- and for hosts where RCCL cannot be loaded.  `name`
+ * (<= 80 characters, no slash) is the same on every rank and unique per job; max_bytes >= the largest exchange, i.e. the
+ * coordinate array n x row stride x 4 (row stride: ae_entropy_optim_device_coords).  Not a performance path. */
+int32_t ae_comm_init_hostmem(int32_t rank, int32_t world, const char *name, uint64_t max_bytes, ae_comm **out);
 int32_t ae_comm_destroy(ae_comm *c);
 int32_t ae_comm_all_reduce_sum(ae_comm *c, double *value);
 int32_t ae_entropy_optim_set_comm(ae_entropy_optim *o, ae_comm *c, uint32_t exchanges_per_batch);
@@ -368,9 +380,10 @@ int32_t ae_entropy_optim_plan(ae_entropy_optim *o, uint64_t s_begin, uint64_t co
 int32_t ae_entropy_optim_samples_drawn(ae_entropy_optim *o, uint64_t *samples, uint32_t *rounds);
 /* embedded scales (embedder.rs:1356-1373), n entries */
 int32_t ae_entropy_optim_get_scales(const ae_entropy_optim *o, float *emb_scale);
-/* current coordinates, n x dim row-major */
+/* current coordinates, n x asked_dim row-major */
 int32_t ae_entropy_optim_get_embedded(const ae_entropy_optim *o, float *y);
-/* device pointer to the n x dim f32 coordinate array (for RCCL all-gather by the caller) */
+/* device pointer to the coordinate array (for an all-gather by the caller): n rows of `dim` floats, where `dim` is the ROW STRIDE --
+   asked_dim when that is 2, 3, 4, 8 or 16, else asked_dim zero-padded to 2 / 8 / 16 / 32 / 64 */
 int32_t ae_entropy_optim_device_coords(ae_entropy_optim *o, void **d_y, uint64_t *n, uint64_t *dim);
 /* average duration in ms of the SGD kernel launches since the last call (hipEvent on the handle's
    stream) and their count; resets the accumulators. */
@@ -394,6 +407,15 @@ int32_t ae_embedder_new(const ae_kgraph *g, const ae_embedder_params *params, ae
 int32_t ae_embedder_from_hkgraph(const ae_kgraph_projection *p, const ae_embedder_params *params,
                                  ae_embedder **out);
 int32_t ae_embedder_destroy(ae_embedder *e);
+/* Multi-GPU embedding at the boundary the reference's callers use (no reference counterpart: the reference is one process;
+   SURVEY 8b "8-GPU entry point").  Every rank builds the same graph, creates the same Embedder, attaches its communicator
+   (ae_comm_init / ae_comm_init_hostmem) and calls ae_embedder_embed: the initialisation runs replicated and rank 0's initial
+   embedding is broadcast (the replicas start bit-identical), rank r optimises the r-th contiguous share of the source nodes
+   (both stages of a hierarchical embedding), the coordinate rows are all-gathered `exchanges_per_batch` times per CE batch
+   inside the library, the reported cross entropies are sums over the ranks, and after embed() every rank holds the whole
+   embedding.  Only the rounds mode shards: params.ce_mode must be AE_CE_HOGWILD (approximate -- DESIGN 5 -- so it is never
+   chosen silently); embed() fails with AE_ERR_INVALID_ARG otherwise.  A NULL or one-rank communicator changes nothing. */
+int32_t ae_embedder_set_comm(ae_embedder *e, ae_comm *comm, uint32_t exchanges_per_batch);
 /* Embedder::embed (embedder.rs:183): one_step_embed (:298) or h_embed (:194). Ok(1) -> AE_OK */
 int32_t ae_embedder_embed(ae_embedder *e);
 int32_t ae_embedder_get_nb_nodes(const ae_embedder *e, uint64_t *n);          /* :785 */

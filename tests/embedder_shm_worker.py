@@ -1,0 +1,43 @@
+"""worker of tests/test_gpu_parity.py::test_embedder_multi_gpu_entry_two_ranks_one_gpu: one rank of a two-rank embedding through
+the library's Embedder-level entry (ae_embedder_set_comm) over the shared-memory communicator; both ranks share this box's GPU.
+usage: embedder_shm_worker.py <dir> <rank> <world> <segment name> <flat|hier>"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, rank, world, name, kind = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    import annembed_amd as A
+    from annembed_amd.dist import HostMemComm
+    g0 = np.load(os.path.join(out_dir, "graph.npz"))
+    g = A.KGraph(g0["indptr"], g0["nbr"], g0["dist"])
+    n = len(g0["indptr"]) - 1
+    comm = HostMemComm(rank, world, name, n * 64 * 4)
+    par = A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD, grad_step=1.0)
+    if kind == "hier":
+        small = A.KGraph(g0["s_indptr"], g0["s_nbr"], g0["s_dist"])
+        e = A.Embedder.from_hkgraph(A.KGraphProjection(small, g, g0["proj_node"], g0["proj_dist"]), par)
+    else:
+        e = A.Embedder(g, par)
+    e.set_comm(comm, 2)
+    bad = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2))  # AE_CE_AUTO: a multi-GPU embedding must ask for the rounds mode by name
+    bad.set_comm(comm, 1)
+    try:
+        bad.embed()
+        raise SystemExit("AE_CE_AUTO with a communicator did not fail")
+    except A.AnnembedError as err:
+        assert err.code == 1, err
+    assert e.embed() == 1
+    np.save(os.path.join(out_dir, "y_%s_rank%d.npy" % (kind, rank)), e.get_embedded())
+    np.save(os.path.join(out_dir, "y0_%s_rank%d.npy" % (kind, rank)), e.get_initial_embedding())
+    np.save(os.path.join(out_dir, "ce_%s_rank%d.npy" % (kind, rank)), np.array(e.get_cross_entropy()))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -314,6 +314,34 @@ def test_sequential_bit_exact_at_full_c2_size(A, oracle):
     assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
 
 
+@pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])
+def test_full_schedule_bit_exact_vs_oracle_at_config_size(A, oracle, k, nb_batch):
+    """One FULL CE schedule per small config against the oracle's sequential loop, bit for bit: configs[0] (MNIST-digits shape:
+    60 000 points, k = 6, 30 batches of 3.6 M samples, examples/mnist_digits.rs:92-109) and configs[1] (MNIST-fashion shape:
+    k = 12, 25 batches of 7.2 M samples, examples/mnist_fashion.rs:92-110), from the same initial embedding, through
+    ae_entropy_optimize in the default mode (AE_CE_AUTO -> the sequential-equivalent dataflow).  ~20 / 35 s of oracle time."""
+    import torch
+    import bench
+    n = 60000
+    x = bench.synth_points(n, 784, seed=1)
+    nb_t, ds_t = bench.knn_rows(x, 0, n, k)
+    del x
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    nbr, dist = nb_t.cpu().numpy().astype(np.uint32).reshape(-1), ds_t.cpu().numpy().reshape(-1)
+    del nb_t, ds_t
+    torch.cuda.empty_cache()
+    g = A.KGraph(indptr, nbr, dist, k)
+    rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
+    assert rc == 0
+    y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
+    par = A.EmbedderParams(nb_grad_batch=nb_batch, grad_step=1.0)
+    assert A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), par, y0).get_ce_mode() == A.AE_CE_SEQUENTIAL
+    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), par, y0)
+    yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb_batch, grad_step=1.0)
+    assert np.array_equal(y, yo)
+    assert abs(ce0 - oce0) < 1e-11 * oce0 and abs(ce1 - oce1) < 1e-11 * oce1
+
+
 def _edge_len(indptr, nbr, y):
     src = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr.astype(np.int64)))
     return np.linalg.norm(y[src] - y[nbr], axis=1)
@@ -1139,3 +1167,52 @@ def test_sharded_ce_hip_backend_two_ranks_one_gpu(A, oracle, graph, tmp_path):
     yo, _, oce = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb_batch, grad_step=1.0)
     ce = float(np.load(tmp_path / "ce.npy"))
     assert 0.6 * oce < ce < 1.15 * oce, (ce, oce)  # measured 0.69-0.90 over runs (six batches of the approximate mode from a random start)
+
+
+@pytest.mark.parametrize("kind", ["flat", "hier"])
+def test_embedder_multi_gpu_entry_two_ranks_one_gpu(A, graph, tmp_path, kind):
+    """The multi-GPU embedding at the boundary the reference's callers use (Embedder::embed / from_hkgraph, embedder.rs:183-371;
+    ae_embedder_set_comm): two processes on this box's one GPU, the library's communicator over shared memory (RCCL refuses
+    two ranks on one device).  Both ranks hold bit-identical initial and final embeddings (rank 0's initialisation is broadcast;
+    every batch ends with an exchange), the reported cross entropies are sums over the ranks, and the result is within the
+    rounds mode's documented distance of the un-sharded run of the same mode."""
+    import subprocess
+    import sys
+    indptr, nbr, dist, x = graph
+    n = len(indptr) - 1
+    extra = {}
+    if kind == "hier":
+        ns = n // 8
+        si, sn, sd = knn_graph(x[:ns], 8)
+        x64 = x.astype(np.float64)
+        dd = (x64 ** 2).sum(1)[:, None] + (x64[:ns] ** 2).sum(1)[None, :] - 2 * x64 @ x64[:ns].T
+        pn, pd = dd.argmin(1).astype(np.uint32), np.sqrt(np.maximum(dd.min(1), 0)).astype(np.float32)
+        pn[:ns] = np.arange(ns)
+        pd[:ns] = 0
+        extra = dict(s_indptr=si, s_nbr=sn, s_dist=sd, proj_node=pn, proj_dist=pd)
+    np.savez(tmp_path / "graph.npz", indptr=indptr, nbr=nbr, dist=dist, **extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "annembed_test_%d_%s" % (os.getpid(), kind)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "embedder_shm_worker.py"), str(tmp_path), str(r), "2", name, kind],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-3000:])
+    ya, yb = np.load(tmp_path / ("y_%s_rank0.npy" % kind)), np.load(tmp_path / ("y_%s_rank1.npy" % kind))
+    ia, ib = np.load(tmp_path / ("y0_%s_rank0.npy" % kind)), np.load(tmp_path / ("y0_%s_rank1.npy" % kind))
+    ca, cb = np.load(tmp_path / ("ce_%s_rank0.npy" % kind)), np.load(tmp_path / ("ce_%s_rank1.npy" % kind))
+    assert np.array_equal(ia, ib) and np.array_equal(ya, yb) and np.isfinite(ya).all() and ya.shape == (n, 2)
+    assert np.array_equal(ca, cb)  # the sums run in rank order on every rank
+    # the same embedding un-sharded, same mode: the sharded run lands within the rounds mode's own envelope of it
+    g = A.KGraph(indptr, nbr, dist)
+    par = A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD, grad_step=1.0)
+    if kind == "hier":
+        e = A.Embedder.from_hkgraph(A.KGraphProjection(A.KGraph(extra["s_indptr"], extra["s_nbr"], extra["s_dist"]), g, extra["proj_node"], extra["proj_dist"]), par)
+    else:
+        e = A.Embedder(g, par)
+    assert e.embed() == 1
+    ce1 = e.get_cross_entropy()
+    # CE of the initial embedding: flat = the same dmap initialisation up to its run-to-run rounding; hierarchical = a projection of the
+    # first stage's result, itself a (sharded) stochastic optimisation
+    assert abs(ca[0] - ce1[0]) < (2e-3 if kind == "flat" else 0.05) * ce1[0], (ca, ce1)
+    assert 0.7 * ce1[1] < ca[1] < 1.3 * ce1[1], (ca, ce1)
