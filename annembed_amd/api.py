@@ -317,6 +317,12 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_get_ce_mode(self._h, C.byref(v)))
         return v.value
 
+    def slice_info(self):
+        """AE_CE_SLICED: (colour classes run as matchings, overflow share of the probability mass, colouring rounds, slices of the last batch)"""
+        a, b, c, d = C.c_uint32(), C.c_double(), C.c_uint32(), C.c_uint32()
+        check(L.load().ae_entropy_optim_slice_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
+
     def ce_compute_threaded(self):
         v = C.c_double()
         check(L.load().ae_entropy_optim_ce(self._h, C.byref(v)))

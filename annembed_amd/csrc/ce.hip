@@ -362,13 +362,18 @@ __global__ void df_pred_reads_kernel(uint64_t S, const uint32_t* __restrict__ pl
 // A version row is published by its stores alone: the buffer is filled with an all-ones pattern (a NaN no arithmetic
 // produces: hardware NaNs are the canonical 0x7FC00000) before the kernel, a reader polls the row itself and takes it
 // once every part differs from the pattern -- one memory round trip per dependency hop instead of flag + data.
-template <int DIM>
+// RELAXED (AE_CE_ORDERED): only the two END POINTS of a sample are dependencies -- the attraction is applied to the rows the previous
+// writers of i and j published, exactly as in the sequential order -- while the five negatives are read as the memory system has
+// them: every sample also stores its new rows IN PLACE (write-through), and a negative is one coherent load of that array, never a
+// wait.  That is what the reference's own threaded loop guarantees (rows under a lock for the update, negatives through try_read,
+// embedder.rs:1257-1265); the dependency depth of a C2 batch drops from 4 305 levels to 1 565 (tools/dependency_depth.py).
+template <int DIM, bool RELAXED>
 __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
                                                           const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
                                                           float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err, uint32_t lane_stride) {
     // rows of more than 16 columns (asked_dim 17 ... 64): only the two end points are held in registers, a negative's row is
     // taken when its repulsion is due (7 x 64 registers do not exist); same arithmetic, same order
-    constexpr bool WIDE = DIM > 16;
+    constexpr bool WIDE = DIM > 16 || RELAXED;
     constexpr int NR = WIDE ? 2 : 7;
     // only every lane_stride-th lane carries samples: a wave's trip through the loop below costs the poll round trip plus
     // the arithmetic of whichever lanes advance, and a blocked lane moves once per trip -- fewer passengers, shorter trips
@@ -388,10 +393,14 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
 #pragma unroll
             for (int t = 0; t < 7; t++) {
                 node[t] = plan_nodes[s * 7 + t];
-                pr[t] = pred[s * 7 + t];
+                pr[t] = (RELAXED && t >= 2) ? kNoPred : pred[s * 7 + t];
                 if (t < NR) {
-                    if (pr[t] == kNoPred) load_row<DIM>(c.y, node[t], rows[t]);  // the batch's initial row: c.y is read-only here
-                    else pending |= 1u << t;
+                    if (pr[t] == kNoPred) {  // the batch's initial row (exact mode: c.y is read-only here; relaxed: nobody has written this row yet)
+                        if constexpr (RELAXED) load_row_coherent<DIM>(c.y, node[t], rows[t]);
+                        else load_row<DIM>(c.y, node[t], rows[t]);
+                    } else {
+                        pending |= 1u << t;
+                    }
                 }
             }
             w = plan_w[s];
@@ -402,6 +411,7 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
         uint32_t polls = 0;
         int stage = 0;  // 0: attraction pending; 1..5: repulsion `stage` pending; 6: done
         float grad[DIM];
+        float negs[(RELAXED && DIM <= 16) ? 5 : 1][DIM];  // relaxed form: the negatives' rows as of the current trip
         double scale = 1.;
         if (!finished) scale = (double)c.emb_scale[node[0]];
         while (!__all(finished)) {
@@ -417,8 +427,15 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                         }
                     }
                 }
+                if constexpr (RELAXED && DIM <= 16) {
+                    // the negatives as the memory system has them NOW, re-read on every trip of a waiting sample (they travel with the
+                    // polls: no round trip of their own): when the end points arrive the whole sample completes in that trip
+#pragma unroll
+                    for (int g = 0; g < 5; g++) load_row_coherent<DIM>(c.y, node[2 + g], negs[g]);
+                }
                 if (stage == 0 && (pending & 3u) == 0u) {
                     sample_attract<DIM>(rows[0], rows[1], grad, w, scale, c.b, grad_step);
+                    if constexpr (RELAXED) df_store_version<DIM>(c.y, node[1], rows[1]);  // in place, for the negatives of others (:1239)
                     df_store_version<DIM>(ver, s * 2 + 1, rows[1]);
                     stage = 1;
                 }
@@ -436,19 +453,27 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                         sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
                         stage++;
                     }
+                } else if constexpr (RELAXED && DIM <= 16) {
+                    if (stage == 1) {  // (the negatives were read in this very trip, next to the polls: see below)
+#pragma unroll
+                        for (int g = 0; g < 5; g++) sample_repulse<DIM>(rows[0], negs[g], grad, scale, c.b, grad_step);
+                        stage = 6;
+                    }
                 } else {
                     while (stage >= 1 && stage <= 5) {
                         uint32_t nk = node[2], pk = pr[2];
 #pragma unroll
                         for (int g = 2; g <= 5; g++) { nk = stage == g ? node[1 + g] : nk; pk = stage == g ? pr[1 + g] : pk; }
                         float yk[DIM];
-                        if (pk == kNoPred) load_row<DIM>(c.y, nk, yk);
+                        if constexpr (RELAXED) load_row_coherent<DIM>(c.y, nk, yk);  // as the memory system has it now
+                        else if (pk == kNoPred) load_row<DIM>(c.y, nk, yk);
                         else if (!df_try_load_version<DIM>(ver, pk, yk)) break;  // not published yet: next trip
                         sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
                         stage++;
                     }
                 }
                 if (stage == 6) {
+                    if constexpr (RELAXED) df_store_version<DIM>(c.y, node[0], rows[0]);  // :1301
                     df_store_version<DIM>(ver, s * 2, rows[0]);
                     finished = true;
                 } else if (++polls > (1u << 24)) {  // cannot happen (see above): fail instead of hanging
@@ -588,8 +613,8 @@ static void check_err_flag(ae_entropy_optim* o) {
     if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
 }
 
-template <int DIM>
-static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
+template <int DIM, bool RELAXED>
+static void launch_dataflow2(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
     {
         static int blocks_per_cu = 0, cus = 0;
         if (!blocks_per_cu) {
@@ -601,7 +626,7 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
         }
         const unsigned bs = debug_knob("AE_DF_BLOCK") ? (unsigned)atoi(debug_knob("AE_DF_BLOCK")) : 128u;
         int bpc = 0;
-        AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM>, (int)bs, 0));
+        AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM, RELAXED>, (int)bs, 0));
         // The progress argument needs EVERY block resident (a sample of sweep k + 1 in block 0 may wait on a sample of sweep k
         // in the last block).  The occupancy query can be one block per CU higher than what the hardware admits (SGPR
         // granularity, MI355X_MICROARCH.md "Residency"): the grid is capped one full block per CU below it.
@@ -643,7 +668,7 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
         (void)args;
-        hipLaunchKernelGGL((ce_dataflow_kernel<DIM>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, lane_stride);
+        hipLaunchKernelGGL((ce_dataflow_kernel<DIM, RELAXED>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, lane_stride);
         AE_HIP(hipEventRecord(e1, stream()));
         o->df_events.emplace_back(e0, e1);
         hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
@@ -651,9 +676,15 @@ static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, ui
     }
 }
 
+template <int DIM>
+static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys, bool relaxed) {
+    if (relaxed) launch_dataflow2<DIM, true>(o, st, S, step, rowptr, keys);
+    else launch_dataflow2<DIM, false>(o, st, S, step, rowptr, keys);
+}
+
 // everything of a sequential batch that depends only on (graph, RNG stream, batch index): the plan of its samples, their write
 // events sorted by node, every read's predecessor.  Runs on whatever stream() is current.
-static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, uint32_t iter) {
+static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, uint32_t iter, bool relaxed) {
     if (st.plan_nodes.n < S * 7) st.plan_nodes.alloc(S * 7);
     if (st.plan_w.n < S) st.plan_w.alloc(S);
     if (st.pred.n < S * 7) st.pred.alloc(S * 7);
@@ -672,8 +703,9 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
                        (uint64_t)o->dev.n, st.rowptr.p);
     hipLaunchKernelGGL(df_pred_writes_kernel, dim3(grid_cap(2 * S, 256, 1u << 20)), dim3(256), 0, stream(), S, (const uint32_t*)k1, (const uint32_t*)v1,
                        st.pred.p);
-    hipLaunchKernelGGL(df_pred_reads_kernel, dim3(grid_cap(S * 5, 256, 1u << 22)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
-                       (const uint32_t*)v1, (const uint64_t*)st.rowptr.p, st.pred.p);
+    if (!relaxed)  // (the relaxed form never waits for a negative: no predecessor to find)
+        hipLaunchKernelGGL(df_pred_reads_kernel, dim3(grid_cap(S * 5, 256, 1u << 22)), dim3(256), 0, stream(), S, (const uint32_t*)st.plan_nodes.p,
+                           (const uint32_t*)v1, (const uint64_t*)st.rowptr.p, st.pred.p);
     check_launch("df_pred");
 }
 
@@ -681,7 +713,7 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
 // (Tried and dropped: preparing the set of batch b + 1 on a second stream while the dataflow kernel of batch b runs -- the
 // preparation depends only on graph, RNG stream and batch index.  The kernels do overlap, but the latency-bound dataflow slows
 // by what the overlap saves: C2 11.3 -> 11.5 ms per batch, C3 shape 68.6 -> 69.0 ms, dataflow kernel alone 14.9 -> 21.7 ms.)
-static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter) {
+static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter, bool relaxed) {
     if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
     const uint32_t dim = o->dev.dim;
     if (o->df_ver.n < S * 2 * dim) o->df_ver.alloc(S * 2 * dim);
@@ -689,10 +721,10 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
     auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     ae_entropy_optim::DfSet& st = o->df_set;
-    df_prepare_set(o, st, S, iter);
+    df_prepare_set(o, st, S, iter, relaxed);
     const double t1 = now();
     uint32_t* v1 = reinterpret_cast<uint32_t*>(st.keys1.p) + 2 * S;
-    AE_DISPATCH_DIM(dim, launch_dataflow, o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1);
+    AE_DISPATCH_DIM(dim, launch_dataflow, o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1, relaxed);
     check_launch("ce_dataflow");
     sync();
     if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan + sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
@@ -709,8 +741,9 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
 
 static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step, uint32_t iter) {
     // device-scheduled form; AE_CE_SEQ_LEVELS=1 (debug knob) keeps the host level schedule for A/B
-    if (!debug_knob("AE_CE_SEQ_LEVELS")) {
-        run_sequential_dataflow(o, nb_sample, step, iter);
+    const bool relaxed = o->params.ce_mode == AE_CE_ORDERED;
+    if (relaxed || !debug_knob("AE_CE_SEQ_LEVELS")) {
+        run_sequential_dataflow(o, nb_sample, step, iter, relaxed);
         return;
     }
     if (nb_sample >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^32 samples per batch");
@@ -778,23 +811,24 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 
 
 
-// AE_CE_AUTO never resolves to a mode whose output is not the reference's: the sequential-equivalent dataflow (exact,
-// reproducible) for batches up to kAutoSequentialSamples samples -- there it is also the fastest faithful mode --, beyond that
-// the time-sliced mode on conflict-free matchings (statistical parity, throughput-bound, a tenth of the memory).  Every
-// asked_dim in [1, 64] has both (rows are stored zero-padded, ce_internal.h).  A sharded node range has no faithful schedule:
-// AUTO refuses it -- the caller asks for the approximate rounds mode (AE_CE_HOGWILD) by name.
-constexpr uint64_t kAutoSequentialSamples = 1ull << 25;
+// AE_CE_AUTO resolves to the fastest mode whose output is the reference's: for batches of up to kAutoOrderedSamples
+// samples the ordered dataflow (AE_CE_ORDERED: the sequential order, end points sequentially consistent, negatives as the memory
+// system has them -- half the latency of the bit-exact AE_CE_SEQUENTIAL, which stays the parity mode, by name), beyond that the
+// time-sliced mode (throughput-bound, a tenth of the memory; measured cross-over ~30 M samples per batch).  Every asked_dim in
+// [1, 64] has both (rows are stored zero-padded, ce_internal.h).  A sharded node range has no faithful schedule: AUTO refuses it
+// -- the caller asks for the approximate rounds mode (AE_CE_HOGWILD) by name.
+constexpr uint64_t kAutoOrderedSamples = 1ull << 25;
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
     (void)dim;
-    if (mode > AE_CE_SLICED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
+    if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;
     if (sharded)
         fail(AE_ERR_INVALID_ARG, "AE_CE_AUTO does not shard: no schedule over several devices reproduces the reference's loop "
                                  "(DESIGN 5); ask for the approximate rounds mode by name (ce_mode = AE_CE_HOGWILD) or run the whole graph on one device");
     const bool sliced_ok = max_nbng <= 32 && nnz < 0xFFFFFFFFull;
-    if (samples_per_batch <= kAutoSequentialSamples || !sliced_ok) {
+    if (samples_per_batch <= kAutoOrderedSamples || !sliced_ok) {
         if (samples_per_batch >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "no faithful CE mode fits: rows of more than 32 neighbours or >= 2^32 edges with >= 2^31 samples per batch");
-        return AE_CE_SEQUENTIAL;
+        return AE_CE_ORDERED;
     }
     return AE_CE_SLICED;
 }
@@ -929,6 +963,18 @@ int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim* o, uint32_t* ce_mod
     });
 }
 
+int32_t ae_entropy_optim_slice_info(const ae_entropy_optim* o, uint32_t* classes, double* overflow_fraction, uint32_t* colouring_rounds,
+                                    uint32_t* slices_last_batch) {
+    return guard([&] {
+        if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (o->params.ce_mode != AE_CE_SLICED) fail(AE_ERR_STATE, "the handle does not run AE_CE_SLICED");
+        if (classes) *classes = o->sl_classes;
+        if (overflow_fraction) *overflow_fraction = o->sl_ov_frac;
+        if (colouring_rounds) *colouring_rounds = o->sl_color_rounds;
+        if (slices_last_batch) *slices_last_batch = o->rounds;
+    });
+}
+
 int32_t ae_entropy_optim_ce(ae_entropy_optim* o, double* ce) {
     return guard([&] {
         require_device();
@@ -954,7 +1000,7 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
             if (const char* why = ce_slice_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: %s", why);
         } else if (o->params.ce_mode == AE_CE_EVENT) {
             if (const char* why = ce_event_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_EVENT: %s; use AE_CE_SEQUENTIAL or AE_CE_HOGWILD", why);
-        } else if (o->params.ce_mode != AE_CE_SAMPLE_RACY && o->params.ce_mode != AE_CE_SEQUENTIAL && !ce_node_supports(o)) {
+        } else if (o->params.ce_mode != AE_CE_SAMPLE_RACY && o->params.ce_mode != AE_CE_SEQUENTIAL && o->params.ce_mode != AE_CE_ORDERED && !ce_node_supports(o)) {
             fail(AE_ERR_INVALID_ARG, "AE_CE_HOGWILD needs asked_dim <= 32 and rows of <= 32 neighbours (longer rows: asked_dim in {2,3,4,8,16}); use AE_CE_SEQUENTIAL");
         }
         // one event pair per timed batch, created after validation; ae_entropy_optim_kernel_time drains the list -- a caller that
@@ -974,7 +1020,7 @@ int32_t ae_entropy_optim_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sam
         AE_HIP(hipEventCreate(&e0));
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
-        if (o->params.ce_mode == AE_CE_SEQUENTIAL) {
+        if (o->params.ce_mode == AE_CE_SEQUENTIAL || o->params.ce_mode == AE_CE_ORDERED) {
             run_sequential(o, nb_sample, grad_step, (uint32_t)iter);
             AE_HIP(hipEventRecord(e1, stream()));
             o->events.emplace_back(e0, e1);

@@ -912,11 +912,12 @@ static void slice_color_edges(ae_entropy_optim* o) {
     std::vector<double> hm = mass.to_host();
     double total = 0.;
     for (double v : hm) total += v;
-    // How many classes run as matchings.  A step is a launch: it costs ~8 us of latency whatever it holds, and an event in it ~0.1 ns
-    // (5.6 random requests at the ~55 G requests/s the memory system serves); an event of the overflow class costs ~0.26 ns (two
-    // owner marks, two checks, a pending-list trip and ~1.4 attempts) and the class two to four launches per slice.  The cut that
-    // minimises the batch time -- 0 = everything optimistic (graphs of a few million edges: their steps would hold a few thousand
-    // events), all classes = no overflow (large regular graphs); measured on MI355X, DESIGN 4.3b.
+    // How many classes run as matchings.  A step is a launch: it costs ~9 us of latency whatever it holds, and an event in it
+    // 0.14 ns (rows of <= 8 columns: ~5.6 random requests at the ~55 G requests/s the memory system serves) to 0.24 ns (wider
+    // rows: one wave per SIMD); an event of the overflow class costs 0.24 - 0.28 ns (two owner marks, two checks, a pending-list
+    // trip and ~1.4 attempts) and the class two to four launches per slice.  The cut that minimises the batch time -- 0 =
+    // everything optimistic (graphs of a few million edges: their steps would hold a few thousand events), all classes = no
+    // overflow (large regular graphs).  Constants measured on MI355X at the C3 / C4 / C5-shard shapes.
     uint32_t top = kMaxClasses;
     while (top > 0 && hm[top - 1] == 0.) top--;
     const double events = (double)o->params.nb_sampling_by_edge * (double)nnz;
@@ -929,7 +930,8 @@ static void slice_color_edges(ae_entropy_optim* o) {
             if (c < top) t += hm[c];
             const double frac = total > 0. ? t / total : 0.;
             const double launches = (double)c + (t > 0. ? (frac < 0.05 ? 2.0 : 4.0) : 0.0);
-            const double cost = slices * launches * 8e-6 + events * ((1.0 - frac) * 0.10e-9 + frac * 0.26e-9);
+            const double c_match = o->dev.dim <= 8 ? 0.14e-9 : 0.24e-9, c_opt = o->dev.dim <= 8 ? 0.24e-9 : 0.28e-9;
+            const double cost = slices * launches * 9e-6 + events * ((1.0 - frac) * c_match + frac * c_opt);
             if (cost < best) { best = cost; cut = c; tail = t; }
         }
     }

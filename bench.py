@@ -108,15 +108,20 @@ def edge_quartiles(indptr, nbr, y):
     return np.quantile(np.linalg.norm(y[src] - y[nbr], axis=1), [0.25, 0.5, 0.75])
 
 
-MODE_NAMES = {5: "time-sliced optimistic (AE_CE_SLICED)", 0: "rounds (AE_CE_HOGWILD)", 1: "sequential-equivalent dataflow (AE_CE_SEQUENTIAL), bit-exact vs the oracle", 2: "racy", 3: "event-ordered (AE_CE_EVENT)"}
-MODE_KERNEL = {0: "ce_round_node_kernel (one launch per round)", 1: "ce_dataflow_kernel (one cooperative launch per batch; the batch also holds the plan, sort and predecessor kernels)",
-               3: "ce_event_window_kernel (one launch per window)", 5: "sl_exec_kernel (3 passes per time slice; whole batch incl. event generation and sort)"}
+MODE_NAMES = {5: "time-sliced on conflict-free matchings (AE_CE_SLICED)", 0: "rounds (AE_CE_HOGWILD)", 1: "sequential-equivalent dataflow (AE_CE_SEQUENTIAL), bit-exact vs the oracle", 2: "racy", 3: "event-ordered (AE_CE_EVENT)",
+              6: "ordered dataflow (AE_CE_ORDERED): the sequential order, end points sequentially consistent, negatives as the memory system has them"}
+MODE_KERNEL = {0: "ce_round_node_kernel (one launch per round)",
+               1: "ce_dataflow_kernel (one persistent launch per batch, grid sized one workgroup per CU below the occupancy query; the batch also holds the plan, sort and predecessor kernels)",
+               3: "ce_event_window_kernel (one launch per window)",
+               6: "ce_dataflow_kernel<relaxed> (one persistent launch per batch; the batch also holds the plan, sort and predecessor kernels)",
+               5: "sl_direct_kernel (one launch per colour class and time slice) / sl_exec_kernel (optimistic passes of the overflow class); whole batch incl. event generation and sort"}
 
 
-def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo=0, hi=None, comm=None, exchanges=1, fence=None):
+def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo=0, hi=None, comm=None, exchanges=1, fence=None, hub=None):
     """`warmup` untimed + `steps` timed CE batches of one mode; returns timing and the per-launch roofline inputs"""
-    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=mode)
-    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi)
+    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=mode,
+                              hubness_weighting=hub is not None)
+    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi, hub_counts=hub)
     if comm is not None:
         comm.attach(eo, exchanges)
     nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
@@ -130,7 +135,7 @@ def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo
     sync()
     eo.kernel_time()
     resolved = eo.get_ce_mode()
-    if resolved == 1:
+    if resolved in (1, 6):
         eo.dataflow_time()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -140,9 +145,14 @@ def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = eo.kernel_time()
     rounds = int(eo.samples_drawn()[1]) if resolved in (0, 3) else 1
-    dominant_ms = eo.dataflow_time()[0] if resolved == 1 else None  # the dataflow kernel alone (the batch also plans, sorts, searches)
+    sliced = None
+    if resolved == 5:
+        cl, ovf, crounds, slices = eo.slice_info()
+        sliced = {"matching_classes": cl, "overflow_mass_fraction": ovf, "colouring_rounds": crounds, "slices_per_batch": slices,
+                  "step_launches_per_batch": slices * cl}
+    dominant_ms = eo.dataflow_time()[0] if resolved in (1, 6) else None  # the dataflow kernel alone (the batch also plans, sorts, searches)
     return dict(eo=eo, elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, kernel_ms=kernel_ms, batches_timed=int(launches), rounds=rounds,
-                mode=resolved, nb_sample=nb_sample, ce_before=ce_before, ce_after=eo.ce_compute_threaded(), dominant_ms=dominant_ms)
+                mode=resolved, nb_sample=nb_sample, ce_before=ce_before, ce_after=eo.ce_compute_threaded(), dominant_ms=dominant_ms, sliced=sliced)
 
 
 def roofline_of(run, k, d):
@@ -156,7 +166,10 @@ def roofline_of(run, k, d):
     bytes_per_launch = bytes_per_sample * run["nb_sample"] / lpb
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     whole = bytes_per_sample * run["nb_sample"] / (run["ms_per_step"] * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+    extra = {}
+    if run.get("sliced"):
+        extra["sliced"] = run["sliced"]
+    return {**extra, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
             "achieved_whole_batch": whole, "frac_whole_batch": whole / 8000.0,
             "kernel": MODE_KERNEL.get(run["mode"], "?"), "launches_per_batch": lpb, "launch_avg_ms": launch_ms, "batch_kernel_ms": kernel_ms,
             "batches_timed": run["batches_timed"], "bytes_per_sample": bytes_per_sample, "bytes_per_launch": bytes_per_launch}
@@ -168,32 +181,56 @@ def full_schedule(A, kg, node_params, y0, d, mode, nb_batch=25):
     return y, ce
 
 
-def scale_shape(A, L, name, n, k, d, steps, with_sequential):
-    """configs[2] / configs[3] shapes on one GPU, on the node-permuted lattice graph: the rounds mode (and the sequential mode
-    where it is affordable); the default mode resolves to the sequential mode at these sizes (more nodes than resident lanes)"""
+def higgs_shaped_points(n, dim=28, ncomp=64, seed=2):
+    """configs[2] stand-in: mixture of 64 Gaussians in 28-D with per-column standardisation (examples/higgs.rs:158-176)"""
+    rng = np.random.default_rng(seed)
+    means = rng.normal(size=(ncomp, dim)) * 2.0
+    scales = 0.5 + rng.random((ncomp, dim))
+    lab = rng.integers(0, ncomp, n)
+    x = means[lab] + scales[lab] * rng.normal(size=(n, dim))
+    x = (x - x.mean(0)) / x.std(0)
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+def scale_shape(A, L, name, n, k, d, steps, with_sequential, knn_points=None):
+    """configs[2] / configs[3] shapes on one GPU.  Default: the node-permuted lattice graph (uniform in-degree).  knn_points: the
+    EXACT kNN graph of those points instead -- real in-degree skew (hubs), hubness-weighted negative sampling as examples/higgs.rs
+    switches it on (:204-242)."""
     import torch
-    indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)
-    kg = A.KGraph(indptr, nbr, dst, k)
+    hub = None
+    if knn_points is None:
+        indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)
+        kg = A.KGraph(indptr, nbr, dst, k)
+        graph = "ring lattice, node ids randomly permuted"
+    else:
+        t0 = time.perf_counter()
+        kg = A.KGraph.bruteforce_l2(knn_points, k)
+        knn_s = time.perf_counter() - t0
+        hub = kg.hubness()
+        graph = "exact kNN graph of %d Higgs-shaped points (28-D, 64 components), hubness-weighted negatives; max in-degree %d (mean %d); built in %.1f s" % (
+            n, int(hub.max()), k, knn_s)
     t0 = time.perf_counter()
     y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
     L.check(L.load().ae_synchronize())
     init_s = time.perf_counter() - t0
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
-    out = {"nodes": n, "k": k, "asked_dim": d, "graph": "ring lattice, node ids randomly permuted", "dmap_init_s": init_s}
+    out = {"nodes": n, "k": k, "asked_dim": d, "graph": graph, "dmap_init_s": init_s}
+    if hub is not None:
+        out["max_in_degree"] = int(hub.max())
     def entry(r, faithful):
         return {"faithful": faithful, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
                 "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "ce_after": r["ce_after"], "roofline": roofline_of(r, k, d)}
-    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, 2, 1)
+    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, 2, 1, hub=hub)
     r.pop("eo")
     out["rounds_mode"] = entry(r, False)
-    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SLICED, 2, 1)
+    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SLICED, 2, 1, hub=hub)
     r.pop("eo")
     out["sliced_mode"] = entry(r, "statistically")
-    auto = A.EntropyOptim(kg, node_params, A.EmbedderParams(asked_dim=d), y0)
+    auto = A.EntropyOptim(kg, node_params, A.EmbedderParams(asked_dim=d, hubness_weighting=hub is not None), y0, hub_counts=hub)
     out["default_mode_resolves_to"] = MODE_NAMES.get(auto.get_ce_mode())
     del auto
     if with_sequential:
-        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, 2, 1)
+        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, 2, 1, hub=hub)
         r.pop("eo")
         out["exact_mode"] = entry(r, True)
     out["note"] = "same number of batches from the same start in every mode: ce_after is comparable across the modes of a shape"
@@ -216,7 +253,7 @@ def main():
     ap.add_argument("--no-exact-mode", action="store_true")
     ap.add_argument("--no-fidelity", action="store_true")
     ap.add_argument("--no-scale-shapes", action="store_true")
-    ap.add_argument("--ce-mode", default="auto", choices=["auto", "event", "rounds", "sequential"], help="mode of the headline figure at N = 1")
+    ap.add_argument("--ce-mode", default="auto", choices=["auto", "event", "rounds", "sequential", "ordered"], help="mode of the headline figure at N = 1")
     ap.add_argument("--lattice-graph", action="store_true",
                     help="N = 1 scale runs: ring-lattice kNN graph (node ids permuted) with --points-per-gpu nodes instead of the MNIST-shaped points")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling on 60 k MNIST-shaped points per GPU (round-1 arrangement) instead of the strong-scaling configs[3] shape")
@@ -332,7 +369,7 @@ def main():
     y0 = A.set_data_box(y0, 10.0)
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
 
-    mode = {"auto": A.AE_CE_AUTO, "event": A.AE_CE_EVENT, "rounds": A.AE_CE_HOGWILD, "sequential": A.AE_CE_SEQUENTIAL}[args.ce_mode]
+    mode = {"auto": A.AE_CE_AUTO, "event": A.AE_CE_EVENT, "rounds": A.AE_CE_HOGWILD, "sequential": A.AE_CE_SEQUENTIAL, "ordered": A.AE_CE_ORDERED}[args.ce_mode]
     head = time_mode(A, L, kg, node_params, y0, d, mode, args.steps, args.warmup, fence=fence)
     head_eo = head.pop("eo")
     params = A.EmbedderParams(asked_dim=d, nb_grad_batch=25, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0)
@@ -363,7 +400,7 @@ def main():
         qs = edge_quartiles(indptr, nbr, ys)
         fidelity = {"schedule": "25 batches from the dmap initialisation, same graph and start", "reference": "AE_CE_SEQUENTIAL (bit-exact vs the oracle's sequential loop)",
                     "ce_sequential": ces, "edge_quartiles_sequential": qs.tolist()}
-        for name, m in (("event", A.AE_CE_EVENT), ("sliced", A.AE_CE_SLICED), ("rounds", A.AE_CE_HOGWILD)):
+        for name, m in (("ordered", A.AE_CE_ORDERED), ("event", A.AE_CE_EVENT), ("sliced", A.AE_CE_SLICED), ("rounds", A.AE_CE_HOGWILD)):
             ym, cem = full_schedule(A, kg, node_params, y0, d, m)
             qm = edge_quartiles(indptr, nbr, ym)
             fidelity[name] = {"ce/ce_seq": cem / ces, "q25_ratio": qm[0] / qs[0], "q50_ratio": qm[1] / qs[1], "q75_ratio": qm[2] / qs[2]}
@@ -383,15 +420,18 @@ def main():
         torch.cuda.empty_cache()
         scale_shapes = {
             "c3_shape": scale_shape(A, L, "c3", 1_650_000, 6, 2, 6, with_sequential=True),
+            # configs[2] again on a graph with REAL in-degree skew: exact kNN of the Higgs-shaped points, hubness weighting on
+            "c3_knn_shape": scale_shape(A, L, "c3knn", 1_650_000, 6, 2, 6, with_sequential=True, knn_points=higgs_shaped_points(1_650_000)),
             "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 4, with_sequential=True),
             # configs[4]: one GPU's eighth of the 50 M nodes as a graph of its own (k = 10, 16-D)
             "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 4, with_sequential=False),
         }
 
     roof = roofline_of(head, k, d)
-    if head["mode"] == 1:
-        roof["latency_bound_note"] = ("the batch is a dependency chain, not a stream: 4 305 levels deep on this graph (tools/dependency_depth.py), "
-                                      "%.2f us per level in this run; DESIGN.md 4.4" % (roof["launch_avg_ms"] * 1e3 / 4305.0))
+    if head["mode"] in (1, 6):
+        depth = 4305.0 if head["mode"] == 1 else 1565.0
+        roof["latency_bound_note"] = ("the batch is a dependency chain, not a stream: %d levels deep on this graph (tools/dependency_depth.py), "
+                                      "%.2f us per level in this run; DESIGN.md 4.4" % (depth, roof["launch_avg_ms"] * 1e3 / depth))
     replay = pmc_traffic(head["mode"])
     if replay:
         roof.update(replay)
@@ -404,9 +444,10 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",  # the --gpus N series is strong scaling of the configs[3] shape; its one-GPU point is scale_shapes.c4_shape (this line's value is configs[1])
         "vs_baseline": None,
-        "dtype": "f32 coordinates, f64 scalars" if head["mode"] in (1, 3) else "f32",
+        "dtype": "f32 coordinates, f64 scalars" if head["mode"] in (1, 3, 6) else "f32",
+        "cpu_baseline": cpu,
         "data": "synthetic",
         "config": {
             "workload": ("ring-lattice kNN graph (node ids permuted) %d nodes -> %dD, k=%d, dmap init + CE loop (scale run)" % (n, d, k))
@@ -427,8 +468,6 @@ def main():
         "samples_per_s": head["nb_sample"] / (head["ms_per_step"] * 1e-3),
         "ce_before": head["ce_before"], "ce_after": head["ce_after"],
     }
-    if cpu:
-        out["cpu_baseline"] = cpu
     print(json.dumps(out))
 
 
@@ -578,7 +617,7 @@ def pmc_traffic(mode):
     (profiles/<round>/pmc_ce_*.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes).
     Not a measurement of this run: reported under its own keys, `traffic` stays null."""
     import glob
-    name = {0: "pmc_ce_round.json", 1: "pmc_ce_dataflow.json", 3: "pmc_ce_event.json"}.get(mode)
+    name = {0: "pmc_ce_round.json", 1: "pmc_ce_dataflow.json", 3: "pmc_ce_event.json", 6: "pmc_ce_ordered.json"}.get(mode)
     if not name:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
@@ -612,8 +651,8 @@ def cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch):
     return {
         "value": n * batches / el, "unit": "points/s", "cores": int(cores), "kind": "port",
         "sample": "%d CE batches (%d SGD samples each) of the same graph, OpenMP Hogwild restatement of "
-                  "src/embedder.rs:1311-1315 on all host cores" % (batches, nb_sample),
-        "samples_per_s": nb_sample * batches / el,
+                  "src/embedder.rs:1311-1315 on all host cores (a cache line per row, dynamic chunks of 4096 samples)" % (batches, nb_sample),
+        "samples_per_s": nb_sample * batches / el, "samples_per_s_per_core": nb_sample * batches / el / max(1, int(cores)),
     }
 
 

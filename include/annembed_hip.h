@@ -114,12 +114,13 @@ enum {
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
     AE_CE_EVENT = 3,
-    /* Default: never a mode whose output is not the reference's.  AE_CE_SEQUENTIAL (exact and reproducible) for batches of up to
-       2^25 samples -- there it is also the fastest faithful mode --, AE_CE_SLICED beyond (statistical parity, throughput-bound, a
-       tenth of the memory).  Every asked_dim in [1, 64] has both: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or
-       64 columns (a zero column adds +0 to every distance and never moves).  A sharded node range (several GPUs) has no faithful
-       schedule: AE_CE_AUTO refuses it with AE_ERR_INVALID_ARG -- ask for AE_CE_HOGWILD by name.  ae_entropy_optim_get_ce_mode
-       reports the choice. */
+    /* Default: the fastest mode whose output is the reference's.  AE_CE_ORDERED for batches of up to 2^25 samples, AE_CE_SLICED
+       beyond (measured cross-over ~30 M samples per batch); both statistically faithful (as the reference's own threaded loop is
+       not reproducible sample by sample either) -- the bit-exact replay of the reference's sequential loop is AE_CE_SEQUENTIAL,
+       by name.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
+       column adds +0 to every distance and never moves).  A sharded node range (several GPUs) has no faithful schedule:
+       AE_CE_AUTO refuses it with AE_ERR_INVALID_ARG -- ask for AE_CE_HOGWILD by name.  ae_entropy_optim_get_ce_mode reports
+       the choice. */
     AE_CE_AUTO = 4,
     /* Time-sliced execution on conflict-free matchings (ce_slice.hip): the batch's events (the same edge-keyed Poisson process
        as AE_CE_EVENT) are cut into thin time slices; the graph's edges are coloured once (a proper edge colouring: every class is
@@ -128,7 +129,15 @@ enum {
        Edges without a colour (hubs) and, on graphs of a few million edges, all of them run optimistically instead: an event that
        holds both its rows exclusively runs, the others are deferred to the next pass.  Scalar arithmetic in f32.  Statistical
        parity like AE_CE_EVENT, throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes, one device. */
-    AE_CE_SLICED = 5
+    AE_CE_SLICED = 5,
+    /* The samples of AE_CE_SEQUENTIAL (same Philox plan, same order, same f64 arithmetic) with only their two END POINTS as
+       dependencies: every attraction is applied to the rows the previous writers of i and j produced, exactly as the sequential
+       loop does; the five negatives are read as the memory system has them (every sample also stores its rows in place) -- what the
+       reference's threaded loop guarantees (rows under a lock for the update, negatives through try_read, embedder.rs:1257-1265).
+       Not reproducible in the last bits of the negatives' contributions; statistical parity; about half the latency of
+       AE_CE_SEQUENTIAL on small graphs (a C2 batch is 1 565 dependency levels deep instead of 4 305).  Any asked_dim, one device,
+       < 2^31 samples per batch. */
+    AE_CE_ORDERED = 6
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
@@ -364,6 +373,11 @@ int32_t ae_entropy_optim_gradient_iteration_lockstep(ae_entropy_optim *const *sh
                                                      double grad_step, uint64_t iter, uint32_t exchanges_per_batch);
 /* the AE_CE_* mode the handle runs (AE_CE_AUTO resolved at create) */
 int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim *o, uint32_t *ce_mode);
+/* AE_CE_SLICED (no reference counterpart): how the graph's edges were scheduled -- the number of colour classes that run as
+   conflict-free matchings (0 = every event runs optimistically), the share of the edge probability mass in the overflow class, the
+   rounds the colouring took, and the time slices of the last batch.  AE_ERR_STATE for a handle in another mode. */
+int32_t ae_entropy_optim_slice_info(const ae_entropy_optim *o, uint32_t *classes, double *overflow_fraction,
+                                    uint32_t *colouring_rounds, uint32_t *slices_last_batch);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);
 /* gradient_iteration_threaded(nb_sample, grad_step) (embedder.rs:1311-1315).  `iter` keys the RNG

@@ -573,10 +573,10 @@ int orc_ce_plan(const orc_ce *c, uint64_t s, uint32_t iter, uint32_t *nodes7, fl
 
 #define ORC_MAXDIM 64
 /* ce_optim_edge_shannon, src/embedder.rs:1167-1302: one SGD sample applied to c->y */
-static void apply_sample(const orc_ce *c, const orc_plan *p, double grad_step) {
+static void apply_sample_at(const orc_ce *c, const orc_plan *p, double grad_step, float *y, uint64_t stride) {
     uint64_t dim = c->dim;
     float yi[ORC_MAXDIM], yj[ORC_MAXDIM], grad[ORC_MAXDIM];
-    float *Yi = c->y + (uint64_t)p->i * dim, *Yj = c->y + (uint64_t)p->j * dim;
+    float *Yi = y + (uint64_t)p->i * stride, *Yj = y + (uint64_t)p->j * stride;
     for (uint64_t t = 0; t < dim; t++) { yi[t] = Yi[t]; yj[t] = Yj[t]; grad[t] = 0.f; } /* :1185-1186,:1199 */
     double weight = (double)p->w;                  /* :1202 */
     double scale = (double)c->emb_scale[p->i];     /* :1204 */
@@ -603,7 +603,7 @@ static void apply_sample(const orc_ce *c, const orc_plan *p, double grad_step) {
     for (uint64_t t = 0; t < dim; t++) { yi[t] -= grad[t]; yj[t] += grad[t]; } /* :1237-1238 */
     for (uint64_t t = 0; t < dim; t++) Yj[t] = yj[t];                           /* :1239 */
     for (int g = 0; g < 5; g++) {                  /* :1244-1299 */
-        const float *Yk = c->y + (uint64_t)p->k[g] * dim;
+        const float *Yk = y + (uint64_t)p->k[g] * stride;
         float yk[ORC_MAXDIM];
         for (uint64_t t = 0; t < dim; t++) yk[t] = Yk[t];
         float ak = 0.f;
@@ -629,6 +629,7 @@ static void apply_sample(const orc_ce *c, const orc_plan *p, double grad_step) {
     }
     for (uint64_t t = 0; t < dim; t++) Yi[t] = yi[t]; /* :1301 */
 }
+static void apply_sample(const orc_ce *c, const orc_plan *p, double grad_step) { apply_sample_at(c, p, grad_step, c->y, c->dim); }
 
 /* gradient_iteration (sequential), src/embedder.rs:1305-1309: samples s = s_begin .. s_begin+nb_sample-1 */
 int orc_gradient_iteration(const orc_ce *c, uint64_t s_begin, uint64_t nb_sample, double grad_step, uint32_t iter) {
@@ -643,19 +644,28 @@ int orc_gradient_iteration(const orc_ce *c, uint64_t s_begin, uint64_t nb_sample
 
 /* gradient_iteration_threaded, src/embedder.rs:1311-1315: lock-free (Hogwild) over OpenMP threads.
  * Used as the CPU baseline.  The reference guards each row by an RwLock (:942) but releases it
- * between read and write-back (:1185-1186,:1239,:1301); the races are the same. */
+ * between read and write-back (:1185-1186,:1239,:1301); the races are the same.  Like the reference, whose rows are separate
+ * heap allocations (Arc<RwLock<Array1<F>>>, :994-998), every row sits on a cache line of its own during the run (rows packed
+ * 8 to a line make 128 threads fight over every line: measured 3.4x one thread); chunks of 4096 samples are handed out
+ * dynamically, as rayon's work stealing does. */
 int orc_gradient_iteration_hogwild(const orc_ce *c, uint64_t nb_sample, double grad_step, uint32_t iter, int nthreads) {
     if (c->dim > ORC_MAXDIM) return ORC_ERR_ARG;
     int err = 0;
+    const uint64_t stride = ((c->dim + 15) / 16) * 16; /* floats: multiples of 64 bytes */
+    float *pad = NULL;
+    if (posix_memalign((void **)&pad, 64, sizeof(float) * stride * c->n) != 0) return ORC_ERR_ARG;
+    for (uint64_t i = 0; i < c->n; i++) memcpy(pad + i * stride, c->y + i * c->dim, sizeof(float) * c->dim);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(static) reduction(| : err)
+#pragma omp parallel for schedule(dynamic, 4096) reduction(| : err)
 #endif
     for (int64_t s = 0; s < (int64_t)nb_sample; s++) {
         orc_plan p; int rc = sample_plan(c, (uint64_t)s, iter, &p);
         if (rc) { err |= rc; continue; }
-        apply_sample(c, &p, grad_step);
+        apply_sample_at(c, &p, grad_step, pad, stride);
     }
+    for (uint64_t i = 0; i < c->n; i++) memcpy(c->y + i * c->dim, pad + i * stride, sizeof(float) * c->dim);
+    free(pad);
     return err;
 }
 int orc_max_threads(void) {

@@ -319,7 +319,7 @@ def test_full_schedule_bit_exact_vs_oracle_at_config_size(A, oracle, k, nb_batch
     """One FULL CE schedule per small config against the oracle's sequential loop, bit for bit: configs[0] (MNIST-digits shape:
     60 000 points, k = 6, 30 batches of 3.6 M samples, examples/mnist_digits.rs:92-109) and configs[1] (MNIST-fashion shape:
     k = 12, 25 batches of 7.2 M samples, examples/mnist_fashion.rs:92-110), from the same initial embedding, through
-    ae_entropy_optimize in the default mode (AE_CE_AUTO -> the sequential-equivalent dataflow).  ~20 / 35 s of oracle time."""
+    ae_entropy_optimize in the parity mode (AE_CE_SEQUENTIAL: the sequential-equivalent dataflow).  ~20 / 35 s of oracle time."""
     import torch
     import bench
     n = 60000
@@ -334,8 +334,7 @@ def test_full_schedule_bit_exact_vs_oracle_at_config_size(A, oracle, k, nb_batch
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
     assert rc == 0
     y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
-    par = A.EmbedderParams(nb_grad_batch=nb_batch, grad_step=1.0)
-    assert A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), par, y0).get_ce_mode() == A.AE_CE_SEQUENTIAL
+    par = A.EmbedderParams(nb_grad_batch=nb_batch, grad_step=1.0, ce_mode=A.AE_CE_SEQUENTIAL)
     y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), par, y0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb_batch, grad_step=1.0)
     assert np.array_equal(y, yo)
@@ -350,8 +349,8 @@ def _edge_len(indptr, nbr, y):
 def test_event_mode_statistics_match_oracle(A, oracle):
     """The event-ordered mode (AE_CE_EVENT) is not reproducible sample by sample (neither is the reference's rayon loop); its
     statistics are the sequential loop's: final cross entropy within 3 % and edge-length quantiles within 5 % of the oracle's
-    sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n).  The default
-    (AE_CE_AUTO) resolves to the sequential mode and reproduces the oracle bit for bit.  Kept as evidence next to them: the
+    sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n), and so are the
+    default's (AE_CE_AUTO -> the ordered dataflow at this size).  AE_CE_SEQUENTIAL reproduces the oracle bit for bit.  Kept as evidence next to them: the
     rounds mode (AE_CE_HOGWILD, stale partner rows) and the literal racy per-sample transcription are NOT inside that
     envelope."""
     n = 20000
@@ -361,17 +360,19 @@ def test_event_mode_statistics_match_oracle(A, oracle):
     y0 = oracle.set_data_box(np.random.default_rng(0).normal(size=(n, 2)).astype(np.float32), 10.0)
     npar = A.NodeParams.from_host(g, p0, s0)
     eo = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
-    assert eo.get_ce_mode() == A.AE_CE_SEQUENTIAL
+    assert eo.get_ce_mode() == A.AE_CE_ORDERED
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 6)
-    yd, _, ced = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6), y0)
-    assert np.array_equal(yd, yo) and abs(ced - oce1) < 1e-11 * oce1  # the default: the oracle's run, bit for bit
-    y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_EVENT), y0)
-    assert abs(ce0 - oce0) < 1e-10 * oce0
-    assert np.isfinite(y).all()
-    assert abs(ce1 - oce1) < 0.03 * oce1, (ce1, oce1)
-    lg, lo = _edge_len(indptr, nbr, y), _edge_len(indptr, nbr, yo)
-    for q in (0.25, 0.5, 0.75, 0.95):
-        assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.05 * np.quantile(lo, q), q
+    yd, _, ced = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_SEQUENTIAL), y0)
+    assert np.array_equal(yd, yo) and abs(ced - oce1) < 1e-11 * oce1  # the parity mode: the oracle's run, bit for bit
+    lo = _edge_len(indptr, nbr, yo)
+    for mode in (A.AE_CE_EVENT, A.AE_CE_AUTO):
+        y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=mode), y0)
+        assert abs(ce0 - oce0) < 1e-10 * oce0
+        assert np.isfinite(y).all()
+        assert abs(ce1 - oce1) < 0.03 * oce1, (mode, ce1, oce1)
+        lg = _edge_len(indptr, nbr, y)
+        for q in (0.25, 0.5, 0.75, 0.95):
+            assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.05 * np.quantile(lo, q), (mode, q)
     # rounds mode: a throughput mode outside the envelope (documented) -- only sanity here
     yr, _, cer = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD), y0)
     assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1
@@ -385,18 +386,19 @@ def test_event_mode_statistics_match_oracle(A, oracle):
                                          (16, 16, False, 0.9), (15, 6, False, 1.0), (1, 6, False, 1.0), (33, 9, False, 1.0), (64, 6, True, 1.0)])
 def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     """Every asked_dim in [1, 64] and every row length (the reference is generic in the dimension and publishes 15-D runs,
-    embedder.rs:604-618).  The default mode resolves to the sequential mode whatever the dimension (rows are stored zero-padded to
-    2 / 3 / 4 / 8 / 16 / 32 / 64 columns; a zero column adds +0 to every distance and never moves): the oracle's run bit for bit
-    at b = 1, 1e-5 relative CE with the general exponent (whose pow() differs in the last bits).  The time-sliced kernel
-    (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours) and, up to 16 columns, the event-ordered one land
-    within 5 % (CE) / 8 % (edge-length median and q90) of it on these 4000-node graphs (the oracle's own seed spread here is ~3 %)."""
+    embedder.rs:604-618).  The sequential mode reproduces the oracle's run whatever the dimension (rows are stored zero-padded to
+    2 / 3 / 4 / 8 / 16 / 32 / 64 columns; a zero column adds +0 to every distance and never moves): bit for bit at b = 1, 1e-5
+    relative CE with the general exponent (whose pow() differs in the last bits).  The default (AE_CE_AUTO -> the ordered
+    dataflow at this size), the time-sliced kernel (hubness-weighted negatives, exponent b != 1, rows of up to 32 neighbours)
+    and, up to 16 columns, the event-ordered one land within 5 % (CE) / 8 % (edge-length median and q90) of it on these
+    4000-node graphs (the oracle's own seed spread here is ~3 %)."""
     n = 4000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=k, seed=11, ncomp=3)
     g = A.KGraph(indptr, nbr, dist)
     rc, p0, s0 = oracle.to_proba_edges(indptr, nbr, dist, 1.0, 1.0)
     y0 = oracle.set_data_box(np.random.default_rng(dim).normal(size=(n, dim)).astype(np.float32), 10.0)
     hubc = g.hubness() if hub else None
-    par = A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b)
+    par = A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b, ce_mode=A.AE_CE_SEQUENTIAL)
     eo = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), par, y0, hub_counts=hubc)
     nb_sample = 10 * len(nbr)
     for it in range(1, 6):
@@ -404,7 +406,6 @@ def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     y, ce1 = eo.get_embedded(), eo.ce_compute_threaded()
     yo, _, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5, hub_counts=hubc, b=b)
     assert np.isfinite(y).all() and y.shape == (n, dim)
-    assert eo.get_ce_mode() == A.AE_CE_SEQUENTIAL
     src = np.repeat(np.arange(n), k)
     lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
 
@@ -416,6 +417,13 @@ def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
     if b == 1.0:
         assert np.array_equal(y, yo)
     close(y, ce1, 1e-5, 1e-4)
+    # the default mode
+    au = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b), y0, hub_counts=hubc)
+    assert au.get_ce_mode() == A.AE_CE_ORDERED
+    for it in range(1, 6):
+        au.gradient_iteration_threaded(nb_sample, 2.0 * (1.0 - it / 5), it)
+    assert np.isfinite(au.get_embedded()).all() and au.get_embedded().shape == (n, dim)
+    close(au.get_embedded(), au.ce_compute_threaded(), 0.05, 0.08)
     if dim <= 16:
         ev = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=dim, nb_grad_batch=5, hubness_weighting=hub, b=b, ce_mode=A.AE_CE_EVENT),
                             y0, hub_counts=hubc)
@@ -433,9 +441,9 @@ def test_ce_any_dim_and_row_length(A, oracle, dim, k, hub, b):
 
 
 def test_converged_run_matches_reference_quality(A, oracle):
-    """Full schedule (dmap initialisation, 20 batches): the default mode's embedding against the oracle's sequential
-    run on the reference's own yardsticks -- final cross entropy and get_quality_estimate_from_edge_length
-    (embedder.rs:620-753); the event-ordered mode within 3-8 % on the same yardsticks."""
+    """Full schedule (dmap initialisation, 20 batches): the sequential mode IS the oracle's sequential run; the default mode
+    (AE_CE_AUTO -> the ordered dataflow) and the event-ordered mode against it on the reference's own yardsticks -- final cross
+    entropy and get_quality_estimate_from_edge_length (embedder.rs:620-753) -- within 3-8 %."""
     n, k, nb = 10000, 10, 20
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=10, k=k, seed=7, ncomp=8)
     g = A.KGraph(indptr, nbr, dist)
@@ -443,15 +451,17 @@ def test_converged_run_matches_reference_quality(A, oracle):
     rc, y0, _ = oracle.dmap_embed_from_kgraph(indptr, nbr, dist, k, oracle.DiffusionParams(2, 5.0, 12))
     y0 = oracle.set_data_box(y0, 10.0)
     yo, _, oce = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, nb)
-    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb), y0)
-    assert np.array_equal(yd, yo) and abs(ced - oce) < 1e-11 * oce  # default mode: the oracle's run
-    y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb, ce_mode=A.AE_CE_EVENT), y0)
-    assert abs(ce - oce) < 0.03 * oce, (ce, oce)
-    q, qo = A.quality_estimate_from_edge_length(g, y, 30), A.quality_estimate_from_edge_length(g, yo, 30)
-    assert abs(q.nb_without_match - qo.nb_without_match) < 0.08 * qo.nb_without_match  # (a count of ~10 % of the nodes: single runs scatter by 2-5 %)
-    assert abs(q.mean_nbmatch - qo.mean_nbmatch) < 0.05 * qo.mean_nbmatch
-    assert abs(q.median_ratio - qo.median_ratio) < 0.08 * qo.median_ratio
-    assert abs(q.radii_quantiles[2] - qo.radii_quantiles[2]) < 0.05 * qo.radii_quantiles[2]
+    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb, ce_mode=A.AE_CE_SEQUENTIAL), y0)
+    assert np.array_equal(yd, yo) and abs(ced - oce) < 1e-11 * oce  # the parity mode: the oracle's run
+    qo = A.quality_estimate_from_edge_length(g, yo, 30)
+    for mode in (A.AE_CE_EVENT, A.AE_CE_AUTO):
+        y, _, ce = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=nb, ce_mode=mode), y0)
+        assert abs(ce - oce) < 0.03 * oce, (mode, ce, oce)
+        q = A.quality_estimate_from_edge_length(g, y, 30)
+        assert abs(q.nb_without_match - qo.nb_without_match) < 0.08 * qo.nb_without_match  # (a count of ~10 % of the nodes: single runs scatter by 2-5 %)
+        assert abs(q.mean_nbmatch - qo.mean_nbmatch) < 0.05 * qo.mean_nbmatch
+        assert abs(q.median_ratio - qo.median_ratio) < 0.08 * qo.median_ratio
+        assert abs(q.radii_quantiles[2] - qo.radii_quantiles[2]) < 0.05 * qo.radii_quantiles[2]
 
 
 def test_hub_and_ragged_rows(A, oracle):
@@ -479,14 +489,16 @@ def test_hub_and_ragged_rows(A, oracle):
     assert rc == 0
     y0 = oracle.set_data_box(rng.normal(size=(n, 2)).astype(np.float32), 10.0)
     yo, oce0, oce1 = oracle.entropy_optimize(indptr, nbr, p0, s0, y0, 5)
-    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5), y0)
-    assert np.array_equal(yd, yo)  # default (sequential) mode: the oracle's run, hub or not
-    y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_EVENT), y0)
-    assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
-    assert abs(ce1 - oce1) < 0.05 * oce1, (ce1, oce1)
+    yd, _, ced = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_SEQUENTIAL), y0)
+    assert np.array_equal(yd, yo)  # sequential mode: the oracle's run, hub or not
     src = np.repeat(np.arange(n), np.diff(indptr.astype(np.int64)))
-    lg, lo = np.linalg.norm(y[src] - y[nbr], axis=1), np.linalg.norm(yo[src] - yo[nbr], axis=1)
-    assert abs(np.median(lg) - np.median(lo)) < 0.06 * np.median(lo)
+    lo = np.linalg.norm(yo[src] - yo[nbr], axis=1)
+    for mode in (A.AE_CE_EVENT, A.AE_CE_AUTO, A.AE_CE_SLICED):  # (the default resolves to the ordered dataflow here)
+        y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=mode), y0)
+        assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
+        assert abs(ce1 - oce1) < 0.05 * oce1, (mode, ce1, oce1)
+        lg = np.linalg.norm(y[src] - y[nbr], axis=1)
+        assert abs(np.median(lg) - np.median(lo)) < 0.06 * np.median(lo), mode
     # the rounds mode on the same graph (rounds sized by the largest in-weight: 176 here): measured 0.89x CE, median +3 %
     yr, _, cer = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0)
     assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1

@@ -98,7 +98,8 @@ def scale(n=1_650_000, k=6, d=2, steps=3, out_path=None):
                 ("match lambda 1", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=1)), ("match lambda 2", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=2)),
                 ("match lambda 4", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=4)),
                 ("match no tile", A.AE_CE_SLICED, dict(AE_SL_NO_TILE=1)), ("match tile always", A.AE_CE_SLICED, dict(AE_SL_TILE_ALWAYS=1, AE_SL_TILE_MIN=1)),
-                ("all-optimistic", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1)), ("rounds", A.AE_CE_HOGWILD, {})]
+                ("all-optimistic", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1)), ("rounds", A.AE_CE_HOGWILD, {}), ("ordered", A.AE_CE_ORDERED, {}),
+                ("sequential", A.AE_CE_SEQUENTIAL, {})]
     if os.environ.get("VARIANTS"):
         keep = os.environ["VARIANTS"].split(",")
         variants = [v for v in variants if v[0] in keep]
