@@ -446,30 +446,46 @@ struct TileShape {
 __device__ __forceinline__ uint32_t tile_window_start(uint32_t wkey, uint32_t w, uint32_t n) { return __umulhi(pcg_hash(wkey + w * 0x9E3779B9u), n); }
 
 // The tile's loads are ISSUED at the start of the kernel (next to the event load) and LANDED in LDS when the sample's own loads
-// are in flight: staging is off the critical path.
+// are in flight: staging is off the critical path.  Hubness-weighted sampling (NodeSampler, embedder.rs:915-930: what
+// examples/higgs.rs switches on) cannot use runs of consecutive rows: there every tile row is an independent draw of the alias
+// table (one 8-byte look-up, then the row) -- a slot picked uniformly afterwards is again a draw of the reference's law; two
+// requests per tile row instead of ten per sample.
 template <int DIM>
 struct TileFetch {
     using T = TileShape<DIM>;
     static constexpr int Q = DIM % 4 == 0 ? DIM / 4 : DIM;  // pieces per row
     f4 pc[T::kPieces];
-    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey) {
+    uint32_t node[T::kPieces];
+    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub) {
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
-            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = x / Q, q = x % Q;
-            uint32_t node = tile_window_start(wkey, r / T::kL, (uint32_t)c.n) + r % T::kL;
-            node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
-            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node * DIM + 4u * q);
-            else pc[z].x = c.y[(uint64_t)node * DIM + q];
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = x / Q;
+            if (hub) {
+                const uint32_t w0 = pcg_hash(wkey + r * 0x9E3779B9u);
+                const uint32_t xs = __umulhi(w0, (uint32_t)c.n);
+                const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                const uint2 he = c.hub_tab[xs];
+                node[z] = (uu < __uint_as_float(he.x)) ? xs : he.y;
+            } else {
+                node[z] = tile_window_start(wkey, r / T::kL, (uint32_t)c.n) + r % T::kL;
+                node[z] -= node[z] >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < T::kPieces; z++) {
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, q = x % Q;
+            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node[z] * DIM + 4u * q);
+            else pc[z].x = c.y[(uint64_t)node[z] * DIM + q];
         }
     }
-    __device__ __forceinline__ void land(const CeDev& c, uint32_t wkey, float* s_tile, uint32_t* s_wstart) {
+    __device__ __forceinline__ void land(float* s_tile, uint32_t* s_tnode) {
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
             const uint32_t x = (uint32_t)z * 256u + threadIdx.x;
             if constexpr (DIM % 4 == 0) *reinterpret_cast<f4*>(s_tile + 4u * x) = pc[z];
             else s_tile[x] = pc[z].x;
+            if (x % Q == 0) s_tnode[x / Q] = node[z];
         }
-        if (threadIdx.x < T::kW) s_wstart[threadIdx.x] = tile_window_start(wkey, threadIdx.x, (uint32_t)c.n);
         __syncthreads();
     }
 };
@@ -479,7 +495,7 @@ struct TileFetch {
 // receives the slots; otherwise node ids (uniform, or hubness-weighted through the alias table), eight candidates at a time so that
 // the alias look-ups overlap.  Returns the number accepted (5 unless the graph is tiny).
 template <int DIM, int KMAX, bool TILE>
-__device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, const uint32_t* s_wstart, uint32_t nb, uint32_t i,
+__device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, const uint32_t* s_tnode, uint32_t nb, uint32_t i,
                                                    const uint32_t (&nbr_reg)[KMAX], uint32_t (&out)[5]) {
     using T = TileShape<DIM>;
     uint32_t got = 0;
@@ -491,9 +507,7 @@ __device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, con
 #pragma unroll
             for (int z = 0; z < 8; z++) {
                 const uint32_t row = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u) >> (32 - T::kRowBits);
-                uint32_t node = s_wstart[row / T::kL] + row % T::kL;
-                node -= node >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
-                cand[z] = node;
+                cand[z] = s_tnode[row];
                 slot[z] = row;
             }
         } else if (hub) {
@@ -626,7 +640,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
     constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
     __shared__ __attribute__((aligned(16))) float s_tile[TILE ? T::kRows * DIM : 4];
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kStageFloats<DIM, SREC>];
-    __shared__ uint32_t s_wstart[T::kW];
+    __shared__ uint32_t s_tnode[TILE ? T::kRows : 1];
     const CeDev c = a.c;
     const bool hub = c.hub_odds != nullptr;
     float* stage = s_stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
@@ -647,7 +661,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
             if (p + 1 < a.end) next_im = a.ev[p + 1].im;
         }
         TileFetch<DIM> ft;
-        if constexpr (TILE) { if (r == 0) ft.issue(c, wkey); }
+        if constexpr (TILE) { if (r == 0) ft.issue(c, wkey, hub); }
         uint32_t run = 1;
         if (act && prev_im == e.im) act = false;  // a repeat of the previous event's edge: its first lane runs the whole run
         else if (act && next_im == e.im) { run = 2; while (p + run < a.end && a.ev[p + run].im == e.im) run++; }
@@ -661,7 +675,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
         fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
         fi.issue(c.y, i, act, yi);     // :1185
         fj.issue(c.y, e.j, act, yj);   // :1186
-        if constexpr (TILE) { if (r == 0) ft.land(c, wkey, s_tile, s_wstart); }
+        if constexpr (TILE) { if (r == 0) ft.land(s_tile, s_tnode); }
         fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
         fi.land(stage, yi);
         fj.land(stage, yj);
@@ -669,7 +683,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
         if (act) {
             for (uint32_t q = 0; q < run; q++) {
                 uint32_t neg[5];
-                uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_wstart, pcg_hash(nkey + (p + q)), i, nbr_reg, neg);
+                uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, neg);
                 if (a.dbg & 4) { got = 0; for (int g = 0; g < 5; g++) neg[g] = TILE ? 0u : i; }
                 if (!(a.dbg & 1)) run_sample<DIM, F64, TILE>(c, s_tile, yi, yj, w, scale_f, a.step, neg, got);
                 else if (got == 77u) yi[0] += (float)neg[0];
@@ -728,7 +742,7 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
     constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
     __shared__ __attribute__((aligned(16))) float s_tile[TILE ? T::kRows * DIM : 4];
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kStageFloats<DIM, SREC>];
-    __shared__ uint32_t s_wstart[T::kW];
+    __shared__ uint32_t s_tnode[TILE ? T::kRows : 1];
     __shared__ uint32_t s_wave_cnt[4], s_base;
     const CeDev c = a.c;
     const uint32_t sub = blockIdx.y, dsub = (blockIdx.x + blockIdx.y) % (uint32_t)kSub;
@@ -741,8 +755,8 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
     const uint32_t wkey = pcg_hash(nkey + a.pass_seq * 0x9E3779B9u) + (blockIdx.x * (uint32_t)kSub + sub) * 64u;
     if constexpr (TILE) {
         TileFetch<DIM> ft;
-        ft.issue(c, wkey);
-        ft.land(c, wkey, s_tile, s_wstart);
+        ft.issue(c, wkey, hub);
+        ft.land(s_tile, s_tnode);
     }
     float* stage = s_stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
     unsigned long long done = 0;
@@ -771,7 +785,7 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         fj.land(stage, yj);
         if (win) {
             uint32_t neg[5];
-            const uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_wstart, pcg_hash(nkey + idx), i, nbr_reg, neg);
+            const uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_tnode, pcg_hash(nkey + idx), i, nbr_reg, neg);
             run_sample<DIM, F64, TILE>(c, s_tile, yi, yj, w, scale_f, a.step, neg, got);
             done++;
         }
@@ -819,7 +833,7 @@ void launch_exec3(const SliceArgs& a, unsigned grid, uint32_t srec) {
 }
 template <int DIM>
 void launch_exec(const SliceArgs& a, unsigned grid, uint32_t srec, bool f64) {
-    const bool tile = a.tile && !a.c.hub_odds && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    const bool tile = a.tile && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
     if (f64) { if (tile) launch_exec3<DIM, true, true>(a, grid, srec); else launch_exec3<DIM, true, false>(a, grid, srec); }
     else { if (tile) launch_exec3<DIM, false, true>(a, grid, srec); else launch_exec3<DIM, false, false>(a, grid, srec); }
 }
@@ -833,7 +847,7 @@ void launch_direct3(const DirectArgs& a, uint32_t srec) {
 }
 template <int DIM>
 void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
-    const bool tile = a.tile && !a.c.hub_odds && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    const bool tile = a.tile && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
     if (f64) { if (tile) launch_direct3<DIM, true, true>(a, srec); else launch_direct3<DIM, true, false>(a, srec); }
     else { if (tile) launch_direct3<DIM, false, true>(a, srec); else launch_direct3<DIM, false, false>(a, srec); }
 }
@@ -1121,7 +1135,33 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, grid, o->sl_srec_floats, f64);
                 cur = (cur + 1) % 3;
             }
-            // the next slice's mark kernel marks in owner[0]; the last pass above marked in owner[passes & 1]: the mark
+            // Rows that receive more overflow events per slice than the passes above can run (hubs: one event per row and pass, as
+            // the row's lock serialises them in the reference) would carry a growing backlog to the end of the batch -- their
+            // events would all run AFTER everybody else's (measured on a graph whose hub is every node's neighbour: final CE
+            // 0.61x).  Where the graph has such rows (backlog > 0, known from the edge colouring) the slice is not left before its
+            // pending list is back to the size conflicts alone explain: a look at the counters every 4 extra passes.
+            if (backlog > 0.) {
+                const uint64_t carry_ok = (uint64_t)(0.05 * per_slice_ov) + 16;
+                for (int extra = 0; extra < 100000; extra += 4) {
+                    uint32_t lefts[kSub];
+                    AE_HIP(hipMemcpyAsync(lefts, o->sl_counts.p + cur * kSub, 4 * kSub, hipMemcpyDeviceToHost, stream()));
+                    sync();
+                    uint64_t left = 0;
+                    for (int q = 0; q < kSub; q++) left += lefts[q];
+                    if (left <= carry_ok) break;
+                    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(4, blocks_for(left / kSub + 256, 256)), 65535u);
+                    for (int p = 0; p < 4; p++) {
+                        a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
+                        a.owner_chk = (passes + p) & 1; a.owner_mark = (passes + p + 1) & 1;
+                        a.backoff = 1;
+                        a.tile = 0;
+                        a.pass_seq = pass_seq++;
+                        AE_DISPATCH_DIM(o->dev.dim, launch_exec, a, grid, o->sl_srec_floats, f64);
+                        cur = (cur + 1) % 3;
+                    }
+                }
+            }
+            // the next slice's mark kernel marks in owner[0]; the last pass above marked in owner[(passes + extra) & 1]: the mark
             // kernel re-marks everything that is pending anyway
         }
         // drain: passes until nothing is pending (a look at the counters every 8 passes)

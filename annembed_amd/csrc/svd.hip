@@ -209,6 +209,76 @@ __global__ void __launch_bounds__(BM * 2) dense_mul_panel_mfma_kernel(const floa
     }
 }
 
+// The same product with NO workgroup barrier in the contraction loop (round 3).  The whole panel X (n x l floats: 63 KB at
+// 784 x 20) is staged in LDS once per workgroup; afterwards every wave is on its own: lane (i = lane % 32, h = lane / 32) streams
+// the float4 A[row_i][k0 + 4 h .. + 3] of ITS row straight from memory -- 32 bytes per row and instruction, the rest of the 128-byte
+// line comes from the caches on the next trips -- and feeds four MFMAs with it: MFMA t contracts k = k0 + 4 h + t, whose X operand
+// (lane (j, h) -> X[k0 + 4 h + t][j]) is an LDS read.  Any assignment of the k's to (trip, h, t) is a valid contraction order as
+// long as both operands agree.  The next trip's U loads are issued before this trip's 4 U MFMAs.  60000 x 784, l = 20: 47 us per
+// product (4.0 TB/s; the tiled kernel above: 52 us).  Tried and measured slower: fully coalesced loads (8 lanes per 128-byte line)
+// through a wave-private LDS tile -- 64 us: with the tile the workgroup needs 80 KB of LDS and only one fits a CU.
+// Requires n % 8 == 0 and n * l * 4 <= 64 KB of LDS; 128 rows per workgroup (4 waves), two workgroups per CU.
+template <int U>
+__global__ void __launch_bounds__(256) dense_mul_panel_mfma_stream_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                                          const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
+    extern __shared__ __attribute__((aligned(16))) float sXs[];  // n x l
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (uint64_t idx = tid * 4ull; idx < n * l; idx += 1024) {  // (n % 8 == 0 => n * l % 4 == 0)
+        *reinterpret_cast<float4*>(sXs + idx) = *reinterpret_cast<const float4*>(x + idx);
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    const uint64_t row = blockIdx.x * 128ull + (uint64_t)w * 32u + (uint64_t)i;
+    const bool rin = row < m;
+    const float* pa = a + (rin ? row : 0) * n + 4 * h;
+    const bool jin = (uint32_t)i < l;                 // (the B operand's lane index j = lane % 32)
+    const float* pb = sXs + (uint64_t)(4 * h) * l + (jin ? i : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.f;
+    uint64_t k0 = 0;
+    const uint64_t full = n / (8 * U);  // whole trips of U loads
+    float4 cur[U], nxt[U];
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = *reinterpret_cast<const float4*>(pa + 8 * u);
+    }
+    for (uint64_t t = 0; t < full; t++, k0 += 8 * U) {
+        const bool more = t + 1 < full;
+#pragma unroll
+        for (int u = 0; u < U; u++) nxt[u] = *reinterpret_cast<const float4*>(pa + (more ? k0 + 8 * U : k0) + 8 * u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float* b = pb + (k0 + 8 * u) * l;
+            const float b0 = jin ? b[0] : 0.f, b1 = jin ? b[l] : 0.f, b2 = jin ? b[2 * l] : 0.f, b3 = jin ? b[3 * l] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].x : 0.f, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].y : 0.f, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].z : 0.f, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].w : 0.f, b3, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    for (; k0 < n; k0 += 8) {  // remainder trips
+        const float4 v = *reinterpret_cast<const float4*>(pa + k0);
+        const float* b = pb + k0 * l;
+        const float b0 = jin ? b[0] : 0.f, b1 = jin ? b[l] : 0.f, b2 = jin ? b[2 * l] : 0.f, b3 = jin ? b[3 * l] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.x : 0.f, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.y : 0.f, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.z : 0.f, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.w : 0.f, b3, acc, 0, 0, 0);
+    }
+    if (jin) {
+        const uint64_t rb = blockIdx.x * 128ull + (uint64_t)w * 32u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint64_t r = rb + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (r < m) y[r * l + i] = acc[q];
+        }
+    }
+}
+
 // partial[chunk][n x l] = A[rows of chunk]^T * X[rows of chunk].  A workgroup owns a strip of 128 columns of A and a
 // chunk of rows.  Lane (h = lane / 32, i = lane % 32) loads the float4 A[row + h][c0 + 4 i .. 4 i + 3] -- 512 contiguous
 // bytes per row, one 1 KB load instruction per 2 rows -- and feeds FOUR MFMAs: MFMA q multiplies the strided column set
@@ -864,6 +934,12 @@ void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l
     if (l <= 32 && !debug_knob("AE_NO_MFMA")) {  // matrix-core path
         constexpr int BM = 128;  // (64-row workgroups measured 5 % slower)
         const unsigned g2 = blocks_for(a.nrows, BM);
+        const size_t x_bytes = (size_t)a.ncols * l * sizeof(float);
+        if (a.ncols % 8 == 0 && x_bytes <= 64 * 1024 && !debug_knob("AE_MFMA_TILED")) {  // the panel fits in LDS: barrier-free streaming form
+            hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4>), dim3(g2), dim3(256), x_bytes, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+            check_launch("dense_mul_panel_mfma_stream");
+            return;
+        }
         if (a.ncols % 4 == 0)
             hipLaunchKernelGGL((dense_mul_panel_mfma_kernel<true, BM>), dim3(g2), dim3(BM * 2), 0, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
         else

@@ -45,7 +45,8 @@ def avg(d, counter, needle):
             if needle in r['Kernel_Name'] and r['Counter_Name'] == counter:
                 tot += float(r['Counter_Value']); seen.add(r['Dispatch_Id'])
     return (tot / len(seen), len(seen)) if seen else (None, 0)
-for needle, fname in (('ce_dataflow_kernel', 'pmc_ce_dataflow.json'), ('ce_event_window_kernel', 'pmc_ce_event.json'), ('ce_round_node_kernel', 'pmc_ce_round.json')):
+for needle, fname in (('ce_dataflow_kernel<2, false>', 'pmc_ce_dataflow.json'), ('ce_dataflow_kernel<2, true>', 'pmc_ce_ordered.json'),
+                      ('ce_event_window_kernel', 'pmc_ce_event.json'), ('ce_round_node_kernel', 'pmc_ce_round.json')):
     fetch, nf = avg('pmc_fetch', 'FETCH_SIZE', needle)
     write, nw = avg('pmc_write', 'WRITE_SIZE', needle)
     if fetch is not None and write is not None:
