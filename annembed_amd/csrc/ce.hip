@@ -710,9 +710,11 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
 }
 
 // AE_CE_SEQUENTIAL scheduled on the device (see the dataflow kernels above).
-// (Tried and dropped: preparing the set of batch b + 1 on a second stream while the dataflow kernel of batch b runs -- the
+// (Tried and dropped, twice: preparing the set of batch b + 1 on a second stream while the dataflow kernel of batch b runs -- the
 // preparation depends only on graph, RNG stream and batch index.  The kernels do overlap, but the latency-bound dataflow slows
-// by what the overlap saves: C2 11.3 -> 11.5 ms per batch, C3 shape 68.6 -> 69.0 ms, dataflow kernel alone 14.9 -> 21.7 ms.)
+// by what the overlap saves: exact form C2 11.3 -> 11.5 ms per batch, C3 shape 68.6 -> 69.0 ms; ordered form (round 3) C2 5.79 ->
+// 5.73 ms -- and the co-running planner skews the ordered kernel's waves enough to show in its fidelity on the stiff k = 6 graph:
+// final CE 1.000 -> 1.010 of the sequential mode's over three seeds.)
 static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter, bool relaxed) {
     if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
     const uint32_t dim = o->dev.dim;

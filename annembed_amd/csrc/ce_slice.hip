@@ -1023,7 +1023,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_backlog.alloc_pooled(1);
         d_backlog.zero();
         hipLaunchKernelGGL(sl_backlog_kernel, dim3(grid_cap(n, 256, 1024)), dim3(256), 0, stream(), n, (const float*)o->sl_node_ov.p,
-                           (float)(seg_samples / (double)n), (float)(passes * n_slices) * 0.5f, d_backlog.p);
+                           (float)(seg_samples / (double)n), (float)(passes * n_slices), d_backlog.p);
         d_backlog.download(&backlog, 1);
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list

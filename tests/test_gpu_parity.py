@@ -1119,9 +1119,11 @@ def test_sharded_protocol_lockstep_four_shards(A, oracle, graph):
     """The sharded CE protocol with several exchanges per batch, on one GPU: four rounds-mode shard handles run in lockstep
     (ae_entropy_optim_gradient_iteration_lockstep -- round for round and exchange for exchange what four processes with a
     communicator attached run).  After every batch the four replicas are identical; every row moved; the final cross entropy
-    is compared with the UN-SHARDED SEQUENTIAL ORACLE.  The rounds mode is approximate and sharding adds to it: measured on
-    this graph 0.69x / 0.85x / 0.91x at 1 / 4 / every-round exchanges (six batches from a random start); the bars below only
-    keep the protocol from drifting further.  The 60 k-point measurements (1-8 shards, two graph families) are in
+    is compared with the UN-SHARDED SEQUENTIAL ORACLE.  NOT a parity test: the only mode that shards is the approximate rounds mode
+    (asked for by name -- AE_CE_AUTO refuses a sharded range), and sharding adds to its distance from the reference: measured on
+    this graph 0.69x / 0.85x / 0.91x at 1 / 4 / every-round exchanges (six batches from a random start).  The exact assertions here
+    are the protocol's (identical replicas after every exchange, every row moved, ranges and modes refused when they must be); the
+    ratio bars are a regression guard around those measurements, not a tolerance anybody should read as "matches the reference".  The 60 k-point measurements (1-8 shards, two graph families) are in
     profiles/r02/shard_fidelity_*.json (tools/run_shard_fidelity.py) and DESIGN 5."""
     from annembed_amd.dist import shard_range
     indptr, nbr, dist, _ = graph
@@ -1156,7 +1158,8 @@ def test_sharded_ce_hip_backend_two_ranks_one_gpu(A, oracle, graph, tmp_path):
     """Two processes (gloo; both on this box's one GPU) each run the HIP library on their shard of the source nodes and exchange
     the owned rows once per batch.  Checked against the UN-SHARDED SEQUENTIAL ORACLE, not against an emulation of the protocol:
     the replicas are identical after every exchange, every row moved, and the final cross entropy is within the distance the
-    rounds mode + sharding are documented to have from the reference on this graph (measured 0.69-0.90x)."""
+    rounds mode + sharding are documented to have from the reference on this graph (measured 0.69-0.90x) -- a
+    regression guard, not a parity claim: the sharded path is the approximate mode, by name (AE_CE_AUTO refuses a sharded range)."""
     import subprocess
     import sys
     import socket
