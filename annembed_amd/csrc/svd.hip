@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BM * 2) dense_mul_panel_mfma_kernel(const floa
 // product (4.0 TB/s; the tiled kernel above: 52 us).  Tried and measured slower: fully coalesced loads (8 lanes per 128-byte line)
 // through a wave-private LDS tile -- 64 us: with the tile the workgroup needs 80 KB of LDS and only one fits a CU.
 // Requires n % 8 == 0 and n * l * 4 <= 64 KB of LDS; 128 rows per workgroup (4 waves), two workgroups per CU.
-template <int U>
+template <int U, bool NT>
 __global__ void __launch_bounds__(256) dense_mul_panel_mfma_stream_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
                                                                           const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
     extern __shared__ __attribute__((aligned(16))) float sXs[];  // n x l
@@ -239,14 +239,23 @@ __global__ void __launch_bounds__(256) dense_mul_panel_mfma_stream_kernel(const 
     uint64_t k0 = 0;
     const uint64_t full = n / (8 * U);  // whole trips of U loads
     float4 cur[U], nxt[U];
+    auto ld = [&](const float* p) {
+        if constexpr (NT) {
+            using v4 = __attribute__((ext_vector_type(4))) float;
+            const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+            return make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            return *reinterpret_cast<const float4*>(p);
+        }
+    };
     if (full) {
 #pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = *reinterpret_cast<const float4*>(pa + 8 * u);
+        for (int u = 0; u < U; u++) cur[u] = ld(pa + 8 * u);
     }
     for (uint64_t t = 0; t < full; t++, k0 += 8 * U) {
         const bool more = t + 1 < full;
 #pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = *reinterpret_cast<const float4*>(pa + (more ? k0 + 8 * U : k0) + 8 * u);
+        for (int u = 0; u < U; u++) nxt[u] = ld(pa + (more ? k0 + 8 * U : k0) + 8 * u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -936,7 +945,9 @@ void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l
         const unsigned g2 = blocks_for(a.nrows, BM);
         const size_t x_bytes = (size_t)a.ncols * l * sizeof(float);
         if (a.ncols % 8 == 0 && x_bytes <= 64 * 1024 && !debug_knob("AE_MFMA_TILED")) {  // the panel fits in LDS: barrier-free streaming form
-            hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4>), dim3(g2), dim3(256), x_bytes, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+            // (U = 2 / 4 / 8 loads per trip: 46.4 / 47.8 / 48.4 us; non-temporal loads: 63-66 us -- the later trips of a row's 128-byte line
+            // must come from the caches)
+            hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, false>), dim3(g2), dim3(256), x_bytes, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
             check_launch("dense_mul_panel_mfma_stream");
             return;
         }
