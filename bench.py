@@ -639,12 +639,22 @@ def cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch):
     eo = O.EntropyOptim(indptr, nbr, proba, scale, y0, b=params.b, seed=params.seed, sampler=0)
     nb_sample = params.nb_sampling_by_edge * len(nbr)
     cores = O.max_threads()
-    eo.gradient_iteration_hogwild(nb_sample // 8, 1.0, 1, 0)  # warm the thread pool
+    # the cores this process may really use: the scheduler affinity and a cgroup CPU quota, if any (OpenMP sees the machine's)
+    try:
+        usable = len(os.sched_getaffinity(0))
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(float(quota) / float(period))))
+        cores = max(1, min(int(cores), usable))
+    except Exception:
+        cores = int(cores)
+    eo.gradient_iteration_hogwild(nb_sample // 8, 1.0, 1, cores)  # warm the thread pool
     batches = 0
     t0 = time.perf_counter()
     while True:
         batches += 1
-        eo.gradient_iteration_hogwild(nb_sample, params.grad_step * (1.0 - batches / nb_batch), batches + 1, 0)
+        eo.gradient_iteration_hogwild(nb_sample, params.grad_step * (1.0 - batches / nb_batch), batches + 1, cores)
         el = time.perf_counter() - t0
         if el > 10.0 or batches >= 8:
             break

@@ -218,6 +218,8 @@ def test_c4_shape_single_gpu_properties(A):
         if name == "auto":
             drawn, _ = h.samples_drawn()
             assert abs(drawn - S) < 6 * np.sqrt(S)
+            classes, overflow, _, slices = h.slice_info()  # at this size the slices run as conflict-free matchings
+            assert classes >= 12 and overflow < 0.05 and slices >= 200, (classes, overflow, slices)
         del h
     assert abs(ces["auto"] - ces["sequential"]) < 0.01 * ces["sequential"], ces
     with pytest.raises(A.AnnembedError):
@@ -245,8 +247,8 @@ def test_c4_shape_single_gpu_properties(A):
 def test_c5_shape_one_shard_properties(A):
     """configs[4] shape, one GPU's share of it: the full 50 M-node graph (k = 10, ring lattice with randomly PERMUTED node ids)
     and the full 50 M x 16 coordinate replica on the device, this rank owning the first eighth of the nodes (6.25 M sources,
-    62.5 M edges, 625 M samples per batch).  AE_CE_AUTO resolves to the rounds mode for a sharded range (the d = 16 node
-    kernel with tile negatives); one batch keeps its invariants: samples drawn within 6 sigma of the shard's nb_sample,
+    62.5 M edges, 625 M samples per batch).  The rounds mode, asked for by name (AE_CE_AUTO refuses a sharded range; the d = 16
+    node kernel with tile negatives); one batch keeps its invariants: samples drawn within 6 sigma of the shard's nb_sample,
     finite rows, every owned row moved, NO row outside the shard touched (owner computes), the box stays bounded."""
     n, k, d, world = 50_000_000, 10, 16, 8
     rng = np.random.default_rng(4)
