@@ -370,7 +370,11 @@ __global__ void df_pred_reads_kernel(uint64_t S, const uint32_t* __restrict__ pl
 template <int DIM, bool RELAXED>
 __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, const uint32_t* __restrict__ plan_nodes,
                                                           const float* __restrict__ plan_w, const uint32_t* __restrict__ pred,
-                                                          float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err, uint32_t lane_stride) {
+                                                          float* __restrict__ ver, double grad_step, unsigned int* __restrict__ err, uint32_t lane_stride_arg) {
+    // (bit 31 of the stride argument: the relaxed form computes its repulsion coefficients in f32)
+    const uint32_t lane_stride = lane_stride_arg & 0x7FFFFFFFu;
+    const bool f32_repulsion = (lane_stride_arg >> 31) != 0u;
+    (void)f32_repulsion;
     // rows of more than 16 columns (asked_dim 17 ... 64): only the two end points are held in registers, a negative's row is
     // taken when its repulsion is due (7 x 64 registers do not exist); same arithmetic, same order
     constexpr bool WIDE = DIM > 16 || RELAXED;
@@ -455,8 +459,14 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                     }
                 } else if constexpr (RELAXED && DIM <= 16) {
                     if (stage == 1) {  // (the negatives were read in this very trip, next to the polls: see below)
+                        if (f32_repulsion) {
+                            const float sf = (float)scale, inv_s2 = __builtin_amdgcn_rcpf(sf * sf);
 #pragma unroll
-                        for (int g = 0; g < 5; g++) sample_repulse<DIM>(rows[0], negs[g], grad, scale, c.b, grad_step);
+                            for (int g = 0; g < 5; g++) sample_repulse_f32<DIM>(rows[0], negs[g], grad, inv_s2, (float)c.b, (float)grad_step);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < 5; g++) sample_repulse<DIM>(rows[0], negs[g], grad, scale, c.b, grad_step);
+                        }
                         stage = 6;
                     }
                 } else {
@@ -668,7 +678,10 @@ static void launch_dataflow2(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, u
         AE_HIP(hipEventCreate(&e1));
         AE_HIP(hipEventRecord(e0, stream()));
         (void)args;
-        hipLaunchKernelGGL((ce_dataflow_kernel<DIM, RELAXED>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, lane_stride);
+        // f32 repulsion coefficients (debug knob AE_DF_F32_REPULSION): C2 batch 5.8 -> 5.4 ms, but the faster kernel's wave skew shows
+        // in the fidelity on the stiff k = 6 graph (final CE 1.010 x the sequential mode's over three seeds, f64: 1.000): not the default
+        const uint32_t stride_arg = lane_stride | ((RELAXED && debug_knob("AE_DF_F32_REPULSION")) ? 0x80000000u : 0u);
+        hipLaunchKernelGGL((ce_dataflow_kernel<DIM, RELAXED>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, stride_arg);
         AE_HIP(hipEventRecord(e1, stream()));
         o->df_events.emplace_back(e0, e1);
         hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,

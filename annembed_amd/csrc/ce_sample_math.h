@@ -101,6 +101,26 @@ __device__ __forceinline__ void sample_repulse(float* yi, const float* yk, float
 #pragma unroll
     for (int t = 0; t < DIM; t++) yi[t] -= grad[t];  // :1297
 }
+// The repulsion with its scalar coefficient in f32 (hardware reciprocals): for the modes whose negatives are read unsynchronised
+// anyway (AE_CE_ORDERED, AE_CE_SLICED) -- the rounding of the coefficient (1e-7) is far below the difference between two
+// admissible readings of the negative's row; the five dependent repulsions of a source event are on the critical path of its
+// node's chain (4 dependent f64 divisions each).
+template <int DIM>
+__device__ __forceinline__ void sample_repulse_f32(float* yi, const float* yk, float* grad, float inv_s2, float b, float step) {
+    float ak = 0.f;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) { const float df = yi[t] - yk[t]; ak += df * df; }
+    const float d = ak * inv_s2;
+    if (ak > 0.f) {
+        const float coeff = b == 1.f ? 2.0f * inv_s2 * __builtin_amdgcn_rcpf(1.0f + d)
+                                     : 2.0f * b * __builtin_amdgcn_rcpf(1.0f + __powf(d, b)) * __powf(d, b - 1.0f) * inv_s2;
+        const float cf = fminf(step * coeff * __builtin_amdgcn_rcpf(fmaxf(d * d, 1.0f / 16.0f)), 2.0f);
+#pragma unroll
+        for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
+    }  // else: `gradient` keeps its previous value, as in the reference
+#pragma unroll
+    for (int t = 0; t < DIM; t++) yi[t] -= grad[t];
+}
 constexpr uint64_t kUnpublished64 = ~0ull;
 constexpr uint32_t kUnpublished32 = ~0u;
 template <int DIM>
