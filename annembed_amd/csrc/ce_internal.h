@@ -108,8 +108,7 @@ struct ae_entropy_optim {
     uint64_t ev_resident_blocks = 0;
     DevBuf<float> ev_slots;
     // time-sliced optimistic mode (ce_slice.hip)
-    DevBuf<uint32_t> sl_erec, sl_edge_src, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
-    DevBuf<float> sl_list_scale;
+    DevBuf<uint32_t> sl_erec, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
     DevBuf<unsigned long long> sl_done;
     float sl_pmax = 0.f;
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
