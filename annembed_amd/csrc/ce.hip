@@ -943,10 +943,16 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         sync();
         const bool sharded = node_lo != 0 || node_hi != n;
         const uint32_t mode = resolve_ce_mode(params->ce_mode, dim, sharded, params->nb_sampling_by_edge * (edge_hi - edge_lo), g->max_nbng, g->nnz);
-        if (mode == AE_CE_EVENT || mode == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
-        if (mode == AE_CE_EVENT) ce_event_prepare(o.get());
-        if (mode == AE_CE_SLICED) ce_slice_prepare(o.get());
-        o->params.ce_mode = mode;
+        uint32_t mode_final = mode;
+        if (params->ce_mode == AE_CE_AUTO && mode == AE_CE_SLICED && ce_slice_unsupported(o.get())) {  // (e.g. more than 2^27 nodes)
+            if (params->nb_sampling_by_edge * (edge_hi - edge_lo) >= (1ull << 31))
+                fail(AE_ERR_INVALID_ARG, "no faithful CE mode fits this problem: AE_CE_SLICED: %s; AE_CE_ORDERED: >= 2^31 samples per batch", ce_slice_unsupported(o.get()));
+            mode_final = AE_CE_ORDERED;
+        }
+        if (mode_final == AE_CE_EVENT || mode_final == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
+        if (mode_final == AE_CE_EVENT) ce_event_prepare(o.get());
+        o->params.ce_mode = mode_final;  // (ce_slice_prepare reads it: the cost model of the matching cut belongs to this mode only)
+        if (mode_final == AE_CE_SLICED) ce_slice_prepare(o.get());
         return o.release();
     }
 }
