@@ -462,6 +462,8 @@ def main():
         "rounds_mode": rounds_mode,
         "exact_mode": exact_mode,
         "scale_shapes": scale_shapes,
+        "multi_gpu_note": ("--gpus N shards the APPROXIMATE rounds mode only (by name; AE_CE_AUTO refuses a sharded node range, DESIGN 5): output that is the "
+                           "reference's comes from one GPU -- scale_shapes.c4_shape.sliced_mode is configs[3]'s shape, c5_shard_shape one eighth of configs[4]'s"),
         "svd_init": {"gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5},
         "svd_dense": svd_dense,
         "knn_producer": knn_producer,
@@ -600,7 +602,11 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
                              else "torch/gloo (validation)")},
             "roofline": roof,
             "per_rank_batch_ms_max": kernel_ms_max,
-            "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the bit-exact mode (its `value` is NOT the one-GPU point of this series); "
+            "faithful": False,
+            "multi_gpu_note": ("only the APPROXIMATE rounds mode shards (AE_CE_AUTO refuses a sharded node range: no schedule over devices reproduces the "
+                               "reference's loop at a viable exchange volume, DESIGN 5); for output that IS the reference's, configs[3] / [4] run on ONE GPU "
+                               "(the --gpus 1 line's scale_shapes.c4_shape.sliced_mode)"),
+            "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the default faithful mode (its `value` is NOT the one-GPU point of this series); "
                                  "the same graph and mode as here on ONE GPU is its key scale_shapes.c4_shape.rounds_mode (points_per_s, ms_per_step)"
                                  if not args.weak else "the --gpus 1 line's key rounds_mode (same shape and mode on one GPU)"),
             "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
