@@ -1138,9 +1138,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             // Rows that receive more overflow events per slice than the passes above can run (hubs: one event per row and pass, as
             // the row's lock serialises them in the reference) would carry a growing backlog to the end of the batch -- their
             // events would all run AFTER everybody else's (measured on a graph whose hub is every node's neighbour: final CE
-            // 0.61x).  Where the graph has such rows (backlog > 0, known from the edge colouring) the slice is not left before its
+            // 0.61x).  Where the graph has such rows (expected backlog > 1 % of the events, known from the edge colouring) the slice is not left before its
             // pending list is back to the size conflicts alone explain: a look at the counters every 4 extra passes.
-            if (backlog > 0.) {
+            if (backlog > 0.01 * seg_samples) {  // (below 1 % of the events the late ones do not show: blobs k = 6 with in-degrees up to 105: CE 1.002-1.014 either way)
                 const uint64_t carry_ok = (uint64_t)(0.05 * per_slice_ov) + 16;
                 for (int extra = 0; extra < 100000; extra += 4) {
                     uint32_t lefts[kSub];

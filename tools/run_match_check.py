@@ -20,7 +20,7 @@ from tools.run_event_check import blobs, edge_q  # noqa: E402
 
 
 def knobs(**kw):
-    for k in ("AE_SL_LAMBDA", "AE_SL_NO_MATCH", "AE_SL_NO_TILE", "AE_SL_TILE_MIN", "AE_SL_TILE_ALWAYS", "AE_SL_CLASS_CAP", "AE_SL_TAIL", "AE_SL_EPT", "AE_SL_NO_SPREAD"):
+    for k in ("AE_SL_LAMBDA", "AE_SL_NO_MATCH", "AE_SL_NO_TILE", "AE_SL_TILE_MIN", "AE_SL_TILE_ALWAYS", "AE_SL_CLASS_CAP", "AE_SL_TAIL", "AE_SL_EPT", "AE_SL_NO_SPREAD", "AE_SL_PASSES"):
         os.environ.pop(k, None)
     for k, v in kw.items():
         if v is not None:
@@ -70,6 +70,7 @@ def fidelity(kind="blobs6", n=60000, nb_batch=40, out_path=None):
     variants = [("match lambda %g" % lam, dict(AE_SL_LAMBDA=lam)) for lam in lambdas]
     variants += [("match lambda %g no spread" % lam, dict(AE_SL_LAMBDA=lam, AE_SL_NO_SPREAD=1)) for lam in lambdas if lam >= 2]
     variants += [("all-optimistic", dict(AE_SL_NO_MATCH=1))]
+    variants += [("all-optimistic %d passes" % p, dict(AE_SL_NO_MATCH=1, AE_SL_PASSES=p)) for p in (2, 1)]
     for name, kw in variants:
         rr = []
         for sd in seeds[:2]:
@@ -98,7 +99,9 @@ def scale(n=1_650_000, k=6, d=2, steps=3, out_path=None):
                 ("match lambda 1", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=1)), ("match lambda 2", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=2)),
                 ("match lambda 4", A.AE_CE_SLICED, dict(AE_SL_LAMBDA=4)),
                 ("match no tile", A.AE_CE_SLICED, dict(AE_SL_NO_TILE=1)), ("match tile always", A.AE_CE_SLICED, dict(AE_SL_TILE_ALWAYS=1, AE_SL_TILE_MIN=1)),
-                ("all-optimistic", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1)), ("rounds", A.AE_CE_HOGWILD, {}), ("ordered", A.AE_CE_ORDERED, {}),
+                ("all-optimistic", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1)), ("all-optimistic 2 passes", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1, AE_SL_PASSES=2)),
+                ("all-optimistic 1 pass", A.AE_CE_SLICED, dict(AE_SL_NO_MATCH=1, AE_SL_PASSES=1)),
+                ("rounds", A.AE_CE_HOGWILD, {}), ("ordered", A.AE_CE_ORDERED, {}),
                 ("sequential", A.AE_CE_SEQUENTIAL, {})]
     if os.environ.get("VARIANTS"):
         keep = os.environ["VARIANTS"].split(",")
