@@ -623,17 +623,27 @@ static void check_err_flag(ae_entropy_optim* o) {
     if (h) fail(AE_ERR_INVALID_ARG, "negative sampling could not find 5 admissible nodes (graph too small for its neighbourhood size?)");
 }
 
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        AE_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        AE_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+// `run`: the stream of the version fill and the dataflow kernel (null: the library stream) and the CUs it may use; the commit
+// follows on the library stream (the caller has ordered it after `run`)
 template <int DIM, bool RELAXED>
-static void launch_dataflow2(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys) {
+static void launch_dataflow2(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys,
+                             hipStream_t run, int run_cus) {
     {
-        static int blocks_per_cu = 0, cus = 0;
-        if (!blocks_per_cu) {
-            int dev = 0;
-            AE_HIP(hipGetDevice(&dev));
-            hipDeviceProp_t prop;
-            AE_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount;
-        }
+        int blocks_per_cu = 0;
+        const int cus = run ? run_cus : device_cus();
+        StreamScope on_run(run ? run : stream());
         const unsigned bs = debug_knob("AE_DF_BLOCK") ? (unsigned)atoi(debug_knob("AE_DF_BLOCK")) : 128u;
         int bpc = 0;
         AE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, ce_dataflow_kernel<DIM, RELAXED>, (int)bs, 0));
@@ -684,25 +694,33 @@ static void launch_dataflow2(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, u
         hipLaunchKernelGGL((ce_dataflow_kernel<DIM, RELAXED>), dim3(grid), dim3(bs), 0, stream(), dev, S, pn, pw, pred, ver, step, err, stride_arg);
         AE_HIP(hipEventRecord(e1, stream()));
         o->df_events.emplace_back(e0, e1);
-        hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
-                           (const float*)ver, o->dev.y, (const unsigned int*)o->err.p);
     }
+    if (run) {  // back on the library stream, after the kernel
+        AE_HIP(hipEventRecord(o->df_ahead.ran, run));
+        AE_HIP(hipStreamWaitEvent(stream(), o->df_ahead.ran, 0));
+    }
+    hipLaunchKernelGGL((df_commit_kernel<DIM>), dim3(blocks_for(o->dev.n, 256)), dim3(256), 0, stream(), o->dev.n, rowptr, keys,
+                       (const float*)o->df_ver.p, o->dev.y, (const unsigned int*)o->err.p);
 }
 
 template <int DIM>
-static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys, bool relaxed) {
-    if (relaxed) launch_dataflow2<DIM, true>(o, st, S, step, rowptr, keys);
-    else launch_dataflow2<DIM, false>(o, st, S, step, rowptr, keys);
+static void launch_dataflow(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, double step, const uint64_t* rowptr, const uint32_t* keys, bool relaxed,
+                            hipStream_t run, int run_cus) {
+    if (relaxed) launch_dataflow2<DIM, true>(o, st, S, step, rowptr, keys, run, run_cus);
+    else launch_dataflow2<DIM, false>(o, st, S, step, rowptr, keys, run, run_cus);
 }
 
 // everything of a sequential batch that depends only on (graph, RNG stream, batch index): the plan of its samples, their write
 // events sorted by node, every read's predecessor.  Runs on whatever stream() is current.
-static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, uint32_t iter, bool relaxed) {
+static void df_reserve_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S) {
     if (st.plan_nodes.n < S * 7) st.plan_nodes.alloc(S * 7);
     if (st.plan_w.n < S) st.plan_w.alloc(S);
     if (st.pred.n < S * 7) st.pred.alloc(S * 7);
     if (st.keys0.n < 2 * S + 16) { st.keys0.alloc(2 * S + 16); st.keys1.alloc(2 * S + 16); }  // (+16: df_pred_reads_kernel's window may overhang)
     if (st.rowptr.n < o->dev.n + 1) st.rowptr.alloc(o->dev.n + 1);
+}
+static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uint64_t S, uint32_t iter, bool relaxed) {
+    df_reserve_set(o, st, S);
     launch_plan(o, o->sample_offset, S, iter, st.plan_nodes.p, st.plan_w.p);
     // each key buffer holds 2 S node keys followed by 2 S version ids
     uint32_t* k0 = reinterpret_cast<uint32_t*>(st.keys0.p);
@@ -722,12 +740,45 @@ static void df_prepare_set(ae_entropy_optim* o, ae_entropy_optim::DfSet& st, uin
     check_launch("df_pred");
 }
 
-// AE_CE_SEQUENTIAL scheduled on the device (see the dataflow kernels above).
-// (Tried and dropped, twice: preparing the set of batch b + 1 on a second stream while the dataflow kernel of batch b runs -- the
-// preparation depends only on graph, RNG stream and batch index.  The kernels do overlap, but the latency-bound dataflow slows
-// by what the overlap saves: exact form C2 11.3 -> 11.5 ms per batch, C3 shape 68.6 -> 69.0 ms; ordered form (round 3) C2 5.79 ->
-// 5.73 ms -- and the co-running planner skews the ordered kernel's waves enough to show in its fidelity on the stiff k = 6 graph:
-// final CE 1.000 -> 1.010 of the sequential mode's over three seeds.)
+// Two CU-masked streams for the overlap of a batch's dataflow kernel with the preparation of the next one: the first quarter of the
+// CU mask bits (tools/probe_cumask.hip: bit b = one CU of XCD b % 8, so every XCD gives the same share) prepares, the rest runs.
+static bool df_ahead_streams(ae_entropy_optim* o) {
+    auto& a = o->df_ahead;
+    if (a.tried) return a.run != nullptr;
+    a.tried = 1;
+    const int cus = device_cus();
+    int prep_cus = cus / 4;
+    if (debug_knob("AE_DF_PREP_CUS")) prep_cus = std::max(8, std::min(cus - 8, atoi(debug_knob("AE_DF_PREP_CUS"))));
+    std::vector<uint32_t> m_prep((cus + 31) / 32, 0u), m_run((cus + 31) / 32, 0u);
+    for (int b = 0; b < cus; b++) (b < prep_cus ? m_prep : m_run)[b / 32] |= 1u << (b % 32);
+    hipStream_t run = nullptr, prep = nullptr;
+    if (hipExtStreamCreateWithCUMask(&run, (uint32_t)m_run.size(), m_run.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&prep, (uint32_t)m_prep.size(), m_prep.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (run) (void)hipStreamDestroy(run);
+        return false;  // no CU masks on this runtime: batches run one after the other on the library stream
+    }
+    AE_HIP(hipEventCreateWithFlags(&a.start, hipEventDisableTiming));
+    AE_HIP(hipEventCreateWithFlags(&a.ran, hipEventDisableTiming));
+    AE_HIP(hipEventCreateWithFlags(&a.prepared, hipEventDisableTiming));
+    a.run = run;
+    a.prep = prep;
+    a.run_cus = cus - prep_cus;
+    return true;
+}
+
+// AE_CE_SEQUENTIAL / AE_CE_ORDERED scheduled on the device (see the dataflow kernels above).
+// The preparation of a batch depends only on graph, RNG stream and batch index: while the dataflow kernel of batch b runs, the set of
+// batch b + 1 (same size, next index -- what every caller's schedule asks next; anything else is prepared afresh) is built on a second
+// stream.  On the SAME CUs that was tried and dropped, twice: the kernels do overlap, but the latency-bound dataflow slows by what the
+// overlap saves (exact form C2 11.3 -> 11.5 ms per batch; ordered form 5.79 -> 5.73 ms) and the co-running planner skews the ordered
+// kernel's waves enough to show in its fidelity on the stiff k = 6 graph (final CE 1.000 -> 1.010 of the sequential mode's).  A hop's
+// price sits in the memory queue of the CU that polls, so the two get DISJOINT CUs (CU-masked streams): a quarter of the CUs prepares.
+// Measured (MI355X, C2 batch): exact form 10.76 -> 9.28 ms (its kernel 8.25 -> 9.15 ms on 192 CUs -- more waves per CU, longer
+// hops -- but 2.4 ms of preparation gone from the critical path); ordered form 5.81 -> 5.68 ms at C2 and 2.86 -> 3.13 ms at 60 k x
+// k 6 (kernel 4.48 -> 5.21 ms against 1.3 ms of preparation hidden; with 32 preparing CUs the preparation, 8.6 ms, becomes the
+// critical path): the exact form overlaps, the ordered form does not.  Only where the dataflow is latency-bound (thin waves: batches
+// of up to 2^24 samples); bigger batches need every CU for either part.
 static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step, uint32_t iter, bool relaxed) {
     if (S >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "sequential mode supports < 2^31 samples per batch");
     const uint32_t dim = o->dev.dim;
@@ -735,12 +786,41 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
     const bool prof = debug_knob("AE_CE_PROF") != nullptr;
     auto now = [&] { if (prof) sync(); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    ae_entropy_optim::DfSet& st = o->df_set;
-    df_prepare_set(o, st, S, iter, relaxed);
+    auto& ahead = o->df_ahead;
+    bool overlap = !relaxed && S <= (1ull << 24);
+    if (debug_knob("AE_DF_AHEAD")) overlap = atoi(debug_knob("AE_DF_AHEAD")) != 0;
+    overlap = overlap && df_ahead_streams(o);
+    uint32_t cur = 0;
+    if (ahead.valid && overlap && ahead.S == S && ahead.iter == iter && ahead.relaxed == relaxed) {
+        cur = ahead.set;
+        AE_HIP(hipStreamWaitEvent(stream(), ahead.prepared, 0));
+    } else {
+        if (ahead.valid) AE_HIP(hipStreamSynchronize(ahead.prep));  // a set nobody asked for: let it finish before its buffers are reused
+        df_prepare_set(o, o->df_sets[0], S, iter, relaxed);
+    }
+    ahead.valid = false;
+    ae_entropy_optim::DfSet& st = o->df_sets[cur];
     const double t1 = now();
+    if (overlap) {
+        df_reserve_set(o, o->df_sets[cur ^ 1], S);
+        AE_HIP(hipEventRecord(ahead.start, stream()));
+        AE_HIP(hipStreamWaitEvent(ahead.run, ahead.start, 0));
+        AE_HIP(hipStreamWaitEvent(ahead.prep, ahead.start, 0));
+    }
     uint32_t* v1 = reinterpret_cast<uint32_t*>(st.keys1.p) + 2 * S;
-    AE_DISPATCH_DIM(dim, launch_dataflow, o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1, relaxed);
+    AE_DISPATCH_DIM(dim, launch_dataflow, o, st, S, step, (const uint64_t*)st.rowptr.p, (const uint32_t*)v1, relaxed, overlap ? ahead.run : nullptr,
+                    ahead.run_cus);
     check_launch("ce_dataflow");
+    if (overlap) {
+        StreamScope on_prep(ahead.prep);
+        df_prepare_set(o, o->df_sets[cur ^ 1], S, iter + 1, relaxed);
+        AE_HIP(hipEventRecord(ahead.prepared, ahead.prep));
+        ahead.valid = true;
+        ahead.S = S;
+        ahead.iter = iter + 1;
+        ahead.relaxed = relaxed;
+        ahead.set = cur ^ 1;
+    }
     sync();
     if (prof) fprintf(stderr, "CESEQ dataflow samples=%llu: plan + sort + predecessors %.2f ms, dataflow + commit %.2f ms\n",
                       (unsigned long long)S, (t1 - t0) * 1e3, (now() - t1) * 1e3);

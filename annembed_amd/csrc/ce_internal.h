@@ -85,7 +85,17 @@ struct ae_entropy_optim {
         DevBuf<float> plan_w;
         DevBuf<uint64_t> keys0, keys1, rowptr;
     };
-    DfSet df_set;
+    DfSet df_sets[2];
+    // The set of batch b + 1 is prepared while the dataflow kernel of batch b runs, each on its own share of the CUs (two CU-masked
+    // streams: a latency-bound kernel slows down when throughput kernels share its CUs' memory queues, not when they run elsewhere).
+    struct DfAhead {
+        hipStream_t run = nullptr, prep = nullptr;   // created on first use; null if the runtime refuses CU masks (then: no overlap)
+        hipEvent_t start = nullptr, ran = nullptr, prepared = nullptr;
+        int run_cus = 0, tried = 0;
+        bool valid = false, relaxed = false;         // a prepared set is waiting: for batch (S, iter) in df_sets[set]
+        uint64_t S = 0;
+        uint32_t iter = 0, set = 0;
+    } df_ahead;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> df_events;  // around the dataflow kernel alone
     DevBuf<float> df_ver;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -123,6 +133,9 @@ struct ae_entropy_optim {
     bool comm_equal = false;
     uint32_t comm_exchanges = 1;
     ~ae_entropy_optim() {
+        if (df_ahead.prep) { (void)hipStreamSynchronize(df_ahead.prep); (void)hipStreamDestroy(df_ahead.prep); }
+        if (df_ahead.run) { (void)hipStreamSynchronize(df_ahead.run); (void)hipStreamDestroy(df_ahead.run); }
+        for (hipEvent_t e : {df_ahead.start, df_ahead.ran, df_ahead.prepared}) if (e) (void)hipEventDestroy(e);
         for (auto& e : df_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }

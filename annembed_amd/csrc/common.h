@@ -82,6 +82,14 @@ inline int32_t guard(F&& f) {
 
 // the stream every kernel of the library is launched on (one per process / current device)
 hipStream_t stream();
+// while it lives, stream() of THIS thread returns `s` (work that runs beside the library stream: ce.hip's batch preparation)
+struct StreamScope {
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+    hipStream_t prev;
+};
 void require_device();
 // stream-ordered allocations (hipMallocAsync on the library stream, default pool kept warm): for the temporaries
 // of the per-call hot functions -- a hipMalloc / hipFree pair costs a device synchronisation

@@ -22,7 +22,12 @@ void require_device() {
              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
 }
 
+static thread_local hipStream_t t_stream_override = nullptr;
+StreamScope::StreamScope(hipStream_t s) : prev(t_stream_override) { t_stream_override = s; }
+StreamScope::~StreamScope() { t_stream_override = prev; }
+
 hipStream_t stream() {
+    if (t_stream_override) return t_stream_override;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) fail(AE_ERR_NO_DEVICE, "hipGetDevice failed (no HIP device?)");
     std::lock_guard<std::mutex> lk(g_stream_mu);

@@ -71,6 +71,9 @@ int main() {
         run<1, 64, 6>(y, (uint32_t)(bytes / 64), sink, "64-B rows, 4 lanes per row, 6 rows");
         run<1, 64, 12>(y, (uint32_t)(bytes / 64), sink, "64-B rows, 4 lanes per row, 12 rows");
         run<1, 64, 24>(y, (uint32_t)(bytes / 64), sink, "64-B rows, 4 lanes per row, 24 rows");
+        run<1, 128, 6>(y, (uint32_t)(bytes / 128), sink, "128-B rows, 8 lanes per row, 6 rows");
+        run<1, 128, 12>(y, (uint32_t)(bytes / 128), sink, "128-B rows, 8 lanes per row, 12 rows");
+        run<1, 128, 24>(y, (uint32_t)(bytes / 128), sink, "128-B rows, 8 lanes per row, 24 rows");
         CK(hipFree(y));
     }
     return 0;
