@@ -212,71 +212,121 @@ __global__ void __launch_bounds__(BM * 2) dense_mul_panel_mfma_kernel(const floa
 // The same product with NO workgroup barrier in the contraction loop (round 3).  The whole panel X (n x l floats: 63 KB at
 // 784 x 20) is staged in LDS once per workgroup; afterwards every wave is on its own: lane (i = lane % 32, h = lane / 32) streams
 // the float4 A[row_i][k0 + 4 h .. + 3] of ITS row straight from memory -- 32 bytes per row and instruction, the rest of the 128-byte
-// line comes from the caches on the next trips -- and feeds four MFMAs with it: MFMA t contracts k = k0 + 4 h + t, whose X operand
-// (lane (j, h) -> X[k0 + 4 h + t][j]) is an LDS read.  Any assignment of the k's to (trip, h, t) is a valid contraction order as
-// long as both operands agree.  The next trip's U loads are issued before this trip's 4 U MFMAs.  60000 x 784, l = 20: 47 us per
-// product (4.0 TB/s; the tiled kernel above: 52 us).  Tried and measured slower: fully coalesced loads (8 lanes per 128-byte line)
-// through a wave-private LDS tile -- 64 us: with the tile the workgroup needs 80 KB of LDS and only one fits a CU.
-// Requires n % 8 == 0 and n * l * 4 <= 64 KB of LDS; 128 rows per workgroup (4 waves), two workgroups per CU.
-template <int U, bool NT>
-__global__ void __launch_bounds__(256) dense_mul_panel_mfma_stream_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
-                                                                          const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
-    extern __shared__ __attribute__((aligned(16))) float sXs[];  // n x l
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (uint64_t idx = tid * 4ull; idx < n * l; idx += 1024) {  // (n % 8 == 0 => n * l % 4 == 0)
-        *reinterpret_cast<float4*>(sXs + idx) = *reinterpret_cast<const float4*>(x + idx);
-    }
-    __syncthreads();
+// line comes from the caches on the next loads -- and feeds four MFMAs with it: MFMA t contracts k = k0 + 4 h + t, whose X operand
+// (lane (j, h) -> X[k0 + 4 h + t][j]) comes from LDS.  Any assignment of the k's to (trip, h, t) is a valid contraction order as
+// long as both operands agree.
+//  * LDS layout of the panel: [k / 4][j][k % 4] -- the four X operands of a float4 of A are ONE 16-byte LDS read;
+//  * two register sets, no copies: while the MFMAs of one trip run, the loads of the next trip are in flight and those of the trip
+//    after it are being issued (the first form copied `next` into `current` at the end of a trip, which waits for every load);
+//  * the panel's loads are all issued before the first LDS store (one load per loop trip with its wait was ~10 us of 47);
+//  * rows beyond m and columns beyond l are computed on clamped addresses and never stored: no select in the loop;
+//  * KS = 2: the contraction is split over two waves per 32-row group (wave (g, s) contracts the s-th half of the k range; the halves
+//    are added through LDS at the end, in a fixed order) -- 16 waves per CU instead of 8 at the same 63 KB of LDS per workgroup.
+// Tried and measured slower: fully coalesced loads (8 lanes per 128-byte line) through a wave-private LDS tile (64 us: 80 KB of LDS per
+// workgroup, one per CU); non-temporal loads (63-66 us: the later loads of a row's 128-byte line must come from the caches).
+// Requires n % 8 == 0, l % 4 == 0 and n * l * 4 <= 64 KB of LDS; 128 rows per workgroup, two workgroups per CU.
+template <int U, int KS>
+__global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                                               const float* __restrict__ x, float* __restrict__ y, uint32_t l) {
+    extern __shared__ __attribute__((aligned(16))) float sXs[];  // [n / 4][l][4] (KS = 2: at least 4 x 64 x 16 floats, the partial sums' exchange)
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, ks = tid >> 8;
     const int i = lane & 31, h = lane >> 5;
     const uint64_t row = blockIdx.x * 128ull + (uint64_t)w * 32u + (uint64_t)i;
-    const bool rin = row < m;
-    const float* pa = a + (rin ? row : 0) * n + 4 * h;
+    // this wave's k range: [k_lo, k_hi), multiples of 8
+    const uint64_t k_mid = KS == 2 ? (n / 16) * 8 : n;
+    const uint64_t k_lo = ks ? k_mid : 0, k_hi = ks ? n : k_mid;
+    const float* pa = a + (row < m ? row : 0) * n + 4 * h;
+    const uint64_t full = (k_hi - k_lo) / (8 * U);  // whole trips of U loads
+    float4 buf0[U], buf1[U];
+    auto issue = [&](float4 (&buf)[U], uint64_t k) {
+#pragma unroll
+        for (int u = 0; u < U; u++) buf[u] = *reinterpret_cast<const float4*>(pa + k + 8 * u);
+    };
+    if (full) issue(buf0, k_lo);  // the first trip's loads do not wait for the panel
+    const int nrem = (int)((k_hi - k_lo - full * 8 * U) / 8);  // float4 loads of the remainder (< U): issued now, used last
+    float4 rem[U > 1 ? U - 1 : 1];
+#pragma unroll
+    for (int u = 0; u < U - 1; u++) rem[u] = *reinterpret_cast<const float4*>(pa + k_lo + full * 8 * U + (u < nrem ? 8 * u : 0));
+    {
+        constexpr int XL = 4096 / (256 * KS);  // at most 64 KB = 4096 float4: XL per thread
+        const uint64_t nl = n * l;
+        float4 xs[XL];
+#pragma unroll
+        for (int q = 0; q < XL; q++) {
+            const uint64_t idx = ((uint64_t)q * 256 * KS + tid) * 4;
+            xs[q] = *reinterpret_cast<const float4*>(x + (idx < nl ? idx : nl - 4));
+        }
+#pragma unroll
+        for (int q = 0; q < XL; q++) asm volatile("" : "+v"(xs[q].x), "+v"(xs[q].y), "+v"(xs[q].z), "+v"(xs[q].w));  // (keeps the loads above the stores)
+#pragma unroll
+        for (int q = 0; q < XL; q++) {
+            const uint64_t idx = ((uint64_t)q * 256 * KS + tid) * 4;
+            if (idx < nl) {
+                const uint32_t k = (uint32_t)(idx / l), j = (uint32_t)(idx % l);  // x[k][j .. j + 3]  (l % 4 == 0)
+                float* d = sXs + ((uint64_t)(k >> 2) * l + j) * 4 + (k & 3);
+                d[0] = xs[q].x; d[4] = xs[q].y; d[8] = xs[q].z; d[12] = xs[q].w;
+            }
+        }
+    }
+    __syncthreads();
     const bool jin = (uint32_t)i < l;                 // (the B operand's lane index j = lane % 32)
-    const float* pb = sXs + (uint64_t)(4 * h) * l + (jin ? i : 0);
+    const float* pb = sXs + ((uint64_t)h * l + (jin ? i : 0)) * 4;   // + (k / 4) * l * 4 for the trip's k
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0.f;
-    uint64_t k0 = 0;
-    const uint64_t full = n / (8 * U);  // whole trips of U loads
-    float4 cur[U], nxt[U];
-    auto ld = [&](const float* p) {
-        if constexpr (NT) {
-            using v4 = __attribute__((ext_vector_type(4))) float;
-            const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
-            return make_float4(t.x, t.y, t.z, t.w);
-        } else {
-            return *reinterpret_cast<const float4*>(p);
-        }
-    };
-    if (full) {
-#pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = ld(pa + 8 * u);
-    }
-    for (uint64_t t = 0; t < full; t++, k0 += 8 * U) {
-        const bool more = t + 1 < full;
-#pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = ld(pa + (more ? k0 + 8 * U : k0) + 8 * u);
-        __builtin_amdgcn_sched_barrier(0);
+    auto contract = [&](const float4 (&buf)[U], uint64_t k) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float* b = pb + (k0 + 8 * u) * l;
-            const float b0 = jin ? b[0] : 0.f, b1 = jin ? b[l] : 0.f, b2 = jin ? b[2 * l] : 0.f, b3 = jin ? b[3 * l] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].x : 0.f, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].y : 0.f, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].z : 0.f, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? cur[u].w : 0.f, b3, acc, 0, 0, 0);
+            const float4 b = *reinterpret_cast<const float4*>(pb + (k + 8 * u) * l);  // ((k + 8 u) / 4 + h) * l * 4 floats
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, b.w, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    };
+    uint64_t k0 = k_lo, t = 0;
+    for (; t + 2 < full; t += 2, k0 += 16 * U) {  // trips t and t + 1, and a trip t + 2 exists: every issue is unconditional
+        issue(buf1, k0 + 8 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(buf0, k0);
+        issue(buf0, k0 + 16 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(buf1, k0 + 8 * U);
     }
-    for (; k0 < n; k0 += 8) {  // remainder trips
-        const float4 v = *reinterpret_cast<const float4*>(pa + k0);
-        const float* b = pb + k0 * l;
-        const float b0 = jin ? b[0] : 0.f, b1 = jin ? b[l] : 0.f, b2 = jin ? b[2 * l] : 0.f, b3 = jin ? b[3 * l] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.x : 0.f, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.y : 0.f, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.z : 0.f, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rin ? v.w : 0.f, b3, acc, 0, 0, 0);
+    if (t + 2 == full) {
+        issue(buf1, k0 + 8 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(buf0, k0);
+        contract(buf1, k0 + 8 * U);
+        k0 += 16 * U;
+    } else if (t + 1 == full) {  // its data sit in buf0
+        contract(buf0, k0);
+        k0 += 8 * U;
+    }
+#pragma unroll
+    for (int u = 0; u < U - 1; u++) {  // remainder (loaded at the start)
+        if (u < nrem) {
+            const float4 b = *reinterpret_cast<const float4*>(pb + (k0 + 8 * u) * l);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].w, b.w, acc, 0, 0, 0);
+        }
+    }
+    if constexpr (KS == 2) {  // upper half -> LDS -> lower half adds (low + high: one fixed order)
+        __syncthreads();      // every wave is done with the panel
+        float* ex = sXs + ((uint64_t)w * 64 + lane) * 16;
+        if (ks) {
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) *reinterpret_cast<float4*>(ex + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+        }
+        __syncthreads();
+        if (ks) return;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(ex + q);
+            acc[q] += v.x; acc[q + 1] += v.y; acc[q + 2] += v.z; acc[q + 3] += v.w;
+        }
     }
     if (jin) {
         const uint64_t rb = blockIdx.x * 128ull + (uint64_t)w * 32u;
@@ -366,19 +416,99 @@ __global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_kernel(const float
     }
 }
 
+// The same product with two register sets (round 3; n % 4 == 0): while the MFMAs of one trip run, the loads of the next trip are in
+// flight and those of the trip after it are being issued -- the form above issues a trip's loads only after the previous trip's
+// MFMAs and relies on the other waves to cover the gap.  Chunks sized so that the grid is about two workgroups per CU (a wave then
+// runs ~20 trips instead of 2); rows beyond the chunk are read from clamped addresses and contracted against a zero X operand.
+__global__ void __launch_bounds__(256) dense_t_mul_panel_mfma_pp_kernel(const float* __restrict__ a, uint64_t m, uint64_t n,
+                                                                           const float* __restrict__ x, float* __restrict__ partial,
+                                                                           uint32_t l, uint64_t rows_per_chunk) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t c0 = blockIdx.x * 128ull;
+    const uint64_t chunk = blockIdx.y;
+    const uint64_t i0 = chunk * rows_per_chunk;
+    const uint64_t i1 = i0 + rows_per_chunk < m ? i0 + rows_per_chunk : m;
+    const uint64_t col = c0 + 4ull * (lane & 31);
+    const int kh = lane >> 5;
+    const bool jok = (uint32_t)(lane & 31) < l;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+    constexpr int U = 4;
+    const uint64_t colc = col < n ? col : 0;           // (a strip's columns beyond n are computed on column 0 and never stored)
+    const uint32_t jc = jok ? (uint32_t)(lane & 31) : 0u;
+    const float* pa = a + colc;
+    const float* px = x + jc;
+    float4 a0[U], a1[U];
+    float b0[U], b1[U];
+    auto issue = [&](float4 (&av)[U], float (&bv)[U], uint64_t r0) {
+#pragma unroll
+        for (int uu = 0; uu < U; uu++) {
+            const uint64_t rr = r0 + 8 * (uint64_t)uu + kh;
+            const uint64_t rc = rr < i1 ? rr : i0;
+            av[uu] = *reinterpret_cast<const float4*>(pa + rc * n);
+            bv[uu] = px[rc * l];
+        }
+    };
+    auto contract = [&](const float4 (&av)[U], const float (&bv)[U], uint64_t r0) {
+#pragma unroll
+        for (int uu = 0; uu < U; uu++) {
+            const float b = (r0 + 8 * (uint64_t)uu + kh < i1) ? bv[uu] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[uu].x, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[uu].y, b, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[uu].z, b, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[uu].w, b, acc[3], 0, 0, 0);
+        }
+    };
+    // the 4 waves of the workgroup interleave the rows of the chunk (wave w: row pairs 2 w, 2 w + 8, ...); every issue is unconditional
+    uint64_t r0 = i0 + 2 * (uint64_t)__builtin_amdgcn_readfirstlane(w);
+    issue(a0, b0, r0);
+    for (; r0 < i1; r0 += 16 * U) {  // (a third register set, two trips in flight behind the contraction, measured no faster: 47.6-49.2 us)
+        issue(a1, b1, r0 + 8 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(a0, b0, r0);
+        issue(a0, b0, r0 + 16 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(a1, b1, r0 + 8 * U);
+    }
+    __shared__ float red[4 * 64 * 16];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // one strided column set at a time through the reduction buffer
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) red[(w * 16 + q) * 64 + lane] = acc[t][q];
+        __syncthreads();
+        if (w == 0 && jok) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float v = (red[q * 64 + lane] + red[(16 + q) * 64 + lane]) + (red[(32 + q) * 64 + lane] + red[(48 + q) * 64 + lane]);
+                const uint64_t irow = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);  // row of the MFMA output tile
+                const uint64_t crow = c0 + 4 * irow + t;                          // = column of A (strided set t)
+                if (crow < n) partial[(chunk * n + crow) * l + (lane & 31)] = v;
+            }
+        }
+    }
+}
+
 __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t chunks, uint64_t count, float* __restrict__ out) {
     uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= count) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // fixed 4-way interleave: deterministic, four loads in flight
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;  // fixed 8-way interleave: deterministic, eight loads in flight
     uint64_t r = 0;
-    for (; r + 4 <= chunks; r += 4) {
+    for (; r + 8 <= chunks; r += 8) {
         s0 += partial[r * count + i];
         s1 += partial[(r + 1) * count + i];
         s2 += partial[(r + 2) * count + i];
         s3 += partial[(r + 3) * count + i];
+        s4 += partial[(r + 4) * count + i];
+        s5 += partial[(r + 5) * count + i];
+        s6 += partial[(r + 6) * count + i];
+        s7 += partial[(r + 7) * count + i];
     }
     for (; r < chunks; r++) s0 += partial[r * count + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    out[i] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
 }
 
 constexpr int kGramTile = 64;
@@ -944,10 +1074,14 @@ void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l
         constexpr int BM = 128;  // (64-row workgroups measured 5 % slower)
         const unsigned g2 = blocks_for(a.nrows, BM);
         const size_t x_bytes = (size_t)a.ncols * l * sizeof(float);
-        if (a.ncols % 8 == 0 && x_bytes <= 64 * 1024 && !debug_knob("AE_MFMA_TILED")) {  // the panel fits in LDS: barrier-free streaming form
-            // (U = 2 / 4 / 8 loads per trip: 46.4 / 47.8 / 48.4 us; non-temporal loads: 63-66 us -- the later trips of a row's 128-byte line
-            // must come from the caches)
-            hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, false>), dim3(g2), dim3(256), x_bytes, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+        if (a.ncols % 8 == 0 && l % 4 == 0 && x_bytes <= 64 * 1024 && !debug_knob("AE_MFMA_TILED")) {  // the panel fits in LDS: barrier-free streaming form
+            const size_t lds = std::max<size_t>(x_bytes, 4 * 64 * 16 * sizeof(float));
+            // (U = 2 / 3 / 4 / 6 / 8 loads per trip: 37.4 / 37.4 / 36.2 / 36.4 / 36.7 us; the contraction split over two waves per row group,
+            // 16 waves per CU: 39 us)
+            if (debug_knob("AE_SVD_KSPLIT"))
+                hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, 2>), dim3(g2), dim3(512), lds, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+            else
+                hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, 1>), dim3(g2), dim3(256), lds, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
             check_launch("dense_mul_panel_mfma_stream");
             return;
         }
@@ -1002,12 +1136,18 @@ void mat_t_mul_panel(ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
     const uint64_t m = a.nrows, n = a.ncols;
     if (l <= 32 && !debug_knob("AE_NO_MFMA")) {  // matrix-core path: 32-column tiles x row chunks, then a deterministic reduce
         const uint64_t ctiles = (n + 127) / 128;  // strips of 128 columns
-        uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, std::max<uint64_t>(1, 2048 / ctiles)));
+        const bool pp = n % 4 == 0 && !debug_knob("AE_SVD_T_OLD");
+        // the two-buffer form wants long chunks: about two workgroups per CU (256 CUs) in all (256 / 512 / 768 / 1024 workgroups: 46.7 / 46.7 /
+        // 49.8 / 54.6 us per product at 60000 x 784); the older form many short ones
+        uint64_t chunks = std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, std::max<uint64_t>(1, (pp ? 512 : 2048) / ctiles)));
         const uint64_t rpc = ((m + chunks - 1) / chunks + 7) & ~7ull;
         chunks = (m + rpc - 1) / rpc;
         static DevBuf<float> part;
         if (part.n < chunks * n * l) { sync(); part.alloc(chunks * n * l); }
-        if (n % 4 == 0)
+        if (pp)
+            hipLaunchKernelGGL(dense_t_mul_panel_mfma_pp_kernel, dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m,
+                               n, d_x, part.p, l, rpc);
+        else if (n % 4 == 0)
             hipLaunchKernelGGL((dense_t_mul_panel_mfma_kernel<true>), dim3((unsigned)ctiles, (unsigned)chunks), dim3(256), 0, stream(), a.values.p, m,
                                n, d_x, part.p, l, rpc);
         else
