@@ -323,12 +323,14 @@ template <int NF>
 __device__ __forceinline__ void coop_issue(const float* __restrict__ base, uint32_t idx, bool want, f4 (&pc)[NF / 4]) {
     constexpr int G = NF / 4;
     const uint32_t sub = (threadIdx.x & 63) & (G - 1);
-    const uint32_t word = idx | (want ? 0x80000000u : 0u);
+    // UNCONDITIONAL loads (a lane that wants nothing asks for record 0: one shared line): a load under `if (want)` makes the register
+    // allocator merge the two paths with a copy behind the load -- an `s_waitcnt vmcnt(0)` in the middle of the issue phase, which
+    // also drains the tile's loads (seen in the ISA of sl_direct_kernel<8,16>)
+    const uint32_t word = want ? idx : 0u;
 #pragma unroll
     for (int t = 0; t < G; t++) {
         const uint32_t wt = group_bcast<G>(word, t);
-        pc[t] = f4{0.f, 0.f, 0.f, 0.f};
-        if (wt & 0x80000000u) pc[t] = *reinterpret_cast<const f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * NF + sub * 4u);
+        pc[t] = *reinterpret_cast<const f4*>(base + (uint64_t)wt * NF + sub * 4u);
     }
 }
 template <int NF>
@@ -367,7 +369,7 @@ struct RowFetch {  // a coordinate row on its way to its lane
     f4 pc[kCoopRow<DIM> ? DIM / 4 : 1];
     __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want, float* out) {
         if constexpr (kCoopRow<DIM>) coop_issue<DIM>(y, node, want, pc);
-        else if (want) load_row<DIM>(y, node, out);
+        else load_row<DIM>(y, want ? node : 0u, out);
     }
     __device__ __forceinline__ void land(float* stage, float* out) {
         if constexpr (kCoopRow<DIM>) {
@@ -648,8 +650,11 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
     const uint32_t wkey = pcg_hash(nkey + a.step_seq * 0x85EBCA6Bu) + blockIdx.x * 64u;
     uint32_t done = 0;
     const uint32_t base = a.begin + blockIdx.x * 256u * a.ept;
-    for (uint32_t r = 0; r < a.ept; r++) {
-        if (base + r * 256u >= a.end) break;  // (uniform over the workgroup)
+    // one pass over 256 events; FIRST (a compile-time tag): the pass that also stages the tile.  Kept out of the loop below so that the
+    // wait for the event load counts the tile's loads behind it (`vmcnt(pieces)`); with a run-time `r == 0` the compiler has to assume
+    // the path without them and waits for everything: the tile's random reads became a hop of their own in front of the rows.
+    auto pass = [&](uint32_t r, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const uint32_t p = base + r * 256u + threadIdx.x;
         // hop 1: the event (coalesced) and, beside it, this thread's share of the tile
         bool act = p < a.end;
@@ -661,7 +666,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
             if (p + 1 < a.end) next_im = a.ev[p + 1].im;
         }
         TileFetch<DIM> ft;
-        if constexpr (TILE) { if (r == 0) ft.issue(c, wkey, hub); }
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
         uint32_t run = 1;
         if (act && prev_im == e.im) act = false;  // a repeat of the previous event's edge: its first lane runs the whole run
         else if (act && next_im == e.im) { run = 2; while (p + run < a.end && a.ev[p + run].im == e.im) run++; }
@@ -675,7 +680,7 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
         fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
         fi.issue(c.y, i, act, yi);     // :1185
         fj.issue(c.y, e.j, act, yj);   // :1186
-        if constexpr (TILE) { if (r == 0) ft.land(s_tile, s_tnode); }
+        if constexpr (TILE && FIRST) ft.land(s_tile, s_tnode);
         fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
         fi.land(stage, yi);
         fj.land(stage, yj);
@@ -696,7 +701,9 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
         } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
             row_store<DIM>(c.y, i, act, stage, yi);
         }
-    }
+    };
+    if (base < a.end) pass(0u, std::true_type{});  // (uniform over the workgroup)
+    for (uint32_t r = 1; r < a.ept && base + r * 256u < a.end; r++) pass(r, std::false_type{});
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
 }
