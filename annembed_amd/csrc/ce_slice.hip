@@ -760,22 +760,20 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
     const bool hub = c.hub_odds != nullptr;
     const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
     const uint32_t wkey = pcg_hash(nkey + a.pass_seq * 0x9E3779B9u) + (blockIdx.x * (uint32_t)kSub + sub) * 64u;
-    if constexpr (TILE) {
-        TileFetch<DIM> ft;
-        ft.issue(c, wkey, hub);
-        ft.land(s_tile, s_tnode);
-    }
     float* stage = s_stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
     unsigned long long done = 0;
-    for (uint64_t t0 = blockIdx.x * 256ull; t0 < total; t0 += (uint64_t)gridDim.x * 256ull) {
+    // one trip over 256 pending events; FIRST (compile-time, see sl_direct_kernel): the trip that also stages the tile -- its loads are
+    // issued behind the ownership checks and travel while the rows are requested
+    auto trip = [&](uint64_t t0, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const uint64_t t = t0 + threadIdx.x;
         const bool have = t < total;
-        Pending p{0, 0, 0, 0};
-        bool win = false;
-        if (have) {
-            p = a.lists[so + t];
-            win = own_chk[p.im >> 5] == p.idx && own_chk[p.j] == p.idx;
-        }
+        Pending p = a.lists[so + (have ? t : 0)];
+        if (!have) p = Pending{0, 0, 0, 0};
+        const uint32_t o1 = own_chk[p.im >> 5], o2 = own_chk[p.j];
+        TileFetch<DIM> ft;
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
+        const bool win = have && o1 == p.idx && o2 == p.idx;
         const uint32_t i = p.im >> 5, idx = p.idx;
         // everything that depends only on (i, j): both rows, the static record of i -- in flight together.  Plain (cached) loads: a
         // pass is a launch of its own, everything earlier passes wrote is visible, and the rows this event owns are touched by
@@ -787,6 +785,7 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         fr.issue(a.srec, i, p.im & 31u, win, scale_f, w, nbr_reg);
         fi.issue(c.y, i, win, yi);
         fj.issue(c.y, p.j, win, yj);
+        if constexpr (TILE && FIRST) ft.land(s_tile, s_tnode);
         fr.land(stage, p.im & 31u, win, scale_f, w, nbr_reg);
         fi.land(stage, yi);
         fj.land(stage, yj);
@@ -825,7 +824,11 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
             }
         }
         __syncthreads();  // s_wave_cnt / s_base are reused by the next trip
-    }
+    };
+    // (a tile pass is a slice's first: its grid covers the list in one trip; a workgroup without events leaves at once)
+    const uint64_t t_first = blockIdx.x * 256ull, t_step = (uint64_t)gridDim.x * 256ull;
+    if (t_first < total) trip(t_first, std::true_type{});
+    for (uint64_t t0 = t_first + t_step; t0 < total; t0 += t_step) trip(t0, std::false_type{});
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;

