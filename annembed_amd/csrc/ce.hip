@@ -418,6 +418,13 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
         float negs[(RELAXED && DIM <= 16) ? 5 : 1][DIM];  // relaxed form: the negatives' rows as of the current trip
         double scale = 1.;
         if (!finished) scale = (double)c.emb_scale[node[0]];
+        // (Round 3, read off the ISA: under `if (pending bit)` every slot's poll is load - s_waitcnt vmcnt(0) - use, up to NR round trips
+        // in a row per trip, and the per-sample set-up above is six dependent round trips.  Issuing all polls of a trip together
+        // (unconditionally, a dropped result for slots that are not pending) and the set-up in two batches was built and measured: C2
+        // ordered launch 4.42 against 4.48 ms, exact 8.87 against 9.15 -- nothing -- and the C3 shape, which is throughput-bound, LOST
+        // 8-15 % to the extra requests (ordered 41.1 -> 44.4 ms, exact 68.1 -> 78.2).  Skipping the negatives' re-reads while both end
+        // points are outstanding: 4.61 against 4.64 ms.  A level of the chain costs the store's way to the memory side plus the poll
+        // that finds it, whatever else the trip does; the conditional form stays.)
         while (!__all(finished)) {
             if (!finished) {
 #pragma unroll
