@@ -916,19 +916,24 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 // AE_CE_AUTO resolves to the fastest mode whose output is the reference's: for batches of up to kAutoOrderedSamples
 // samples the ordered dataflow (AE_CE_ORDERED: the sequential order, end points sequentially consistent, negatives as the memory
 // system has them -- half the latency of the bit-exact AE_CE_SEQUENTIAL, which stays the parity mode, by name), beyond that the
-// time-sliced mode (throughput-bound, a tenth of the memory; measured cross-over ~30 M samples per batch).  Every asked_dim in
+// time-sliced mode (throughput-bound, a tenth of the memory).  The cross-over depends on the graph: ~30 M samples per batch on the
+// node-permuted lattice of the scale benchmarks (uniform in-degree: few conflicts, the time-sliced mode's best case), ~250 M on the
+// exact kNN graph of Higgs-shaped points with hubness weighting (1.65 M nodes / 100 M samples: ordered 50 ms, sliced 67; 3.3 M / 200 M:
+// 102 against 110 ms) -- the rule follows the real graph.  Every asked_dim in
 // [1, 64] has both (rows are stored zero-padded, ce_internal.h).  A sharded node range has no faithful schedule: AUTO refuses it
 // -- the caller asks for the approximate rounds mode (AE_CE_HOGWILD) by name.
-constexpr uint64_t kAutoOrderedSamples = 1ull << 25;
+constexpr uint64_t kAutoOrderedSamples = 1ull << 27;
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
-    (void)dim;
     if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;
     if (sharded)
         fail(AE_ERR_INVALID_ARG, "AE_CE_AUTO does not shard: no schedule over several devices reproduces the reference's loop "
                                  "(DESIGN 5); ask for the approximate rounds mode by name (ce_mode = AE_CE_HOGWILD) or run the whole graph on one device");
     const bool sliced_ok = max_nbng <= 32 && nnz < 0xFFFFFFFFull;
-    if (samples_per_batch <= kAutoOrderedSamples || !sliced_ok) {
+    // (the ordered dataflow's scratch: 92 bytes of plan, sorted events and predecessors per sample + two published rows; long rows
+    // at the top of the range would ask for more than a sixth of the device: 48 GB is the line)
+    const uint64_t ordered_scratch = samples_per_batch * (92ull + 8ull * ae_pad_dim((uint32_t)dim));
+    if ((samples_per_batch <= kAutoOrderedSamples && ordered_scratch <= (48ull << 30)) || !sliced_ok) {
         if (samples_per_batch >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "no faithful CE mode fits: rows of more than 32 neighbours or >= 2^32 edges with >= 2^31 samples per batch");
         return AE_CE_ORDERED;
     }

@@ -1,6 +1,6 @@
 """GPU tests at the sizes of BASELINE.json's configs (run with -m gpu on an MI355X).
 
-What is compared with what: the statistically faithful modes -- the default (AE_CE_AUTO -> the ordered dataflow up to 2^25 samples per
+What is compared with what: the statistically faithful modes -- the default (AE_CE_AUTO -> the ordered dataflow up to 2^27 samples per
 batch, the time-sliced mode beyond), AE_CE_EVENT, AE_CE_SLICED -- are held against the HIP SEQUENTIAL mode (AE_CE_SEQUENTIAL) on the
 full schedules of the reference's examples, NOT against the oracle directly: the oracle's sequential loop takes minutes at these sizes.
 That is sound only because the sequential mode itself is pinned to the oracle bit for bit elsewhere -- tests/test_gpu_parity.py:
