@@ -156,8 +156,9 @@ def test_c3_schedule_hierarchical_60k(A):
 
 def test_c3_full_size_properties(A):
     """configs[2] at full size: 1 650 000 x 28 Higgs-shaped points, k = 6, hierarchical (small graph = first n / 24 points),
-    through Embedder.from_hkgraph(...).embed() with the default mode (the sequential-equivalent dataflow on both graphs).  Size-independent properties: finite, centred initial box,
-    embedding inside the reference's clipping envelope, CE reported for both ends."""
+    through Embedder.from_hkgraph(...).embed() with the default mode (the ordered dataflow on both graphs: 99 M samples per batch on the
+    large one, below AE_CE_AUTO's 2^27).  Size-independent properties: finite, centred initial box, embedding inside the reference's
+    clipping envelope, CE reported for both ends."""
     import torch
     n, k = 1650000, 6
     x = _blobs(n)
@@ -180,6 +181,10 @@ def test_c3_full_size_properties(A):
     torch.cuda.empty_cache()
     par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
                            nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True)
+    y_probe = np.zeros((n, 2), np.float32)
+    probe = A.EntropyOptim(large, A.to_proba_edges(large, 0.75, 1.0), par, y_probe, hub_counts=large.hubness())
+    assert probe.get_ce_mode() == A.AE_CE_ORDERED  # what AE_CE_AUTO resolves to on the large graph (exact kNN with hubs: ordered 50 ms per batch, sliced 67)
+    del probe, y_probe
     emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn_h, pd_h), par)
     assert emb.embed() == 1
     y, y0 = emb.get_embedded(), emb.get_initial_embedding()
