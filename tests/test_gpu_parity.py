@@ -243,6 +243,26 @@ def test_sequential_sgd_bit_exact(A, oracle, graph, dim):
     assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
 
 
+def test_sequential_look_ahead_any_call_pattern(A, oracle, graph):
+    """The exact mode prepares batch (S, iter + 1) on a second stream while batch (S, iter) runs (ce.hip, round 3).  Whatever the
+    caller does next -- the expected batch, another size, an index that skips, a repeated index, other calls in between, a
+    handle destroyed with a prepared set nobody asked for -- the coordinates stay the oracle's, bit for bit."""
+    eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1)
+    S = 10 * eo.get_nb_edges()
+    calls = [(S, 1.5, 1), (S, 1.4, 2), (S // 2, 1.3, 3), (S // 2, 1.2, 4), (S, 1.1, 7), (S, 1.0, 7), (S, 0.9, 8), (S + 1000, 0.8, 9)]
+    for n_call, (ns, step, it) in enumerate(calls):
+        eo.gradient_iteration_threaded(ns, step, it)
+        oo.gradient_iteration(ns, step, it)
+        if n_call % 3 == 1:  # other entry points between two batches
+            assert abs(eo.ce_compute_threaded() - oo.ce()) < 1e-11 * oo.ce()
+        assert np.array_equal(eo.get_embedded(), oo.y), "call %d %s" % (n_call, (ns, step, it))
+    del eo  # a prepared set for (S + 1000, 10) is in flight or waiting: the destructor must drain it
+    eo2, oo2, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1)
+    eo2.gradient_iteration_threaded(S, 1.0, 1)
+    oo2.gradient_iteration(S, 1.0, 1)
+    assert np.array_equal(eo2.get_embedded(), oo2.y)
+
+
 @pytest.mark.parametrize("sampler,hub", [(1, False), (0, True)])
 def test_sequential_sgd_bit_exact_samplers(A, oracle, graph, sampler, hub):
     eo, oo, _ = _ce_pair(A, oracle, graph, 2, ce_mode=1, ce_sampler=sampler, hubness_weighting=hub)
