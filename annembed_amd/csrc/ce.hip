@@ -118,12 +118,31 @@ __device__ __forceinline__ bool make_plan_rows(const CeDev& c, uint64_t s, uint3
     }
     row_bounds(c, p.i, ib, ilen);
     uint32_t nb[KMAX];
+    float pr[KMAX];
+    // The row and its KMAX - ilen successors in ONE unconditional read (wide loads; entries beyond the row masked afterwards): under
+    // `t < ilen ? load : sentinel` every entry is a load instruction of its own, 2 KMAX address-unit passes per sample -- what bound
+    // the kernel.  Only the rows at the very end of the arrays (where the read would leave them) take the entry-wise form.
+    if (ib + KMAX <= c.nnz) {
 #pragma unroll
-    for (int t = 0; t < KMAX; t++) nb[t] = (uint32_t)t < ilen ? c.nbr[ib + t] : 0xFFFFFFFFu;  // node ids are < n < 2^32 - 1
+        for (int t = 0; t < KMAX; t++) nb[t] = c.nbr[ib + t];
+        if (rowcdf) {
+#pragma unroll
+            for (int t = 0; t < KMAX; t++) pr[t] = c.proba[ib + t];
+        }
+#pragma unroll
+        for (int t = 0; t < KMAX; t++) {
+            nb[t] = (uint32_t)t < ilen ? nb[t] : 0xFFFFFFFFu;  // node ids are < n < 2^32 - 1
+            if (rowcdf) pr[t] = (uint32_t)t < ilen ? pr[t] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < KMAX; t++) nb[t] = (uint32_t)t < ilen ? c.nbr[ib + t] : 0xFFFFFFFFu;
+        if (rowcdf) {
+#pragma unroll
+            for (int t = 0; t < KMAX; t++) pr[t] = (uint32_t)t < ilen ? c.proba[ib + t] : 0.f;
+        }
+    }
     if (rowcdf) {
-        float pr[KMAX];
-#pragma unroll
-        for (int t = 0; t < KMAX; t++) pr[t] = (uint32_t)t < ilen ? c.proba[ib + t] : 0.f;
         float acc = 0.f;
         uint32_t m = 0;
 #pragma unroll
