@@ -27,6 +27,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
 #include <random>
 
 using namespace ae;
@@ -863,17 +864,22 @@ void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
 }
 
 // stable (LSD radix) sort of (step key, event) pairs on the key bits [0, end_bit)
-void sort_events(uint32_t* keys_in, uint32_t* keys_out, Event* vals_in, Event* vals_out, uint64_t count, unsigned end_bit) {
+// Sorts the events by their (slice, class) key between the two buffer pairs; returns true if the result sits in the second pair.
+// rocPRIM's double-buffer form: the caller's two pairs ARE the ping-pong buffers, the temporary storage is histograms only.  (The
+// in/out form asks for a full copy of keys and values as temporary storage -- 7.6 GB at the C4 shape -- and its size follows the
+// batch's event count: whenever a batch set a new record the stream-ordered pool had to get a fresh block from the driver, 1.5-2 s,
+// a few times per run.  Found in round 3 as C4-shape batches of 300-900 ms among batches of 121 ms.)
+bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned end_bit) {
     static_assert(sizeof(Event) == 8, "events are sorted as 64-bit values");
-    unsigned long long* vi = reinterpret_cast<unsigned long long*>(vals_in);
-    unsigned long long* vo = reinterpret_cast<unsigned long long*>(vals_out);
+    rocprim::double_buffer<uint32_t> dk(keys_a, keys_b);
+    rocprim::double_buffer<unsigned long long> dv(reinterpret_cast<unsigned long long*>(vals_a), reinterpret_cast<unsigned long long*>(vals_b));
     size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vi, vo, count, 0, end_bit, stream()) != hipSuccess)
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, 0, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
-    DevBuf<char> tmp;
-    tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-    if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys_out, vi, vo, count, 0, end_bit, stream()) != hipSuccess)
+    if (o->sl_sort_tmp.n < tmp_bytes + 1) o->sl_sort_tmp.alloc(2 * tmp_bytes + 4096);  // (kept with the handle: no allocation in the batch)
+    if (rocprim::radix_sort_pairs(o->sl_sort_tmp.p, tmp_bytes, dk, dv, count, 0, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs failed");
+    return dk.current() == keys_b;
 }
 
 }  // namespace
@@ -1067,6 +1073,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t ept_force = debug_knob("AE_SL_EPT") ? (uint32_t)std::max(1, atoi(debug_knob("AE_SL_EPT"))) : 0u;
     uint32_t pass_seq = 0, step_seq = 0;
     int cur = 0;  // list that holds what is pending
+    const bool prof = debug_knob("AE_CE_PROF") != nullptr;
+    auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_evgen = 0., t_enqueue = 0., t_drain = 0.;
+    int drain_iterations = 0;
+    const double t_begin = wall();
     o->sl_counts.zero();
     std::vector<uint8_t> class_pos((size_t)n_slices * std::max(1u, classes));
     std::vector<uint32_t> hptr(n_keys + 2);
@@ -1074,6 +1085,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     Event* ev1 = reinterpret_cast<Event*>(o->sl_vals1.p);
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
+        const double t_seg = wall();
         // the order of the classes inside every slice: a fresh uniform permutation (so the order of two events that share a node is
         // uniform, as in an i.i.d. sequence)
         {
@@ -1099,18 +1111,30 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
         AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
         sync();
+        const double t_cnt = wall();
         const uint32_t total = last[0] + last[1];
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(nnz, 256)), dim3(256), 0, stream(), o->dev, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, reinterpret_cast<const EdgeRec*>(o->sl_erec.p), (const uint8_t*)o->sl_color.p,
                            (const uint8_t*)o->sl_class_pos.p, classes, spread, o->sl_keys0.p, ev0);
-        sort_events(o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbits);
-        hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)o->sl_keys1.p, total, (uint32_t)n_keys,
+        if (prof) sync();
+        const double t_fill = wall();
+        const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbits);
+        const uint32_t* sorted_keys = in_second ? o->sl_keys1.p : o->sl_keys0.p;
+        Event* sorted_ev = in_second ? ev1 : ev0;
+        if (prof) sync();
+        const double t_sort = wall();
+        hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), sorted_keys, total, (uint32_t)n_keys,
                            o->sl_sptr.p);
         check_launch("sl_events");
         o->sl_sptr.download(hptr.data(), n_keys + 1);
-        a.ev = ev1;
-        da.ev = ev1;
+        const double t_ev = wall();
+        t_evgen += t_ev - t_seg;
+        if (prof && t_ev - t_seg > 0.1)
+            fprintf(stderr, "CESLICE slow event generation: permutation + count + scan %.1f ms, fill %.1f ms, sort %.1f ms, slice pointers + download %.1f ms\n",
+                    (t_cnt - t_seg) * 1e3, (t_fill - t_cnt) * 1e3, (t_sort - t_fill) * 1e3, (t_ev - t_sort) * 1e3);
+        a.ev = sorted_ev;
+        da.ev = sorted_ev;
         a.key = key;
         da.key = key;
         // NOTE: event indices are positions in this segment's sorted array; what is still pending when a segment ends is
@@ -1174,8 +1198,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             // the next slice's mark kernel marks in owner[0]; the last pass above marked in owner[(passes + extra) & 1]: the mark
             // kernel re-marks everything that is pending anyway
         }
+        const double t_enq = wall();
+        t_enqueue += t_enq - t_ev;
         // drain: passes until nothing is pending (a look at the counters every 8 passes)
         for (int guard = 0; has_overflow && guard < 1000000; guard++) {
+            drain_iterations++;
             uint32_t lefts[kSub];
             unsigned long long flag = 0;
             AE_HIP(hipMemcpyAsync(lefts, o->sl_counts.p + cur * kSub, 4 * kSub, hipMemcpyDeviceToHost, stream()));
@@ -1203,7 +1230,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 cur = (cur + 1) % 3;
             }
         }
+        t_drain += wall() - t_enq;
     }
+    if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
+                      t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");
     std::vector<unsigned long long> h = o->sl_done.to_host();
     o->sl_done.zero();

@@ -640,6 +640,9 @@ def pmc_traffic(mode):
 def cpu_baseline(indptr, nbr, node_params, y0, params, n, nb_batch):
     """The CPU restatement of the reference's Hogwild loop (oracle, kind "port") on the host cores,
     on a bounded sample of the same workload."""
+    # (the OpenMP workers of this leg sleep between parallel regions instead of spinning: nothing of it is left on the host cores when
+    # the launch-heavy scale shapes are timed afterwards)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import oracle as O
     proba, scale = node_params.get()
     eo = O.EntropyOptim(indptr, nbr, proba, scale, y0, b=params.b, seed=params.seed, sampler=0)
