@@ -1220,7 +1220,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(4, blocks_for(left / kSub + 256, 256)), 65535u);
             hipLaunchKernelGGL(sl_mark_kernel, dim3(grid, kSub), dim3(256), 0, stream(), a);
             cur = (cur + 1) % 3;
-            for (int p = 0; p < 8; p++) {
+            // 8 passes before the next look, then 16, 32, 64: what is left after the first looks are the events of a few hubs, one per
+            // hub and pass (a kNN graph with hubness weighting: ~750 passes at the end of a batch -- 94 looks of 8 were 4 ms of host
+            // round trips; a pass over an empty list is a 6 us launch)
+            const int n_pass = std::min(64, 8 << std::min(guard, 3));
+            for (int p = 0; p < n_pass; p++) {
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;
                 a.backoff = 1;
