@@ -30,7 +30,10 @@ npar = A.to_proba_edges(kg, 1.0, 1.0)
 auto = A.EntropyOptim(kg, npar, A.EmbedderParams(asked_dim=d, hubness_weighting=True), y0, hub_counts=hub)
 print("AE_CE_AUTO resolves to mode %d, slice info %s" % (auto.get_ce_mode(), auto.slice_info()), flush=True)
 del auto
+modes = os.environ.get("MODES", "sliced,ordered,rounds").split(",")
 for name, mode in (("sliced", A.AE_CE_SLICED), ("ordered", A.AE_CE_ORDERED), ("rounds", A.AE_CE_HOGWILD)):
+    if name not in modes:
+        continue
     r = bench.time_mode(A, L, kg, npar, y0, d, mode, 2, 1, hub=hub)
     print("%s ms/step %.1f ce_after %.0f" % (name, r["ms_per_step"], r["ce_after"]), flush=True)
     del r
