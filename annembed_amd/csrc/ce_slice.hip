@@ -944,8 +944,10 @@ static void slice_color_edges(ae_entropy_optim* o) {
     for (double v : hm) total += v;
     // How many classes run as matchings.  A step is a launch: it costs ~9 us of latency whatever it holds, and an event in it
     // 0.14 ns (rows of <= 8 columns: ~5.6 random requests at the ~55 G requests/s the memory system serves) to 0.24 ns (wider
-    // rows: one wave per SIMD); an event of the overflow class costs 0.24 - 0.28 ns (two owner marks, two checks, a pending-list
-    // trip and ~1.4 attempts) and the class two to four launches per slice.  The cut that minimises the batch time -- 0 =
+    // rows: one wave per SIMD); an event of the overflow class costs 0.26 ns on a lattice, 0.41 ns on an exact kNN graph with hubs
+    // (two owner marks, two checks, a pending-list trip and 1.4 - 2 attempts: priced at 0.30 / 0.28 ns -- on the kNN graph of 11 M
+    // Higgs-shaped points 0.24 cut at 12 classes, 180 ms per batch; 0.30 at 16, 169 ms; 0.36 at 19, 171 ms) and the class two to four
+    // launches per slice.  The cut that minimises the batch time -- 0 =
     // everything optimistic (graphs of a few million edges: their steps would hold a few thousand events), all classes = no
     // overflow (large regular graphs).  Constants measured on MI355X at the C3 / C4 / C5-shard shapes.
     uint32_t top = kMaxClasses;
@@ -960,7 +962,8 @@ static void slice_color_edges(ae_entropy_optim* o) {
             if (c < top) t += hm[c];
             const double frac = total > 0. ? t / total : 0.;
             const double launches = (double)c + (t > 0. ? (frac < 0.05 ? 2.0 : 4.0) : 0.0);
-            const double c_match = o->dev.dim <= 8 ? 0.14e-9 : 0.24e-9, c_opt = o->dev.dim <= 8 ? 0.24e-9 : 0.28e-9;
+            const double c_match = o->dev.dim <= 8 ? 0.14e-9 : 0.24e-9;
+            const double c_opt = debug_knob("AE_SL_COPT") ? atof(debug_knob("AE_SL_COPT")) * 1e-9 : (o->dev.dim <= 8 ? 0.30e-9 : 0.28e-9);
             const double cost = slices * launches * 9e-6 + events * ((1.0 - frac) * c_match + frac * c_opt);
             if (cost < best) { best = cost; cut = c; tail = t; }
         }
@@ -1021,7 +1024,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t n_slices = (uint32_t)std::max(1.0, std::ceil(2.0 * seg_samples / (double)n / lambda_s));
     // passes per slice of the overflow class: a thin one (a few per cent of the events: conflicts among them are rare) runs once and
     // carries its losers into the next slice
-    const int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
+    int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
     const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : 1;
     const bool f64 = debug_knob("AE_SL_F64") != nullptr;
     const uint32_t classes = o->sl_classes;
@@ -1034,6 +1037,20 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // more overflow events than a slice's passes can run (hubs) accumulate until the drain
     const double per_slice_ov = seg_samples / n_slices * o->sl_ov_frac;
     double backlog = 0.;
+    if (has_overflow && passes == 1 && !debug_knob("AE_SL_PASSES")) {
+        // One pass per slice serves a thin overflow class only while no ROW is busy in it: a row that receives more than a quarter of
+        // an overflow event per slice (a hub whose edges lie beyond the colour budget) queues its events behind one another, slices
+        // late -- seen as a final CE 1.5-4.7 % off on the exact kNN graph of 11 M points when the cut was forced to a 2-5 % overflow
+        // class.  Such a graph gets the three passes of a thick class.
+        DevBuf<double> d_busy;
+        d_busy.alloc_pooled(1);
+        d_busy.zero();
+        double busy = 0.;
+        hipLaunchKernelGGL(sl_backlog_kernel, dim3(grid_cap(n, 256, 1024)), dim3(256), 0, stream(), n, (const float*)o->sl_node_ov.p,
+                           (float)(seg_samples / (double)n), 0.25f * (float)n_slices, d_busy.p);
+        d_busy.download(&busy, 1);
+        if (busy > 0.) passes = 3;
+    }
     if (has_overflow) {
         DevBuf<double> d_backlog;
         d_backlog.alloc_pooled(1);

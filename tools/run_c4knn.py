@@ -30,6 +30,20 @@ npar = A.to_proba_edges(kg, 1.0, 1.0)
 auto = A.EntropyOptim(kg, npar, A.EmbedderParams(asked_dim=d, hubness_weighting=True), y0, hub_counts=hub)
 print("AE_CE_AUTO resolves to mode %d, slice info %s" % (auto.get_ce_mode(), auto.slice_info()), flush=True)
 del auto
+for tail in [t for t in os.environ.get("TAILS", "").split(",") if t]:  # A/B of the class cut (debug knob AE_SL_TAIL: the tail of classes with at most this share of the mass joins the overflow class)
+    os.environ["AE_DEBUG_KNOBS"] = "1"
+    os.environ["AE_SL_TAIL"] = tail
+    r = bench.time_mode(A, L, kg, npar, y0, d, A.AE_CE_SLICED, 2, 1, hub=hub)
+    print("sliced, tail %s: ms/step %.1f ce_after %.0f info %s" % (tail, r["ms_per_step"], r["ce_after"], r["eo"].slice_info()), flush=True)
+    del r
+    os.environ.pop("AE_SL_TAIL")
+for copt in [t for t in os.environ.get("COPTS", "").split(",") if t]:  # A/B of the cost model's price of an optimistic event (ns)
+    os.environ["AE_DEBUG_KNOBS"] = "1"
+    os.environ["AE_SL_COPT"] = copt
+    r = bench.time_mode(A, L, kg, npar, y0, d, A.AE_CE_SLICED, 2, 1, hub=hub)
+    print("sliced, optimistic event priced at %s ns: ms/step %.1f ce_after %.0f info %s" % (copt, r["ms_per_step"], r["ce_after"], r["eo"].slice_info()), flush=True)
+    del r
+    os.environ.pop("AE_SL_COPT")
 modes = os.environ.get("MODES", "sliced,ordered,rounds").split(",")
 for name, mode in (("sliced", A.AE_CE_SLICED), ("ordered", A.AE_CE_ORDERED), ("rounds", A.AE_CE_HOGWILD)):
     if name not in modes:
