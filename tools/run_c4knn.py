@@ -45,6 +45,19 @@ for copt in [t for t in os.environ.get("COPTS", "").split(",") if t]:  # A/B of 
     del r
     os.environ.pop("AE_SL_COPT")
 modes = os.environ.get("MODES", "sliced,ordered,rounds").split(",")
+if "embed" in modes:  # configs[3] end to end on ONE GPU: Embedder.embed() in the default mode (diffusion-map initialisation + 40 batches), then the quality estimate
+    par = A.EmbedderParams(asked_dim=d, nb_grad_batch=40, scale_rho=0.75, beta=1.0, grad_step=1.0, nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True)
+    emb = A.Embedder(kg, par)
+    L.check(L.load().ae_synchronize())
+    t0 = time.perf_counter()
+    rc = emb.embed()
+    t_embed = time.perf_counter() - t0
+    y = emb.get_embedded()
+    print("embed() rc %d in %.2f s, finite %s, cross entropy before / after %s" % (rc, t_embed, bool(np.isfinite(y).all()), emb.get_cross_entropy()), flush=True)
+    t0 = time.perf_counter()
+    q = emb.get_quality_estimate_from_edge_length(50)
+    print("quality estimate in %.2f s" % (time.perf_counter() - t0), flush=True)
+    del emb
 for name, mode in (("sliced", A.AE_CE_SLICED), ("ordered", A.AE_CE_ORDERED), ("rounds", A.AE_CE_HOGWILD)):
     if name not in modes:
         continue
