@@ -101,7 +101,9 @@ enum {
     AE_CE_HOGWILD = 0,
     /* Deterministic: the result of executing samples 0,1,2,... of the reference's `gradient_iteration`
        (src/embedder.rs:1305-1309) in order, obtained by a device-side dataflow over row versions.  Bit-exact against the
-       CPU oracle; the parity mode. */
+       CPU oracle; the parity mode.  For batches of up to 2^24 samples the plan of batch (nb_sample, iter + 1) is prepared on two
+       internal CU-masked streams while batch (nb_sample, iter) runs (any other next call is prepared afresh: the result never
+       depends on it); ae_entropy_optim_destroy waits for a prepared set nobody asked for. */
     AE_CE_SEQUENTIAL = 1,
     /* One thread per sample with racy read-modify-write of both end points, the literal transcription
        of the rayon loop.  Kept for comparison only: on a GPU with more lanes than nodes most updates are
