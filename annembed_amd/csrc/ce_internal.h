@@ -120,6 +120,7 @@ struct ae_entropy_optim {
     // time-sliced optimistic mode (ce_slice.hip)
     DevBuf<uint32_t> sl_erec, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
     DevBuf<unsigned long long> sl_done;
+    DevBuf<uint32_t> sl_chain_head, sl_chain_next;  // chain rounds: per node the head of its pending in-events' list (kept all-NIL between rounds), per list position the next link
     DevBuf<char> sl_sort_tmp;                   // rocPRIM's temporary storage of the event sort (histograms), kept with the handle
     float sl_pmax = 0.f;
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice

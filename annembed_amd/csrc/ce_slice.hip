@@ -835,6 +835,106 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// chain rounds: what is still pending after a slice's passes belongs to a few busy rows (hubs: in-degrees in the thousands on kNN
+// graphs of high-dimensional data), and a pass runs ONE event per row.  A chain round runs ALL pending events of a target row in one
+// lane, the row in registers: (1) link: every pending event pushes itself on its target's list (atomicExch on a head word) and claims
+// its source (owner word, last writer wins); (2) run: the event that ended up at the head of a list walks it -- an event runs if it
+// owns its source and the source is not itself the target of a list of this round (its row would be in another lane's registers),
+// otherwise it goes to the next pending list; (3) unlink: the heads are cleared.  ~2 us per event of a chain (three dependent
+// round trips, the next link prefetched) instead of a pass of its own (a 6-8 us launch).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kNil = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) sl_chain_link_kernel(SliceArgs a, uint32_t* __restrict__ head, uint32_t* __restrict__ next) {
+    const uint32_t sub = blockIdx.y;
+    const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    const uint32_t coin = pcg_hash(a.pass_seq ^ kTagSlCoin);
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
+        const Pending p = a.lists[so + t];
+        const uint32_t pos = (uint32_t)((uint64_t)sub * a.cap + t);
+        // Half of the targets (a fresh coin per node and round) have their lists walked in a round; the events of the others go
+        // straight to the next list.  Two pending events i -> j and j -> i would otherwise wait for each other's row for ever (each
+        // source is the target of a walked list); with the coin one of the two rows is free in half of the rounds.  (Tossing the coin
+        // only for targets that are also sources of pending events was tried: more rounds, not fewer.)
+        if (pcg_hash(p.j ^ coin) & 1u) {
+            next[pos] = atomicExch(&head[p.j], pos);
+            a.owner[p.im >> 5] = p.idx;
+        } else {
+            next[pos] = kNil;
+            const uint32_t dsub = (pos + blockIdx.x) % (uint32_t)kSub;
+            const uint32_t at = atomicAdd(&a.counts[a.dst_list * kSub + dsub], 1u);
+            if (at < a.cap) a.lists[((uint64_t)a.dst_list * kSub + dsub) * a.cap + at] = p;
+            else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) sl_chain_unlink_kernel(SliceArgs a, uint32_t* __restrict__ head) {
+    const uint32_t sub = blockIdx.y;
+    const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) head[a.lists[so + t].j] = kNil;
+}
+template <int DIM, int SREC>
+__global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next) {
+    constexpr int KP = (SREC - 1) / 2, KREG = KP < 32 ? KP : 32;
+    const CeDev c = a.c;
+    const uint32_t sub = blockIdx.y;
+    const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    const Pending* src = a.lists + (uint64_t)a.src_list * kSub * a.cap;  // position = sub-list * cap + index
+    const bool hub = c.hub_odds != nullptr;
+    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
+    unsigned long long done = 0;
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
+        const Pending p0 = a.lists[so + t];
+        const uint32_t pos = (uint32_t)((uint64_t)sub * a.cap + t);
+        if (head[p0.j] != pos) continue;  // the head of its target's list walks it
+        float yj[DIM];
+        load_row<DIM>(c.y, p0.j, yj);
+        uint32_t cur = pos, nxt = next[pos];
+        Pending e = p0;
+        for (;;) {
+            Pending en{0u, 0u, 0u, 0u};
+            uint32_t nn = kNil;
+            if (nxt != kNil) { en = src[nxt]; nn = next[nxt]; }  // the next link travels while this event runs
+            const uint32_t i = e.im >> 5;
+            if (a.owner[i] == e.idx && head[i] == kNil) {
+                float yi[DIM];
+                load_row<DIM>(c.y, i, yi);
+                const float* r = a.srec + (uint64_t)i * SREC;
+                const float scale_f = r[0], w = r[1 + KP + (e.im & 31u)];
+                uint32_t nbr_reg[KREG];
+#pragma unroll
+                for (int q = 0; q < KREG; q++) nbr_reg[q] = __float_as_uint(r[1 + q]);
+                uint32_t neg[5];
+                const uint32_t got = draw_negatives<DIM, KREG, false>(c, hub, nullptr, pcg_hash(nkey + e.idx), i, nbr_reg, neg);
+                run_sample<DIM, false, false>(c, nullptr, yi, yj, w, scale_f, a.step, neg, got);
+                store_row<DIM>(c.y, i, yi);  // :1301
+                done++;
+            } else {  // the source is claimed by another event or is a target of this round: next round
+                const uint32_t dsub = (cur + blockIdx.x) % (uint32_t)kSub;
+                const uint32_t at = atomicAdd(&a.counts[a.dst_list * kSub + dsub], 1u);
+                if (at < a.cap) a.lists[((uint64_t)a.dst_list * kSub + dsub) * a.cap + at] = e;
+                else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+            }
+            if (nxt == kNil) break;
+            cur = nxt; e = en; nxt = nn;
+        }
+        store_row<DIM>(c.y, p0.j, yj);  // :1239
+    }
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;
+}
+template <int DIM>
+void launch_chain_run(const SliceArgs& a, unsigned grid, uint32_t srec, const uint32_t* head, const uint32_t* next) {
+    if (srec == 16) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 16>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else if (srec == 32) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 32>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else if (srec == 64) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 64>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 128>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+}
+
 template <int DIM, bool F64, bool TILE>
 void launch_exec3(const SliceArgs& a, unsigned grid, uint32_t srec) {
     if (srec == 16) hipLaunchKernelGGL((sl_exec_kernel<DIM, 16, F64, TILE>), dim3(grid, kSub), dim3(256), 0, stream(), a);
@@ -1064,6 +1164,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(2 * ev_cap); o->sl_vals1.alloc(2 * ev_cap); }
     if (o->sl_sptr.n < n_keys + 2) o->sl_sptr.alloc(n_keys + 2);
     if (has_overflow && o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4);
+    if ((uint64_t)kSub * cap >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: pending lists beyond 2^32 entries");
+    if (has_overflow && o->sl_chain_next.n < (uint64_t)kSub * cap) o->sl_chain_next.alloc((uint64_t)kSub * cap);
+    if (has_overflow && o->sl_chain_head.n < n) {
+        o->sl_chain_head.alloc(n);
+        AE_HIP(hipMemsetAsync(o->sl_chain_head.p, 0xFF, sizeof(uint32_t) * n, stream()));
+    }
     if (o->sl_class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) o->sl_class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
     unsigned kbits = 1;
     while (kbits < 32 && (n_keys >> kbits)) kbits++;
@@ -1100,6 +1206,16 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     std::vector<uint32_t> hptr(n_keys + 2);
     Event* ev0 = reinterpret_cast<Event*>(o->sl_vals0.p);
     Event* ev1 = reinterpret_cast<Event*>(o->sl_vals1.p);
+    // one chain round over the pending list `cur` (see sl_chain_run_kernel); the f64-scalar debug variant keeps the passes
+    const bool use_chains = !f64 && !debug_knob("AE_SL_NO_CHAIN");
+    auto chain_round = [&](unsigned grid) {
+        a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
+        a.pass_seq = pass_seq++;
+        hipLaunchKernelGGL(sl_chain_link_kernel, dim3(grid, kSub), dim3(256), 0, stream(), a, o->sl_chain_head.p, o->sl_chain_next.p);
+        AE_DISPATCH_DIM(o->dev.dim, launch_chain_run, a, grid, o->sl_srec_floats, (const uint32_t*)o->sl_chain_head.p, (const uint32_t*)o->sl_chain_next.p);
+        hipLaunchKernelGGL(sl_chain_unlink_kernel, dim3(grid, kSub), dim3(256), 0, stream(), a, o->sl_chain_head.p);
+        cur = (cur + 1) % 3;
+    };
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
@@ -1193,7 +1309,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             // pending list is back to the size conflicts alone explain: a look at the counters every 4 extra passes.
             if (backlog > 0.01 * seg_samples) {  // (below 1 % of the events the late ones do not show: blobs k = 6 with in-degrees up to 105: CE 1.002-1.014 either way)
                 const uint64_t carry_ok = (uint64_t)(0.05 * per_slice_ov) + 16;
-                for (int extra = 0; extra < 100000; extra += 4) {
+                uint64_t prev_left = 0;
+                int prev_pass = 0;
+                bool chain_mode = false;
+                for (int extra = 0, look = 0; extra < 1000000; look++) {
                     uint32_t lefts[kSub];
                     AE_HIP(hipMemcpyAsync(lefts, o->sl_counts.p + cur * kSub, 4 * kSub, hipMemcpyDeviceToHost, stream()));
                     sync();
@@ -1201,7 +1320,19 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                     for (int q = 0; q < kSub; q++) left += lefts[q];
                     if (left <= carry_ok) break;
                     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(4, blocks_for(left / kSub + 256, 256)), 65535u);
-                    for (int p = 0; p < 4; p++) {
+                    // Passes while they make progress; a chain round (all pending events of a row in one lane) once the last passes
+                    // ran about one event per pass and row -- more than 48 further passes would be needed at that pace.
+                    const bool slow = prev_pass > 0 && (double)left * prev_pass > 48.0 * (double)std::max<uint64_t>(1, prev_left > left ? prev_left - left : 0);
+                    prev_left = left;
+                    // (Chain rounds INSIDE the slices were measured and are off: a round walks a hub's few hundred events of the slice at
+                    // ~3 us each and the coin halves that -- no better than as many passes; 6.25 M-node kNN graph of 128-D data: 1.37 s per
+                    // batch in the slices against 0.88 s.  They pay in the drain, where thousands of events of a few rows are left.)
+                    if (use_chains && debug_knob("AE_SL_CHAIN_IN_SLICE") && (slow || chain_mode)) { chain_round(grid); chain_round(grid); extra += 2; chain_mode = true; continue; }
+                    // 4, 4, 8, 16, 32, 64 passes between looks: a look is a host round trip
+                    const int n_pass = look < 2 ? 4 : std::min(64, 4 << (look - 1));
+                    extra += n_pass;
+                    prev_pass = n_pass;
+                    for (int p = 0; p < n_pass; p++) {
                         a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                         a.owner_chk = (passes + p) & 1; a.owner_mark = (passes + p + 1) & 1;
                         a.backoff = 1;
@@ -1218,6 +1349,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         const double t_enq = wall();
         t_enqueue += t_enq - t_ev;
         // drain: passes until nothing is pending (a look at the counters every 8 passes)
+        uint64_t drain_prev_left = 0;
+        int drain_prev_pass = 0;
+        bool drain_chain_mode = false;
         for (int guard = 0; has_overflow && guard < 1000000; guard++) {
             drain_iterations++;
             uint32_t lefts[kSub];
@@ -1235,12 +1369,22 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
             a.owner_mark = 0;
             const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(4, blocks_for(left / kSub + 256, 256)), 65535u);
+            // Passes while they make progress; chain rounds (all pending events of a row in one lane, sl_chain_run_kernel) for the rest of
+            // the drain once more than 512 further passes would be needed at the pace of the last ones -- thousands of events of a few rows
+            // are left, one per row and pass.  (Measured: a 10 000-in-degree hub in 1 M nodes 56 -> 41 ms per batch; the kNN graph of 128-D
+            // data, max in-degree 8 764: drain 320 -> 30 ms.  With the threshold at 48 the kNN graph of 28-D data -- in-degrees up to 133,
+            // ~750 events on the busiest row -- lost 63 -> 67-75 ms: a round costs three launches, a look and a coin.)
+            const bool slow = drain_prev_pass > 0 &&
+                              (double)left * drain_prev_pass > 512.0 * (double)std::max<uint64_t>(1, drain_prev_left > left ? drain_prev_left - left : 0);
+            drain_prev_left = left;
+            if (use_chains && (slow || drain_chain_mode)) { chain_round(grid); chain_round(grid); drain_chain_mode = true; continue; }
             hipLaunchKernelGGL(sl_mark_kernel, dim3(grid, kSub), dim3(256), 0, stream(), a);
             cur = (cur + 1) % 3;
             // 8 passes before the next look, then 16, 32, 64: what is left after the first looks are the events of a few hubs, one per
             // hub and pass (a kNN graph with hubness weighting: ~750 passes at the end of a batch -- 94 looks of 8 were 4 ms of host
             // round trips; a pass over an empty list is a 6 us launch)
             const int n_pass = std::min(64, 8 << std::min(guard, 3));
+            drain_prev_pass = n_pass;
             for (int p = 0; p < n_pass; p++) {
                 a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
                 a.owner_chk = p & 1; a.owner_mark = (p + 1) & 1;

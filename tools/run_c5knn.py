@@ -40,6 +40,8 @@ for hw in (False, True):
     print("hubness weighting %s: AE_CE_AUTO resolves to mode %d, slice info %s" % (hw, auto.get_ce_mode(), auto.slice_info()), flush=True)
     del auto
     for name, mode in (("sliced", A.AE_CE_SLICED), ("rounds", A.AE_CE_HOGWILD)):
+        if name not in os.environ.get("MODES", "sliced,rounds").split(","):
+            continue
         r = bench.time_mode(A, L, kg, npar, y0, d, mode, 2, 1, hub=h)
         print("  %s ms/step %.1f ce_after %.0f" % (name, r["ms_per_step"], r["ce_after"]), flush=True)
         del r
