@@ -5,7 +5,7 @@ Embedder / DiffusionMaps / SvdApprox) over the C ABI of libannembed_hip.so.  All
 (hand-written HIP kernels; rocPRIM sort / scan as primitives beside them); there is no CPU fallback: importing the API without the built library, or
 calling it without a GPU, fails loudly.
 """
-from ._lib import (AE_CE_AUTO, AE_CE_EVENT, AE_CE_HOGWILD, AE_CE_ORDERED, AE_CE_SAMPLE_RACY, AE_CE_SEQUENTIAL, AE_CE_SLICED, AE_SAMPLER_ALIAS, AE_SAMPLER_ROWCDF, AnnembedError, LIB_PATH,  # noqa: F401
+from ._lib import (AE_CE_AUTO, AE_CE_EVENT, AE_CE_HOGWILD, AE_CE_ORDERED, AE_CE_SAMPLE_RACY, AE_CE_SEQUENTIAL, AE_CE_SLICED, AE_PRECISION_F32, AE_PRECISION_F64, AE_SAMPLER_ALIAS, AE_SAMPLER_ROWCDF, AnnembedError, LIB_PATH,  # noqa: F401
                    load)
 from .api import (DiffusionMaps, DiffusionParams, Embedder, EmbedderParams, EntropyOptim, GraphLaplacian, KGraph,  # noqa: F401
                   KGraphProjection, MatRepr, NodeParams, QualityReport, RangeApprox, RangePrecision, RangeRank, SvdApprox, SvdResult, entropy_optimize,

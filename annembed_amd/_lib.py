@@ -30,6 +30,8 @@ AE_CE_SLICED = 5
 AE_CE_ORDERED = 6
 AE_SAMPLER_ROWCDF = 0
 AE_SAMPLER_ALIAS = 1
+AE_PRECISION_F64 = 0
+AE_PRECISION_F32 = 1
 
 
 class AnnembedError(RuntimeError):
@@ -44,6 +46,7 @@ class CEmbedderParams(C.Structure):
         ("scale_rho", C.c_double), ("grad_step", C.c_double), ("nb_sampling_by_edge", C.c_uint64),
         ("nb_grad_batch", C.c_uint64), ("grad_factor", C.c_uint64), ("hierarchy_layer", C.c_uint64),
         ("hubness_weighting", C.c_uint8), ("seed", C.c_uint64), ("ce_mode", C.c_uint32), ("ce_sampler", C.c_uint32),
+        ("ce_precision", C.c_uint32),
     ]
 
 

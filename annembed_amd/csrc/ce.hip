@@ -18,6 +18,7 @@
 
 #include "ce_internal.h"
 #include "ce_sample_math.h"
+#include "linalg.h"
 #include <chrono>
 #include "philox.h"
 
@@ -858,7 +859,12 @@ static void run_sequential_dataflow(ae_entropy_optim* o, uint64_t S, double step
     if (h & 8u) {
         o->err.zero();  // reported once: the flag does not poison later calls on the handle
         sync();
-        fail(AE_ERR_STATE, "sequential dataflow kernel: poll budget exceeded (not every workgroup was resident -- is another process using this GPU? -- or the scheduling invariant was violated); the coordinates are those of the batch's start");
+        // AE_CE_SEQUENTIAL commits its row versions only after a clean run (df_commit_kernel skips on the flag): the coordinates are
+        // the batch's start.  AE_CE_ORDERED has stored every finished sample's rows in place: what is left is a partial batch.
+        fail(AE_ERR_STATE, "%s dataflow kernel: poll budget exceeded (not every workgroup was resident -- is another process using this GPU? -- or the scheduling invariant was violated); %s",
+             relaxed ? "ordered" : "sequential",
+             relaxed ? "AE_CE_ORDERED stores rows in place: the coordinates hold a PARTIAL batch (the samples that finished) -- restart from a saved embedding"
+                     : "the coordinates are those of the batch's start");
     }
     check_err_flag(o);
 }
@@ -982,10 +988,9 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         AE_HIP(hipMemcpy2DAsync(o->y.p, sizeof(float) * dim, y0, sizeof(float) * adim, sizeof(float) * adim, n,
                                 y0_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream()));
         // embedded scales: mean of the initial scales as the reference's sequential f32 sum (:1358)
-        std::vector<float> hscale = np->scale.to_host();
-        float ssum = 0.f;
-        for (uint64_t i = 0; i < n; i++) ssum += hscale[i];
-        const float mean_scale = ssum / (float)n;
+        // (on the device: the reference's sequential f32 order as a single-lane chain -- bit parity of the scales with the oracle --, a
+        // tree reduction while the embedder has switched the summation order for a mode that is not the bit-exact one: linalg.h)
+        const float mean_scale = seq_sum_f32(np->scale.p, n) / (float)n;
         o->emb_scale.alloc(n);
         hipLaunchKernelGGL(embedded_scales_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, np->scale.p, mean_scale,
                            o->emb_scale.p);

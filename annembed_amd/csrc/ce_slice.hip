@@ -1126,7 +1126,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // carries its losers into the next slice
     int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
     const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : 1;
-    const bool f64 = debug_knob("AE_SL_F64") != nullptr;
+    // scalar arithmetic: the reference's f64 (embedder.rs:1207-1229) unless the caller opted into f32 (ae_embedder_params.ce_precision)
+    const bool f64 = o->params.ce_precision != AE_PRECISION_F32;
     const uint32_t classes = o->sl_classes;
     const bool has_overflow = o->sl_ov_frac > 0.;
     const uint64_t n_keys = (uint64_t)n_slices * (classes + 1u);

@@ -126,7 +126,8 @@ void comm_broadcast_f32(ae_comm* c, float* p, uint64_t count, int root) {
     if (c->host) {
         HostMem& h = *c->host;
         if (count * sizeof(float) > h.data_bytes) fail(AE_ERR_INVALID_ARG, "host-memory communicator: broadcast of %llu bytes exceeds the segment", (unsigned long long)(count * 4));
-        if (c->rank == root) { sync(); AE_HIP(hipMemcpy(h.data(c->world), p, count * sizeof(float), hipMemcpyDeviceToHost)); }
+        sync();  // every rank: what the library's (non-blocking) stream still does to p comes before the host-path copies below
+        if (c->rank == root) AE_HIP(hipMemcpy(h.data(c->world), p, count * sizeof(float), hipMemcpyDeviceToHost));
         h.barrier(c->world);
         if (c->rank != root) AE_HIP(hipMemcpy(p, h.data(c->world), count * sizeof(float), hipMemcpyHostToDevice));
         h.barrier(c->world);
@@ -266,31 +267,59 @@ int32_t ae_comm_init_hostmem(int32_t rank, int32_t world, const char* name, uint
         snprintf(h.name, sizeof(h.name), "/%s", name);
         h.data_bytes = (size_t)max_bytes;
         h.bytes = 64 + (size_t)world * 64 + h.data_bytes;
+        // Rank 0 creates a fresh segment (O_EXCL after unlinking whatever a crashed run left under the name).  A rank != 0 may open the
+        // STALE segment first (same name, large enough, ready == 1): it therefore proves that rank 0 lives in the mapping it holds -- it
+        // writes a fresh token into its slot and proceeds only when rank 0 has echoed it; a mapping nobody answers in is dropped and the
+        // name opened again (rank 0's unlink + create make the next open the live one).
+        auto map_segment = [&]() {
+            void* m = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, h.fd, 0);
+            if (m == MAP_FAILED) fail(AE_ERR_OOM, "host-memory communicator: mmap of %zu bytes failed", h.bytes);
+            h.base = static_cast<uint8_t*>(m);
+        };
+        auto token_of = [&](int q) { return reinterpret_cast<std::atomic<uint64_t>*>(h.slot(q)); };      // written by rank q
+        auto ack_of = [&](int q) { return reinterpret_cast<std::atomic<uint64_t>*>(h.slot(q) + 8); };    // written by rank 0
+        const auto t_start = std::chrono::steady_clock::now();
+        auto expired = [&] { return std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120); };
         if (rank == 0) {
             shm_unlink(h.name);  // a stale segment of a crashed run
             h.fd = shm_open(h.name, O_CREAT | O_EXCL | O_RDWR, 0600);
             if (h.fd < 0 || ftruncate(h.fd, (off_t)h.bytes) != 0) fail(AE_ERR_STATE, "host-memory communicator: cannot create the segment %s (%s)", h.name, strerror(errno));
+            map_segment();  // (a fresh segment is zero-filled: arrived = generation = 0, no tokens)
+            h.hdr()->ready.store(1, std::memory_order_release);
+            for (int q = 1; q < world; q++) {
+                uint64_t t;
+                while ((t = token_of(q)->load(std::memory_order_acquire)) == 0) {
+                    usleep(500);
+                    if (expired()) fail(AE_ERR_STATE, "host-memory communicator: rank %d did not join the segment %s within 120 s", q, h.name);
+                }
+                ack_of(q)->store(t, std::memory_order_release);
+            }
         } else {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (;;) {  // until rank 0 has created and sized it
+            const uint64_t token = ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)rank << 56) | 1ull;
+            for (;;) {
+                if (expired()) fail(AE_ERR_STATE, "host-memory communicator: rank 0 did not create / answer in the segment %s within 120 s", h.name);
                 h.fd = shm_open(h.name, O_RDWR, 0600);
                 struct stat st;
-                if (h.fd >= 0 && fstat(h.fd, &st) == 0 && (size_t)st.st_size >= h.bytes) break;
-                if (h.fd >= 0) { close(h.fd); h.fd = -1; }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(AE_ERR_STATE, "host-memory communicator: rank 0 did not create the segment %s within 120 s", h.name);
-                usleep(2000);
-            }
-        }
-        void* m = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, h.fd, 0);
-        if (m == MAP_FAILED) fail(AE_ERR_OOM, "host-memory communicator: mmap of %zu bytes failed", h.bytes);
-        h.base = static_cast<uint8_t*>(m);
-        if (rank == 0) {  // (a fresh segment is zero-filled: arrived = generation = 0)
-            h.hdr()->ready.store(1, std::memory_order_release);
-        } else {
-            const auto t0 = std::chrono::steady_clock::now();
-            while (h.hdr()->ready.load(std::memory_order_acquire) != 1) {
-                usleep(1000);
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) fail(AE_ERR_STATE, "host-memory communicator: segment never became ready");
+                if (h.fd < 0 || fstat(h.fd, &st) != 0 || (size_t)st.st_size < h.bytes) {  // not created / not sized yet
+                    if (h.fd >= 0) { close(h.fd); h.fd = -1; }
+                    usleep(2000);
+                    continue;
+                }
+                map_segment();
+                bool live = false;
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(500)) {
+                    if (h.hdr()->ready.load(std::memory_order_acquire) == 1) {
+                        token_of(rank)->store(token, std::memory_order_release);
+                        if (ack_of(rank)->load(std::memory_order_acquire) == token) { live = true; break; }
+                    }
+                    usleep(500);
+                }
+                if (live) break;
+                munmap(h.base, h.bytes);  // nobody answers here: a stale segment (or rank 0 is slow: the same name is opened again)
+                h.base = nullptr;
+                close(h.fd);
+                h.fd = -1;
             }
         }
         h.barrier(world);

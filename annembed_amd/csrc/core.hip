@@ -66,7 +66,7 @@ using namespace ae;
 // kernels
 // ---------------------------------------------------------------------------------------------
 // validates the KGraph invariants: non-empty rows (kgraph.rs:520-537), ascending distances
-// (kgraph.rs:508-509), indices < n, row length <= max_nbng.  err[0] = code, err[1] = node.
+// (kgraph.rs:508-509), indices < n and != the row's own node (kgraph.rs:501), row length <= max_nbng.  err[0] = code, err[1] = node.
 __global__ void kgraph_validate_kernel(uint64_t n, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ nbr,
                                        const float* __restrict__ dist, uint32_t max_nbng, unsigned long long* err,
                                        unsigned int* nonuniform, uint32_t k0) {
@@ -79,7 +79,7 @@ __global__ void kgraph_validate_kernel(uint64_t n, const uint64_t* __restrict__ 
     else if (e - b > max_nbng) code = AE_ERR_INVALID_ARG;
     else {
         for (uint64_t x = b; x < e; x++) {
-            if (nbr[x] >= n) code = AE_ERR_INVALID_ARG;
+            if (nbr[x] >= n || nbr[x] == i) code = AE_ERR_INVALID_ARG;  // (a node is not its own neighbour: assert of kgraph.rs:501)
             if (x > b && dist[x] < dist[x - 1]) code = AE_ERR_INVALID_ARG;
             if (!(dist[x] >= 0.f)) code = AE_ERR_INVALID_ARG;  // also rejects NaN
         }
@@ -280,7 +280,7 @@ static void finish_kgraph(ae_kgraph* g) {
         if (code == AE_ERR_ISOLATED_NODE)
             fail(code, "node rank %llu has no neighbour (graph would not be connected; kgraph.rs:520-537)",
                  (unsigned long long)node);
-        fail(code, "invalid KGraph row %llu: rows must be non-empty, sorted by increasing distance, <= max_nbng long, indices < n",
+        fail(code, "invalid KGraph row %llu: rows must be non-empty, sorted by increasing distance, <= max_nbng long, indices < n and never the row's own node",
              (unsigned long long)node);
     }
     g->uniform_k = (hnon == 0 && g->n && g->nnz == (uint64_t)k0 * g->n) ? k0 : 0;
@@ -361,6 +361,7 @@ int32_t ae_embedder_params_default(ae_embedder_params* p) {
         p->seed = kDefaultSeed;
         p->ce_mode = AE_CE_AUTO;
         p->ce_sampler = AE_SAMPLER_ROWCDF;
+        p->ce_precision = AE_PRECISION_F64;
     });
 }
 

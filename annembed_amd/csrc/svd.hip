@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(c
     const int nrem = (int)((k_hi - k_lo - full * 8 * U) / 8);  // float4 loads of the remainder (< U): issued now, used last
     float4 rem[U > 1 ? U - 1 : 1];
 #pragma unroll
-    for (int u = 0; u < U - 1; u++) rem[u] = *reinterpret_cast<const float4*>(pa + k_lo + full * 8 * U + (u < nrem ? 8 * u : 0));
+    for (int u = 0; u < U - 1; u++)  // (u >= nrem: never used -- loaded from the start of the wave's k range, inside the row: with nrem == 0 the remainder's base is one past the row, for the last row of A past the allocation)
+        rem[u] = *reinterpret_cast<const float4*>(pa + (u < nrem ? k_lo + full * 8 * U + 8 * u : k_lo));
     {
         constexpr int XL = 4096 / (256 * KS);  // at most 64 KB = 4096 float4: XL per thread
         const uint64_t nl = n * l;

@@ -11,8 +11,13 @@
       u64    n                  u64  nnz
       u64[n+1] indptr           u32[nnz] nbr            f32[nnz] dist           u64[n] data_ids
   little endian, rows sorted by increasing distance (src/fromhnsw/kgraph.rs:508-509).
+* MNIST / Fashion-MNIST IDX files (src/utils/mnistio.rs:56-201): `read_image_file` (magic 2051, big-endian header, 60000 or 10000
+  items of 28 x 28 bytes), `read_label_file` (magic 2049), `load_mnist_train_data` / `load_mnist_test_data` (the four file names),
+  and `mnist_images_as_vectors`: the flattening of examples/mnist_fashion.rs:43-66 (row-major pixels as f32, train then test) --
+  the hook that lets this build be held against the only results the reference publishes on this path (embedder.rs:585-618).
 No device code here: this is the boundary's file plumbing.
 """
+import os
 import csv
 import io as _io
 import math
@@ -157,3 +162,96 @@ def read_kgraph(path):
     if int(out["indptr"][0]) != 0 or int(out["indptr"][-1]) != nnz:
         raise ValueError("corrupt indptr")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# MNIST IDX files -- src/utils/mnistio.rs
+# ------------------------------------------------------------------------------------------------------------------
+IDX_IMAGE_MAGIC = 2051  # mnistio.rs:69
+IDX_LABEL_MAGIC = 2049  # mnistio.rs:135
+
+
+def read_image_file(f):
+    """read_image_file, src/utils/mnistio.rs:56-121: four big-endian u32 (magic 2051, items, rows 28, columns 28), then items x 28 x 28
+    bytes.  Returns uint8[items, 28, 28] (image k = out[k]; the reference stores Array3[[row, column, k]] -- same bytes, same order
+    within an image).  The reference asserts the magic, items in {60000, 10000} and the 28 x 28 shape: ValueError here."""
+    head = f.read(16)
+    if len(head) != 16:
+        raise ValueError("IDX image file: truncated header")
+    magic, nbitem, nbrow, nbcolumn = struct.unpack(">IIII", head)
+    if magic != IDX_IMAGE_MAGIC:
+        raise ValueError("IDX image file: magic %d, expected %d (mnistio.rs:69)" % (magic, IDX_IMAGE_MAGIC))
+    if nbitem not in (60000, 10000):
+        raise ValueError("IDX image file: %d items, expected 60000 or 10000 (mnistio.rs:79)" % nbitem)
+    if nbrow != 28 or nbcolumn != 28:
+        raise ValueError("IDX image file: %d x %d images, expected 28 x 28 (mnistio.rs:89,99)" % (nbrow, nbcolumn))
+    body = f.read(nbitem * 784)
+    if len(body) != nbitem * 784:
+        raise ValueError("IDX image file: truncated (read_exact fails, mnistio.rs:106)")
+    return np.frombuffer(body, np.uint8).reshape(nbitem, 28, 28).copy()
+
+
+def read_label_file(f):
+    """read_label_file, src/utils/mnistio.rs:123-147: magic 2049, items, then one byte per item"""
+    head = f.read(8)
+    if len(head) != 8:
+        raise ValueError("IDX label file: truncated header")
+    magic, nbitem = struct.unpack(">II", head)
+    if magic != IDX_LABEL_MAGIC:
+        raise ValueError("IDX label file: magic %d, expected %d (mnistio.rs:135)" % (magic, IDX_LABEL_MAGIC))
+    if nbitem not in (60000, 10000):
+        raise ValueError("IDX label file: %d items, expected 60000 or 10000 (mnistio.rs:145)" % nbitem)
+    body = f.read(nbitem)
+    if len(body) != nbitem:
+        raise ValueError("IDX label file: truncated")
+    return np.frombuffer(body, np.uint8).copy()
+
+
+class MnistData:
+    """MnistData, src/utils/mnistio.rs:16-54"""
+
+    def __init__(self, image_filename, label_filename):
+        with open(image_filename, "rb") as f:
+            self.images = read_image_file(f)
+        with open(label_filename, "rb") as f:
+            self.labels = read_label_file(f)
+        if len(self.images) != len(self.labels):
+            raise ValueError("images and labels differ in number")
+
+    def get_labels(self):
+        return self.labels
+
+    def get_images(self):
+        return self.images
+
+
+def load_mnist_train_data(dname):
+    """load_mnist_train_data, src/utils/mnistio.rs:150-165"""
+    return MnistData(os.path.join(dname, "train-images-idx3-ubyte"), os.path.join(dname, "train-labels-idx1-ubyte"))
+
+
+def load_mnist_test_data(dname):
+    """load_mnist_test_data, src/utils/mnistio.rs:167-184"""
+    return MnistData(os.path.join(dname, "t10k-images-idx3-ubyte"), os.path.join(dname, "t10k-labels-idx1-ubyte"))
+
+
+def mnist_images_as_vectors(dname, with_test=True):
+    """The data matrix of examples/mnist_fashion.rs:38-66 / mnist_digits.rs: every image as 784 f32 (row-major pixels), the 60000
+    training images followed by the 10000 test images -> (float32[n, 784], uint8[n] labels)."""
+    tr = load_mnist_train_data(dname)
+    xs, ls = [tr.get_images().reshape(-1, 784)], [tr.get_labels()]
+    if with_test:
+        te = load_mnist_test_data(dname)
+        xs.append(te.get_images().reshape(-1, 784))
+        ls.append(te.get_labels())
+    return np.ascontiguousarray(np.concatenate(xs).astype(np.float32)), np.concatenate(ls)
+
+
+def find_mnist_dir(candidates=None):
+    """first directory that holds the four IDX files (`data/mnist/*-idx3-ubyte`), or None"""
+    names = ("train-images-idx3-ubyte", "train-labels-idx1-ubyte", "t10k-images-idx3-ubyte", "t10k-labels-idx1-ubyte")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for d in candidates or (os.environ.get("AE_MNIST_DIR", ""), os.path.join(root, "data", "fashion-mnist"), os.path.join(root, "data", "mnist")):
+        if d and all(os.path.exists(os.path.join(d, nm)) for nm in names):
+            return d
+    return None

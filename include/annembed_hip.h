@@ -86,6 +86,11 @@ typedef struct ae_embedder_params {
     uint64_t seed;      /* Philox key for every random draw of the embedding. default 4664397  */
     uint32_t ce_mode;   /* AE_CE_* below. default AE_CE_AUTO                                    */
     uint32_t ce_sampler; /* AE_SAMPLER_* below. default AE_SAMPLER_ROWCDF                       */
+    uint32_t ce_precision; /* AE_PRECISION_* below. default AE_PRECISION_F64: the reference's arithmetic -- f32 coordinates,
+                              f64 scalars (src/embedder.rs:1207-1229) -- in every faithful mode.  AE_PRECISION_F32 is an explicit
+                              opt-in to f32 scalars with hardware reciprocals, honoured by AE_CE_SLICED only (about 8 % faster at the
+                              configs[3] shape; AE_CE_SEQUENTIAL / AE_CE_ORDERED / AE_CE_EVENT always compute the reference's f64
+                              scalars; AE_CE_HOGWILD is f32 by definition) */
 } ae_embedder_params;
 
 enum {
@@ -130,7 +135,8 @@ enum {
        a matching), and a step = the events of one class in one slice is one launch in which no two samples share a row: every
        lane applies its sample exactly as src/embedder.rs:1207-1301 (both rows, one gradient), class order drawn afresh per slice.
        Edges without a colour (hubs) and, on graphs of a few million edges, all of them run optimistically instead: an event that
-       holds both its rows exclusively runs, the others are deferred to the next pass.  Scalar arithmetic in f32.  Statistical
+       holds both its rows exclusively runs, the others are deferred to the next pass.  Scalar arithmetic as `ce_precision` says (default:
+       the reference's f64 scalars).  Statistical
        parity like AE_CE_EVENT, throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes, one device. */
     AE_CE_SLICED = 5,
     /* The samples of AE_CE_SEQUENTIAL (same Philox plan, same order, same f64 arithmetic) with only their two END POINTS as
@@ -139,8 +145,13 @@ enum {
        reference's threaded loop guarantees (rows under a lock for the update, negatives through try_read, embedder.rs:1257-1265).
        Not reproducible in the last bits of the negatives' contributions; statistical parity; about half the latency of
        AE_CE_SEQUENTIAL on small graphs (a C2 batch is 1 565 dependency levels deep instead of 4 305).  Any asked_dim, one device,
-       < 2^31 samples per batch. */
+       < 2^31 samples per batch.  If the dataflow kernel's poll budget is ever exceeded (AE_ERR_STATE: another process holding part
+       of the GPU), the coordinates hold a PARTIAL batch -- rows are stored in place -- where AE_CE_SEQUENTIAL leaves the batch's start. */
     AE_CE_ORDERED = 6
+};
+enum {
+    AE_PRECISION_F64 = 0, /* coordinates f32, scalar coefficients f64: what the reference computes */
+    AE_PRECISION_F32 = 1  /* scalar coefficients in f32 (AE_CE_SLICED only): a throughput option, narrower than the reference */
 };
 enum {
     /* edge ~ uniform source node x per-row inverse CDF.  Same law as the alias table because every
@@ -182,7 +193,7 @@ typedef struct ae_kgraph ae_kgraph;
 /* Build from an already flattened graph: rows sorted by increasing distance (the invariant of
    kgraph.rs:508-509), indices already dense NodeIdx.  `indptr` has n+1 entries.
    Errors: AE_ERR_ISOLATED_NODE if a row is empty (kgraph.rs:520-537), AE_ERR_INVALID_ARG if a row is
-   not sorted, longer than max_nbng, or holds an index >= n. */
+   not sorted, longer than max_nbng, holds an index >= n or the row's own node (kgraph.rs:501). */
 int32_t ae_kgraph_create(const uint64_t *indptr, const uint32_t *nbr, const float *dist, uint64_t n,
                          uint32_t max_nbng, ae_kgraph **out);
 

@@ -62,6 +62,11 @@ def test_kgraph_roundtrip_and_validation(A, graph):
     nb2[5] = 2500
     with pytest.raises(A.AnnembedError):
         A.KGraph(indptr, nb2, dist)
+    nb3 = nbr.copy()
+    nb3[int(indptr[7]) + 2] = 7  # node 7 as its own neighbour (assert of kgraph.rs:501)
+    with pytest.raises(A.AnnembedError) as e:
+        A.KGraph(indptr, nb3, dist)
+    assert e.value.code == 1
 
 
 def test_kgraph_from_ragged_bit_exact(A, oracle):
@@ -707,6 +712,19 @@ def test_gpu_range_approx_rank(A, oracle):  # svdapprox.rs:1231 in f32: residual
         data[r_] = data[2]
     q = A.subspace_iteration(A.MatRepr.from_array2(data), 28, 2)
     assert np.linalg.norm(data - q @ (q.T @ data)) / np.linalg.norm(data) < 1e-5
+
+
+@pytest.mark.parametrize("m,ncols,rank", [(4096, 128, 20), (2048, 256, 20), (1500, 32, 8), (700, 1024, 20), (1000, 784, 20)])
+def test_gpu_dense_direct_svd_column_counts(A, oracle, m, ncols, rank):
+    """Dense direct_svd (svdapprox.rs:721-799 on a Array2: the streaming MFMA product) where the column count leaves NO remainder trip
+    (ncols % 32 == 0: the remainder's loads used to sit one past the row, for the last row past the end of A -- ADVICE r3) and
+    where it leaves one (784), l % 4 == 0: singular values vs the oracle's LAPACK path, A ~ U S Vt on a matrix of exact rank."""
+    rng = np.random.default_rng(m + ncols)
+    a = (rng.normal(size=(m, rank)) @ rng.normal(size=(rank, ncols))).astype(np.float32)
+    r = A.SvdApprox(A.MatRepr.from_array2(a)).direct_svd(A.RangeRank(rank, 3))
+    s_ref = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:rank]
+    assert _relmax(r.s, s_ref) < 2e-4
+    assert np.linalg.norm((r.u * r.s) @ r.vt - a) / np.linalg.norm(a) < 1e-4
 
 
 def test_gpu_svd_sparse_vs_oracle(A, oracle):

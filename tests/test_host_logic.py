@@ -48,6 +48,7 @@ def test_embedder_params_default_matches_reference():
     assert (p.asked_dim, p.dmap_init, p.beta, p.b, p.scale_rho, p.grad_step) == (2, True, 1.0, 1.0, 1.0, 2.0)
     assert (p.nb_sampling_by_edge, p.nb_grad_batch, p.grad_factor, p.hierarchy_layer, p.hubness_weighting) == (10, 20, 4, 0, False)
     assert p.seed == 4664397 and p.ce_mode == A.AE_CE_AUTO and p.ce_sampler == A.AE_SAMPLER_ROWCDF
+    assert p.ce_precision == A.AE_PRECISION_F64  # the reference's f64 scalars unless the caller opts out (embedder.rs:1207-1229)
     p.set_dim(5)
     p.set_nb_gradient_batch(7)
     assert p.c().asked_dim == 5 and p.c().nb_grad_batch == 7

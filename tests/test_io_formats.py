@@ -90,3 +90,40 @@ def test_embed_cli_flags_mirror_reference_defaults():
         E.parse(["--csv", "x.csv", "hnsw", "--dist", "DistFoo", "--nbconn", "4", "--ef", "4", "--knbn", "4"])
     with pytest.raises(SystemExit):
         E.parse(["--batch", "5"])  # --csv is required
+
+
+def _write_idx(dirpath, prefix, n, seed):
+    import struct
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(n, 28, 28), dtype=np.uint8)
+    lab = rng.integers(0, 10, size=n, dtype=np.uint8)
+    (dirpath / ("%s-images-idx3-ubyte" % prefix)).write_bytes(struct.pack(">IIII", 2051, n, 28, 28) + img.tobytes())
+    (dirpath / ("%s-labels-idx1-ubyte" % prefix)).write_bytes(struct.pack(">II", 2049, n) + lab.tobytes())
+    return img, lab
+
+
+def test_mnist_idx_reader(tmp_path):
+    """IDX files as src/utils/mnistio.rs:56-201 reads them: big-endian header, magic 2051 / 2049, 60000 or 10000 items of 28 x 28;
+    the flattened matrix of examples/mnist_fashion.rs:43-66 is row-major pixels, train then test."""
+    import io
+    import struct
+    itr, ltr = _write_idx(tmp_path, "train", 60000, 1)
+    ite, lte = _write_idx(tmp_path, "t10k", 10000, 2)
+    tr = aio.load_mnist_train_data(tmp_path)
+    assert np.array_equal(tr.get_images(), itr) and np.array_equal(tr.get_labels(), ltr)
+    x, lab = aio.mnist_images_as_vectors(tmp_path)
+    assert x.shape == (70000, 784) and x.dtype == np.float32 and lab.shape == (70000,)
+    # image k, row i, column j -> vector[k][28 i + j]  (the iteration order of images.slice(s![.., .., k]).iter())
+    assert x[3, 28 * 5 + 7] == float(itr[3, 5, 7]) and x[60000 + 11, 28 * 27 + 1] == float(ite[11, 27, 1])
+    assert np.array_equal(lab[:60000], ltr) and np.array_equal(lab[60000:], lte)
+    assert aio.find_mnist_dir([str(tmp_path)]) == str(tmp_path) and aio.find_mnist_dir([str(tmp_path / "nowhere")]) is None
+    # the reference's asserts (mnistio.rs:69, 79, 89, 99, 135, 145) as ValueErrors
+    for head in (struct.pack(">IIII", 2049, 60000, 28, 28), struct.pack(">IIII", 2051, 1234, 28, 28), struct.pack(">IIII", 2051, 10000, 32, 28)):
+        with pytest.raises(ValueError):
+            aio.read_image_file(io.BytesIO(head + bytes(784)))
+    with pytest.raises(ValueError, match="truncated"):
+        aio.read_image_file(io.BytesIO(struct.pack(">IIII", 2051, 10000, 28, 28) + bytes(100)))
+    with pytest.raises(ValueError):
+        aio.read_label_file(io.BytesIO(struct.pack(">II", 2051, 10000) + bytes(10000)))
+    with pytest.raises(ValueError):
+        aio.read_label_file(io.BytesIO(struct.pack(">II", 2049, 10000) + bytes(9999)))
