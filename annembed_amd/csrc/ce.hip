@@ -1115,6 +1115,17 @@ int32_t ae_entropy_optim_slice_info(const ae_entropy_optim* o, uint32_t* classes
     });
 }
 
+int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim* o, uint32_t* max_in_degree, double* busiest_row_events_per_step) {
+    return guard([&] {
+        if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (o->params.ce_mode != AE_CE_SLICED) fail(AE_ERR_STATE, "the handle does not run AE_CE_SLICED");
+        if (max_in_degree) *max_in_degree = o->sl_max_in_degree;
+        // (half an event per node and slice on average: a row of degree D sees 0.5 D / mean degree of them, spread over the classes)
+        if (busiest_row_events_per_step)
+            *busiest_row_events_per_step = o->sl_classes ? 0.5 * (double)(o->sl_max_in_degree + o->g->max_nbng) * (double)o->dev.n / (double)(2 * o->dev.nnz) / (double)o->sl_classes : 0.;
+    });
+}
+
 int32_t ae_entropy_optim_ce(ae_entropy_optim* o, double* ce) {
     return guard([&] {
         require_device();

@@ -124,6 +124,10 @@ struct ae_entropy_optim {
     DevBuf<char> sl_sort_tmp;                   // rocPRIM's temporary storage of the event sort (histograms), kept with the handle
     float sl_pmax = 0.f;
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
+    DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
+    DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
+    DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
+    uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)
     DevBuf<float> sl_node_ov;                   // per node: probability mass of its overflow edges
     DevBuf<float> sl_srec;                      // per node: static record {embedded scale, neighbour ids, edge probabilities}
     uint32_t sl_srec_floats = 16;

@@ -1,0 +1,851 @@
+// ce_slice_kernels.h -- device side of AE_CE_SLICED (ce_slice.hip holds the host driver, the colouring and the event generation):
+// lane-group memory access, the tile of negatives, one sample on rows in registers, the step kernel (a colour class of a time slice,
+// with chains through hub rows), the optimistic pass kernel of the overflow class, chain rounds.  Everything here is a template over
+// the row stride; ce_slice_dim*.hip instantiate one stride each (the translation units compile side by side).
+#pragma once
+#include "ce_node_common.h"
+#include "ce_sample_math.h"
+
+#include <type_traits>
+
+namespace ae {
+namespace sl {
+
+constexpr uint32_t kTagSlCount = 0xFFFF0031u, kTagSlTime = 0xFFFF0032u, kTagSlNeg = 0xFFFF0033u, kTagSlCoin = 0xFFFF0034u, kTagSlColor = 0xFFFF0035u;
+// the pending list is kept as kSub sub-lists with a counter each: appends (one atomic per WORKGROUP) spread over kSub addresses --
+// one counter serialises at ~12 ns per atomic, which with one atomic per wave was 2/3 of a pass at the C3 shape
+constexpr int kSub = 16;
+constexpr uint32_t kMaxClasses = 64;        // colours are bits of a 64-bit mask per node
+constexpr uint8_t kNoColor = 0xFFu, kOverflowColor = 0xFEu;
+
+struct EdgeRec {       // per edge, 16 bytes (colouring, event generation)
+    uint32_t j;        // target
+    float w;           // probability
+    uint32_t pad;
+    uint32_t im;       // source << 5 | slot of the edge in the source's row
+};
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;                // (<= 2^27 nodes: ce_slice_unsupported)
+// An event in the sorted arrays: 8 bytes {source << 5 | slot of the edge in the source's row, target} -- the rows of both end
+// points and the source's static record are requested in ONE hop after the (coalesced) event load.  The events of a step are sorted
+// by target: those that share one are adjacent and run as a chain through the target's row (sl_step_body).
+struct Event {
+    uint32_t im, j;
+};
+struct Pending {       // a pending event of the overflow class: 16 bytes, read and written coalesced
+    uint32_t idx, im, j, pad;
+};
+
+struct SliceArgs {
+    CeDev c;
+    const float* srec;          // per node: static record of SREC floats {embedded scale, neighbour ids, edge probabilities}
+    const Event* ev;            // the batch segment's events sorted by (slice, class)
+    uint32_t f0, f1;            // the slice's overflow events = [f0, f1) of ev
+    uint32_t* owner;            // [2][n]
+    Pending* lists;             // [3][kSub][cap]: pending events, in kSub independent sub-lists (cap entries each)
+    int tile;                   // 1: the negatives of this pass are drawn from a tile of rows staged in LDS (see sl_exec_kernel)
+    uint32_t* counts;           // [3][kSub]
+    uint64_t cap;
+    uint32_t key;               // (batch << 12) | segment
+    uint32_t pass_seq;          // running pass number of the batch (RNG key of the back-off coin)
+    int src_list, dst_list, zero_list, owner_chk, owner_mark;
+    int backoff;                // 1: a deferred event marks only with probability 1/2
+    double step;
+    unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = overflow flag
+};
+
+struct DirectArgs {
+    CeDev c;
+    const float* srec;
+    const Event* ev;
+    uint32_t begin, end;        // the step's events = [begin, end) of ev, sorted by edge (repeats of an edge adjacent)
+    uint32_t ept;               // events per thread
+    uint32_t key;               // (batch << 12) | segment
+    uint32_t step_seq;          // running step number of the batch (RNG key of the tile windows)
+    int tile;
+    int dbg;                    // debug knob AE_SL_DBG (measurement only): 1 no arithmetic, 2 no stores, 4 no negatives, 8 no static record
+    double step;
+    unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = error flags (1: pending list overflow, 2: hand-over poll budget)
+    uint32_t* chunk_flag;       // hand-over of a target's row between the 64-event chunks of a step: [chunk] = step token once the chunk's tail is through
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// memory access by lane groups
+// ------------------------------------------------------------------------------------------------------------------
+// The kernels below are bound by the NUMBER of memory requests, not by bytes (tools/ubench_rowgather.hip: ~55 G random requests/s
+// whatever their width up to 64 bytes; a lane that loads a 32-byte row with two 16-byte instructions issues two).  A record of NF
+// floats (a coordinate row of >= 8 columns, a static record) is therefore fetched by a GROUP of G = NF / 4 adjacent lanes: in
+// step t every lane of the group loads its 16-byte piece of the record wanted by the group's lane t -- one request per record --
+// and the pieces are handed to their owner through a wave-private LDS stage (a wave's LDS operations execute in program order:
+// no workgroup barrier).  Stage rows are NF + 4 floats apart (bank spread).
+using f4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// issue: the group's loads into registers (pc[t] = this lane's piece of the record wanted by the group's lane t); land: through
+// the stage to the owners.  Issue everything a sample needs first, land afterwards: one memory round trip, not one per record.
+// value of the group's lane t (t is a constant after unrolling): DPP quad permutes for groups of 2 and 4 lanes (one VALU
+// instruction), the LDS crossbar otherwise
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, true);
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t x, int t) {
+    if constexpr (G == 1) {
+        return x;
+    } else if constexpr (G == 2) {
+        return t == 0 ? quad_perm<0xA0>(x) : quad_perm<0xF5>(x);
+    } else if constexpr (G == 4) {
+        switch (t) {
+            case 0: return quad_perm<0x00>(x);
+            case 1: return quad_perm<0x55>(x);
+            case 2: return quad_perm<0xAA>(x);
+            default: return quad_perm<0xFF>(x);
+        }
+    } else {
+        return (uint32_t)__shfl((int)x, ((int)(threadIdx.x & 63) & ~(G - 1)) + t);
+    }
+}
+// issue: the group's loads into registers (pc[t] = this lane's piece of the record wanted by the group's lane t); land: through
+// the stage to the owners.  Issue everything a sample needs first, land afterwards: one memory round trip, not one per record.
+// idx < 2^31; the top bit of the broadcast word carries `want`.
+template <int NF>
+__device__ __forceinline__ void coop_issue(const float* __restrict__ base, uint32_t idx, bool want, f4 (&pc)[NF / 4]) {
+    constexpr int G = NF / 4;
+    const uint32_t sub = (threadIdx.x & 63) & (G - 1);
+    // UNCONDITIONAL loads (a lane that wants nothing asks for record 0: one shared line): a load under `if (want)` makes the register
+    // allocator merge the two paths with a copy behind the load -- an `s_waitcnt vmcnt(0)` in the middle of the issue phase, which
+    // also drains the tile's loads (seen in the ISA of sl_direct_kernel<8,16>)
+    const uint32_t word = want ? idx : 0u;
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        const uint32_t wt = group_bcast<G>(word, t);
+        pc[t] = *reinterpret_cast<const f4*>(base + (uint64_t)wt * NF + sub * 4u);
+    }
+}
+template <int NF>
+__device__ __forceinline__ void coop_land(const f4 (&pc)[NF / 4], float* stage) {
+    constexpr int G = NF / 4, RS = NF + 4;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
+#pragma unroll
+    for (int t = 0; t < G; t++) *reinterpret_cast<f4*>(stage + (gb + t) * RS + sub * 4) = pc[t];
+    wave_lds_sync();
+}
+template <int NF>
+__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage) {
+    constexpr int G = NF / 4, RS = NF + 4;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
+    const uint32_t word = idx | (want ? 0x80000000u : 0u);
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        const uint32_t wt = group_bcast<G>(word, t);
+        if (wt & 0x80000000u)
+            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * NF + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
+    }
+    wave_lds_sync();
+}
+// rows: cooperative for 8 and 16 columns (2 / 4 lanes per row), one lane per row otherwise (<= 4 columns: one request anyway;
+// 32 / 64 columns: rare, kept simple)
+template <int DIM>
+constexpr bool kCoopRow = DIM == 8 || DIM == 16;
+template <int SREC>
+constexpr bool kCoopRec = SREC <= 32;
+template <int DIM, int SREC>
+constexpr int kStageFloats = (kCoopRow<DIM> || kCoopRec<SREC>) ? 64 * ((((kCoopRow<DIM> ? DIM : 0) > (kCoopRec<SREC> ? SREC : 0)) ? DIM : SREC) + 4) : 1;
+
+template <int DIM>
+struct RowFetch {  // a coordinate row on its way to its lane
+    f4 pc[kCoopRow<DIM> ? DIM / 4 : 1];
+    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want, float* out) {
+        if constexpr (kCoopRow<DIM>) coop_issue<DIM>(y, node, want, pc);
+        else load_row<DIM>(y, want ? node : 0u, out);
+    }
+    __device__ __forceinline__ void land(float* stage, float* out) {
+        if constexpr (kCoopRow<DIM>) {
+            coop_land<DIM>(pc, stage);
+            const float* p = stage + (threadIdx.x & 63) * (DIM + 4);
+#pragma unroll
+            for (int q = 0; q < DIM / 4; q++) {
+                const f4 v = *reinterpret_cast<const f4*>(p + 4 * q);
+                out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+            }
+            wave_lds_sync();
+        }
+    }
+};
+template <int DIM>
+__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in) {
+    if constexpr (kCoopRow<DIM>) {
+        float* p = stage + (threadIdx.x & 63) * (DIM + 4);
+#pragma unroll
+        for (int q = 0; q < DIM / 4; q++) {
+            f4 v; v.x = in[4 * q]; v.y = in[4 * q + 1]; v.z = in[4 * q + 2]; v.w = in[4 * q + 3];
+            *reinterpret_cast<f4*>(p + 4 * q) = v;
+        }
+        coop_store<DIM>(y, node, want, stage);
+    } else {
+        if (want) store_row<DIM>(y, node, in);
+    }
+}
+// the source's static record: embedded scale, the neighbour ids (rejection test of the negatives), the sampled edge's probability
+template <int SREC, int KREG>
+struct RecFetch {
+    static constexpr int KP = (SREC - 1) / 2;
+    f4 pc[kCoopRec<SREC> ? SREC / 4 : 1];
+    __device__ __forceinline__ void issue(const float* __restrict__ srec, uint32_t node, uint32_t m, bool want, float& scale, float& w, uint32_t (&nbr_reg)[KREG]) {
+        if constexpr (kCoopRec<SREC>) {
+            coop_issue<SREC>(srec, node, want, pc);
+        } else {
+            const float* p = srec + (uint64_t)(want ? node : 0u) * SREC;
+            scale = p[0];
+#pragma unroll
+            for (int q = 0; q < KREG; q++) nbr_reg[q] = __float_as_uint(p[1 + q]);
+            w = p[1 + KP + (want ? m : 0u)];
+        }
+    }
+    __device__ __forceinline__ void land(float* stage, uint32_t m, bool want, float& scale, float& w, uint32_t (&nbr_reg)[KREG]) {
+        if constexpr (kCoopRec<SREC>) {
+            coop_land<SREC>(pc, stage);
+            const float* p = stage + (threadIdx.x & 63) * (SREC + 4);
+            scale = p[0];
+#pragma unroll
+            for (int q = 0; q < KREG; q++) nbr_reg[q] = __float_as_uint(p[1 + q]);
+            w = p[1 + KP + (want ? m : 0u)];
+            wave_lds_sync();
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// one sample on rows held in registers
+// ------------------------------------------------------------------------------------------------------------------
+// tile of coordinate rows for the negatives of a crowded launch: kW windows of kL consecutive rows each, window starts uniform
+// over the nodes (wrapping) and fresh per workgroup and launch, staged in LDS with coalesced loads.  A negative is then "window
+// uniform, row uniform": every node has the same probability 1/n, as in embedder.rs:1121; the rows are as fresh as the launch
+// (it started after every earlier launch's writes).  What differs from the reference: the negatives of the samples a workgroup
+// runs in a launch come from the same kW windows (the marginals are exact, the joint law is not).
+template <int DIM>
+struct TileShape {
+    // 256 rows (16 windows of 16 consecutive rows) serve the 5 x 256 draws of a workgroup: staging costs one coalesced row read per
+    // sample instead of five random ones (a tile of 1024 rows costs as much as the gathers it replaces)
+    static constexpr int kRows = DIM <= 16 ? 256 : 128;
+    static constexpr int kL = 16;
+    static constexpr int kW = kRows / kL;
+    static constexpr int kRowBits = DIM <= 16 ? 8 : 7;
+    static constexpr int kPieces = kRows * (DIM % 4 == 0 ? DIM / 4 : DIM) / 256;  // loads per thread: 16-byte pieces (single floats for 3 columns)
+};
+__device__ __forceinline__ uint32_t tile_window_start(uint32_t wkey, uint32_t w, uint32_t n) { return __umulhi(pcg_hash(wkey + w * 0x9E3779B9u), n); }
+
+// The tile's loads are ISSUED at the start of the kernel (next to the event load) and LANDED in LDS when the sample's own loads
+// are in flight: staging is off the critical path.  Hubness-weighted sampling (NodeSampler, embedder.rs:915-930: what
+// examples/higgs.rs switches on) cannot use runs of consecutive rows: there every tile row is an independent draw of the alias
+// table (one 8-byte look-up, then the row) -- a slot picked uniformly afterwards is again a draw of the reference's law; two
+// requests per tile row instead of ten per sample.
+template <int DIM>
+struct TileFetch {
+    using T = TileShape<DIM>;
+    static constexpr int Q = DIM % 4 == 0 ? DIM / 4 : DIM;  // pieces per row
+    f4 pc[T::kPieces];
+    uint32_t node[T::kPieces];
+    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub) {
+#pragma unroll
+        for (int z = 0; z < T::kPieces; z++) {
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = x / Q;
+            if (hub) {
+                const uint32_t w0 = pcg_hash(wkey + r * 0x9E3779B9u);
+                const uint32_t xs = __umulhi(w0, (uint32_t)c.n);
+                const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                const uint2 he = c.hub_tab[xs];
+                node[z] = (uu < __uint_as_float(he.x)) ? xs : he.y;
+            } else {
+                node[z] = tile_window_start(wkey, r / T::kL, (uint32_t)c.n) + r % T::kL;
+                node[z] -= node[z] >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < T::kPieces; z++) {
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, q = x % Q;
+            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node[z] * DIM + 4u * q);
+            else pc[z].x = c.y[(uint64_t)node[z] * DIM + q];
+        }
+    }
+    __device__ __forceinline__ void land(float* s_tile, uint32_t* s_tnode) {
+#pragma unroll
+        for (int z = 0; z < T::kPieces; z++) {
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x;
+            if constexpr (DIM % 4 == 0) *reinterpret_cast<f4*>(s_tile + 4u * x) = pc[z];
+            else s_tile[x] = pc[z].x;
+            if (x % Q == 0) s_tnode[x / Q] = node[z];
+        }
+        __syncthreads();
+    }
+};
+
+// the five negatives (embedder.rs:1241-1253): uniform / NodeSampler (:927-930) draws, rejected when k = i, k = j or k in N(i)
+// (nodeparam.rs:83-85; j is in N(i)).  TILE: a draw is a slot of the staged tile (one hash: window and row from its top bits), `out`
+// receives the slots; otherwise node ids (uniform, or hubness-weighted through the alias table), eight candidates at a time so that
+// the alias look-ups overlap.  Returns the number accepted (5 unless the graph is tiny).
+template <int DIM, int KMAX, bool TILE>
+__device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, const uint32_t* s_tnode, uint32_t nb, uint32_t i,
+                                                   const uint32_t (&nbr_reg)[KMAX], uint32_t (&out)[5]) {
+    using T = TileShape<DIM>;
+    uint32_t got = 0;
+#pragma unroll
+    for (int g = 0; g < 5; g++) out[g] = TILE ? 0u : i;
+    for (uint32_t round = 0; round < 8u && got < 5u; round++) {
+        uint32_t cand[8], slot[8];
+        if constexpr (TILE) {
+#pragma unroll
+            for (int z = 0; z < 8; z++) {
+                const uint32_t row = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u) >> (32 - T::kRowBits);
+                cand[z] = s_tnode[row];
+                slot[z] = row;
+            }
+        } else if (hub) {
+            uint32_t xs[8], al[8];
+            float od[8], uu[8];
+#pragma unroll
+            for (int z = 0; z < 8; z++) {
+                const uint32_t w0 = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u);
+                xs[z] = __umulhi(w0, (uint32_t)c.n);
+                uu[z] = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+                const uint2 he = c.hub_tab[xs[z]];
+                od[z] = __uint_as_float(he.x);
+                al[z] = he.y;
+            }
+#pragma unroll
+            for (int z = 0; z < 8; z++) { cand[z] = (uu[z] < od[z]) ? xs[z] : al[z]; slot[z] = cand[z]; }
+        } else {
+#pragma unroll
+            for (int z = 0; z < 8; z++) { cand[z] = __umulhi(pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u), (uint32_t)c.n); slot[z] = cand[z]; }  // :1121
+        }
+#pragma unroll
+        for (int z = 0; z < 8; z++) {
+            uint32_t acc = cand[z] ^ i;
+#pragma unroll
+            for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand[z]; acc = x < acc ? x : acc; }
+            const bool ok = acc != 0u && got < 5u;
+#pragma unroll
+            for (int g = 0; g < 5; g++) out[g] = (ok && got == (uint32_t)g) ? slot[z] : out[g];  // (static indexing keeps `out` in registers)
+            got += ok ? 1u : 0u;
+        }
+    }
+    return got;
+}
+
+// The sample's scalar arithmetic in f32 (this mode's default; AE_SL_F64 = the reference's f64 scalars, :1207-1229): the same
+// formulas with hardware reciprocals.  This mode is validated statistically -- the rounding of a scalar coefficient (1e-7) is six
+// orders of magnitude below the sampling noise -- and the 24 dependent f64 divisions of a sample were a quarter of a batch.
+template <int DIM>
+__device__ __forceinline__ void attract_f32(float* yi, float* yj, float* grad, float w, float inv_s2, float b, float step) {
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) { grad[t] = 0.f; const float df = yi[t] - yj[t]; acc += df * df; }
+    const float d = acc * inv_s2;
+    if (d > 0.f) {
+        const float coeff = b == 1.f ? 2.0f * inv_s2 * rcp(1.0f + d) : 2.0f * b * rcp(1.0f + __powf(d, b)) * __powf(d, b - 1.0f) * inv_s2;
+        const float rep = rcp(fmaxf(d * d, 1.0f / kProbaMin));
+        const float cf = fmaxf(step * coeff * (-w + (1.f - w) * rep), -0.49f);
+#pragma unroll
+        for (int t = 0; t < DIM; t++) grad[t] = (yj[t] - yi[t]) * cf;
+    }
+#pragma unroll
+    for (int t = 0; t < DIM; t++) { yi[t] -= grad[t]; yj[t] += grad[t]; }
+}
+template <int DIM>
+__device__ __forceinline__ void repulse_f32(float* yi, const float* yk, float* grad, float inv_s2, float b, float step) {
+    float ak = 0.f;
+#pragma unroll
+    for (int t = 0; t < DIM; t++) { const float df = yi[t] - yk[t]; ak += df * df; }
+    const float d = ak * inv_s2;
+    if (ak > 0.f) {
+        const float coeff = b == 1.f ? 2.0f * inv_s2 * rcp(1.0f + d) : 2.0f * b * rcp(1.0f + __powf(d, b)) * __powf(d, b - 1.0f) * inv_s2;
+        const float cf = fminf(step * coeff * rcp(fmaxf(d * d, 1.0f / 16.0f)), 2.0f);
+#pragma unroll
+        for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
+    }  // else: `gradient` keeps its previous value, as in the reference
+#pragma unroll
+    for (int t = 0; t < DIM; t++) yi[t] -= grad[t];
+}
+
+// ce_optim_edge_shannon (embedder.rs:1167-1302) on yi / yj in registers, in its two phases: the attraction (one gradient, both ends
+// -- the part of a sample that a chain through the target's row serialises) and the repulsions from the `got` drawn negatives (tile
+// slots or node ids in `neg`; they move y_i only).  A negative's row may be rewritten during this launch by its owner: at most one
+// launch old.  Gathered negatives of rows of <= 16 columns are requested ahead (`fetch`: a memory round trip); rows in the LDS tile and
+// wider rows are read one at a time in `repulse` (40 / 80 registers less across a chain's turns: three waves per SIMD at 8 columns).
+template <int DIM, bool F64, bool TILE>
+struct SplitSample {
+    static constexpr bool kAhead = DIM <= 16 && !TILE;
+    float grad[DIM];
+    float nrow[kAhead ? 5 : 1][DIM];
+    __device__ __forceinline__ static void fetch_row(const CeDev& c, const float* s_tile, uint32_t x, float* row) {
+        if constexpr (TILE) {
+            if constexpr (DIM % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < DIM / 4; q++) {
+                    const f4 v = *reinterpret_cast<const f4*>(s_tile + x * DIM + 4 * q);
+                    row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int t2 = 0; t2 < DIM; t2++) row[t2] = s_tile[x * DIM + t2];
+            }
+        } else {
+            load_row<DIM>(c.y, x, row);
+        }
+    }
+    __device__ __forceinline__ void fetch(const CeDev& c, const float* s_tile, const uint32_t (&neg)[5]) {
+        if constexpr (kAhead) {
+#pragma unroll
+            for (int g = 0; g < 5; g++) fetch_row(c, s_tile, neg[g], nrow[g]);
+        }
+    }
+    __device__ __forceinline__ void attract(const CeDev& c, float* yi, float* yj, float w, float scale_f, double step) {
+        if constexpr (F64) sample_attract<DIM>(yi, yj, grad, w, (double)scale_f, c.b, step);  // :1207-1238
+        else attract_f32<DIM>(yi, yj, grad, w, rcp(scale_f * scale_f), (float)c.b, (float)step);
+    }
+    __device__ __forceinline__ void repulse_one(const CeDev& c, float* yi, const float* yk, float scale_f, double step) {
+        if constexpr (F64) sample_repulse<DIM>(yi, yk, grad, (double)scale_f, c.b, step);  // :1267-1297
+        else repulse_f32<DIM>(yi, yk, grad, rcp(scale_f * scale_f), (float)c.b, (float)step);
+    }
+    __device__ __forceinline__ void repulse(const CeDev& c, const float* s_tile, float* yi, float scale_f, double step, const uint32_t (&neg)[5], uint32_t got) {
+        if constexpr (kAhead) {
+#pragma unroll
+            for (int g = 0; g < 5; g++)
+                if ((uint32_t)g < got) repulse_one(c, yi, nrow[g], scale_f, step);
+        } else {  // wide rows: one negative at a time (5 x 64 registers do not exist)
+            for (uint32_t g = 0; g < got; g++) {
+                uint32_t x = neg[0];
+#pragma unroll
+                for (int q = 1; q < 5; q++) x = g == (uint32_t)q ? neg[q] : x;
+                fetch_row(c, s_tile, x, nrow[0]);
+                repulse_one(c, yi, nrow[0], scale_f, step);
+            }
+        }
+    }
+};
+template <int DIM, bool F64, bool TILE>
+__device__ __forceinline__ void run_sample(const CeDev& c, const float* s_tile, float* yi, float* yj, float w, float scale_f,
+                                           double step, const uint32_t (&neg)[5], uint32_t got) {
+    SplitSample<DIM, F64, TILE> sm;
+    sm.fetch(c, s_tile, neg);
+    sm.attract(c, yi, yj, w, scale_f, step);
+    sm.repulse(c, s_tile, yi, scale_f, step, neg, got);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// a step: the events of one colour class in one slice
+// ------------------------------------------------------------------------------------------------------------------
+// A class is a forest of in-stars (slice_color_edges): no node is the source of two events of a step, none is source and target, but
+// any number of events may share their TARGET.  Those are adjacent in the step's event range (the events are generated from an edge
+// order sorted by target; the sort by (slice, class) is stable) and run as a CHAIN through the target's row:
+//   * inside a 64-event chunk (one wave): every lane fetches its own event's data (the source's record and row, the negatives) in
+//     parallel; the target's row is loaded by the chain's first lane and handed from lane to lane (one wave shuffle per turn): in turn
+//     t the lanes at position t of their chains apply their attraction to the row they received.  A step without chains is turn 0
+//     only -- the code path of a plain matching;
+//   * across chunks (a chain that spans a chunk boundary, possibly a workgroup boundary): the last lane of the chunk writes the
+//     target's row through to memory and publishes the step's token in the chunk's flag; lane 0 of the next chunk polls the flag and
+//     reads the row with agent-scope loads before its turn.  Workgroups are dispatched in index order on every XCD and a chunk only
+//     waits for the chunk before it, so the wait always ends (poll budget: error flag 2, never a hang).
+// The reference serialises a hub's events through the row's lock at ~0.1 us per hand-over (embedder.rs:942,1185-1186,1239,1301); a
+// turn here costs one attraction (the repulsions of a sample move y_i only: they run after the turns, all lanes side by side), instead of
+// one launch per event and row as in the optimistic passes.
+// Repeats of one edge inside a step (only without `spread`) are run by the first of their lanes, as before; their other lanes hand
+// the target's row on untouched.
+template <int DIM, int SREC, bool F64, bool TILE>
+struct StepShared {
+    using T = TileShape<DIM>;
+    __attribute__((aligned(16))) float tile[TILE ? T::kRows * DIM : 4];
+    __attribute__((aligned(16))) float stage[4 * kStageFloats<DIM, SREC>];
+    uint32_t tnode[TILE ? T::kRows : 1];
+};
+
+template <int DIM>
+__device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t node, const float* in) {
+    float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int DIM>
+__device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint32_t node, float* out) {
+    const float* p = y + (uint64_t)node * DIM;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[2 * q] = __uint_as_float((uint32_t)bits);
+            out[2 * q + 1] = __uint_as_float((uint32_t)(bits >> 32));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) out[t] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
+
+// the events [a.begin, a.end) of one step, workgroup `block` of the step's grid (256 x a.ept events per workgroup)
+template <int DIM, int SREC, bool F64, bool TILE>
+__device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block, StepShared<DIM, SREC, F64, TILE>& sh, uint32_t& done) {
+    constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
+    const CeDev c = a.c;
+    const bool hub = c.hub_odds != nullptr;
+    float* stage = sh.stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
+    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
+    const uint32_t wkey = pcg_hash(nkey + a.step_seq * 0x85EBCA6Bu) + block * 64u;
+    const uint32_t base = a.begin + block * 256u * a.ept;
+    const int lane = threadIdx.x & 63;
+    // one pass over 256 events; FIRST (a compile-time tag): the pass that also stages the tile.  Kept out of the loop below so that the
+    // wait for the event load counts the tile's loads behind it (`vmcnt(pieces)`); with a run-time `r == 0` the compiler has to assume
+    // the path without them and waits for everything: the tile's random reads became a hop of their own in front of the rows.
+    auto pass = [&](uint32_t r, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint32_t p = base + r * 256u + threadIdx.x;
+        // hop 1: the event and its two neighbours in the array (coalesced) and, beside them, this thread's share of the tile
+        const bool act0 = p < a.end;
+        Event e{0u, kNoNode}, pv{0u, kNoNode}, nx{0u, kNoNode};
+        if (act0) {
+            e = a.ev[p];
+            if (p > a.begin) pv = a.ev[p - 1];
+            if (p + 1 < a.end) nx = a.ev[p + 1];
+        }
+        TileFetch<DIM> ft;
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
+        const uint32_t i = e.im >> 5, j = act0 ? e.j : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
+        // chains: this event has the previous one's target / the next one has this one's
+        const bool inrun = act0 && pv.j == j;
+        const bool next_inrun = act0 && nx.j == j;
+        const bool absorbed = inrun && pv.im == e.im;   // a repeat of the previous event's edge: its first lane runs the repeats
+        const bool cmp = act0 && !absorbed;
+        uint32_t rep = 1;
+        if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < a.end && a.ev[p + rep].im == e.im && a.ev[p + rep].j == j) rep++; }
+        const unsigned long long run_mask = __ballot(inrun);
+        const bool cont = (run_mask & 1ull) != 0ull;          // lane 0 continues a chain of the previous chunk (uniform over the wave)
+        const unsigned long long heads = ~run_mask | 1ull;   // first lanes of the chunk's chain segments (a lone event is its own)
+        const int head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+        const uint32_t runpos = act0 ? (uint32_t)(lane - head) + ((cont && head == 0) ? 1u : 0u) : 0u;
+        const bool last_in_seg = lane == 63 || !((run_mask >> (lane + 1)) & 1ull);
+        const bool hand_over = act0 && lane == 63 && next_inrun;   // the chain goes on in the next chunk
+        float yi[DIM], yj[DIM], scale_f = 1.f, w = 0.f;
+        uint32_t nbr_reg[KREG];
+        // hop 2: the source's record and both rows are requested together, then handed to their lanes (a target's row only by the
+        // lane that starts its chain; a chain continued from the previous chunk receives it through memory below)
+        RecFetch<SREC, KREG> fr;
+        RowFetch<DIM> fi, fj;
+        const bool want_rec = cmp && !(a.dbg & 8);
+        fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
+        fi.issue(c.y, i, cmp, yi);             // :1185
+        fj.issue(c.y, j, cmp && !inrun, yj);   // :1186
+        if constexpr (TILE && FIRST) ft.land(sh.tile, sh.tnode);
+        fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
+        fi.land(stage, yi);
+        fj.land(stage, yj);
+        if (a.dbg & 8) { for (int q = 0; q < KREG; q++) nbr_reg[q] = 0xFFFFFFFFu; w = 0.5f; scale_f = 1.f; }
+        const uint32_t chunk = (a.begin >> 6) + ((p - a.begin) >> 6);
+        // the sample's last repetition (its only one unless the edge repeats inside the step): negatives drawn and their rows requested
+        // now; its attraction runs in the lane's turn, its repulsions -- they move y_i only -- after the turns, all lanes side by side
+        SplitSample<DIM, F64, TILE> sm;
+        uint32_t neg[5], got = 0;
+        if (cmp) {
+            got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
+            if (a.dbg & 4) { got = 0; for (int g = 0; g < 5; g++) neg[g] = TILE ? 0u : i; }
+            sm.fetch(c, sh.tile, neg);
+        }
+        for (uint32_t t = 0;; t++) {
+            if (t >= 1u) {   // (only chunks with chains get here)
+                float in[DIM];
+#pragma unroll
+                for (int q = 0; q < DIM; q++) in[q] = __shfl_up(yj[q], 1);
+                if (t == 1u && cont && lane == 0) {   // the target's row as the previous chunk left it
+                    const uint32_t token = a.step_seq + 1u;
+                    uint32_t polls = 0;
+                    while (__hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++polls > (1u << 24)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 2u); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    load_row_agent<DIM>(c.y, j, in);
+                }
+                if (act0 && runpos == t) {
+#pragma unroll
+                    for (int q = 0; q < DIM; q++) yj[q] = in[q];
+                }
+            }
+            if (cmp && runpos == t && !(a.dbg & 1)) {
+                for (uint32_t q = 0; q + 1u < rep; q++) {   // earlier repetitions of the edge: whole samples, one after the other
+                    uint32_t ng[5];
+                    const uint32_t gt = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng);
+                    run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
+                }
+                sm.attract(c, yi, yj, w, scale_f, a.step);
+            }
+            if (!__ballot(act0 && runpos > t)) break;
+        }
+        if (cmp) {
+            if (!(a.dbg & 1)) sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
+            else if (got == 77u) yi[0] += (float)neg[0];
+            done += rep;
+        }
+        // stores: the source's row by every lane that computed, the target's row by the last lane of its chain segment -- written through
+        // and announced where the chain goes on in the next chunk
+        const bool store_j = act0 && last_in_seg && !hand_over;
+        if (!(a.dbg & 2)) {
+            row_store<DIM>(c.y, j, store_j, stage, yj);  // :1239
+            row_store<DIM>(c.y, i, cmp, stage, yi);      // :1301
+        } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
+            row_store<DIM>(c.y, i, cmp, stage, yi);
+        }
+        if (hand_over) {
+            store_row_agent<DIM>(c.y, j, yj);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&a.chunk_flag[chunk], a.step_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (base < a.end) pass(0u, std::true_type{});  // (uniform over the workgroup)
+    for (uint32_t r = 1; r < a.ept && base + r * 256u < a.end; r++) pass(r, std::false_type{});
+}
+
+template <int DIM, int SREC, bool F64, bool TILE>
+__global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
+    __shared__ StepShared<DIM, SREC, F64, TILE> sh;
+    uint32_t done = 0;
+    sl_step_body<DIM, SREC, F64, TILE>(a, blockIdx.x, sh, done);
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the overflow class of a slice: optimistic passes (sl_mark_kernel: ce_slice.hip)
+// ------------------------------------------------------------------------------------------------------------------
+// one pass: the pending events that own both their rows run, the others go to the next list and mark for the next pass
+template <int DIM, int SREC, bool F64, bool TILE>
+__global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
+    using T = TileShape<DIM>;
+    constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
+    __shared__ __attribute__((aligned(16))) float s_tile[TILE ? T::kRows * DIM : 4];
+    __shared__ __attribute__((aligned(16))) float s_stage[4 * kStageFloats<DIM, SREC>];
+    __shared__ uint32_t s_tnode[TILE ? T::kRows : 1];
+    __shared__ uint32_t s_wave_cnt[4], s_base;
+    const CeDev c = a.c;
+    const uint32_t sub = blockIdx.y, dsub = (blockIdx.x + blockIdx.y) % (uint32_t)kSub;
+    const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);  // (an overflowing append is flagged, never read back)
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap, dof = ((uint64_t)a.dst_list * kSub + dsub) * a.cap;
+    const uint32_t* own_chk = a.owner + (uint64_t)a.owner_chk * c.n;
+    uint32_t* own_mark = a.owner + (uint64_t)a.owner_mark * c.n;
+    const bool hub = c.hub_odds != nullptr;
+    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
+    const uint32_t wkey = pcg_hash(nkey + a.pass_seq * 0x9E3779B9u) + (blockIdx.x * (uint32_t)kSub + sub) * 64u;
+    float* stage = s_stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
+    unsigned long long done = 0;
+    // one trip over 256 pending events; FIRST (compile-time, see sl_direct_kernel): the trip that also stages the tile -- its loads are
+    // issued behind the ownership checks and travel while the rows are requested
+    auto trip = [&](uint64_t t0, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint64_t t = t0 + threadIdx.x;
+        const bool have = t < total;
+        Pending p = a.lists[so + (have ? t : 0)];
+        if (!have) p = Pending{0, 0, 0, 0};
+        const uint32_t o1 = own_chk[p.im >> 5], o2 = own_chk[p.j];
+        TileFetch<DIM> ft;
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
+        const bool win = have && o1 == p.idx && o2 == p.idx;
+        const uint32_t i = p.im >> 5, idx = p.idx;
+        // everything that depends only on (i, j): both rows, the static record of i -- in flight together.  Plain (cached) loads: a
+        // pass is a launch of its own, everything earlier passes wrote is visible, and the rows this event owns are touched by
+        // nobody else during the pass
+        float yi[DIM], yj[DIM], scale_f = 1.f, w = 0.f;
+        uint32_t nbr_reg[KREG];
+        RecFetch<SREC, KREG> fr;
+        RowFetch<DIM> fi, fj;
+        fr.issue(a.srec, i, p.im & 31u, win, scale_f, w, nbr_reg);
+        fi.issue(c.y, i, win, yi);
+        fj.issue(c.y, p.j, win, yj);
+        if constexpr (TILE && FIRST) ft.land(s_tile, s_tnode);
+        fr.land(stage, p.im & 31u, win, scale_f, w, nbr_reg);
+        fi.land(stage, yi);
+        fj.land(stage, yj);
+        if (win) {
+            uint32_t neg[5];
+            const uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_tnode, pcg_hash(nkey + idx), i, nbr_reg, neg);
+            run_sample<DIM, F64, TILE>(c, s_tile, yi, yj, w, scale_f, a.step, neg, got);
+            done++;
+        }
+        row_store<DIM>(c.y, p.j, win, stage, yj);  // :1239
+        row_store<DIM>(c.y, i, win, stage, yi);    // :1301
+        // deferred: append to the next list (one atomic per workgroup, on one of kSub counters), mark for the next pass
+        const bool defer = have && !win;
+        const unsigned long long m = __ballot(defer);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave_cnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            s_base = tot ? atomicAdd(&a.counts[a.dst_list * kSub + dsub], tot) : 0u;
+        }
+        __syncthreads();
+        if (defer) {
+            uint32_t before = 0;
+            for (int q = 0; q < wv; q++) before += s_wave_cnt[q];
+            const uint32_t pos = s_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pos < a.cap) {
+                a.lists[dof + pos] = p;
+                const bool mark = !a.backoff || (pcg_hash(idx ^ pcg_hash(a.pass_seq ^ kTagSlCoin)) & 1u);
+                if (mark) {
+                    own_mark[i] = idx;
+                    own_mark[p.j] = idx;
+                }
+            } else {
+                atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+            }
+        }
+        __syncthreads();  // s_wave_cnt / s_base are reused by the next trip
+    };
+    // (a tile pass is a slice's first: its grid covers the list in one trip; a workgroup without events leaves at once)
+    const uint64_t t_first = blockIdx.x * 256ull, t_step = (uint64_t)gridDim.x * 256ull;
+    if (t_first < total) trip(t_first, std::true_type{});
+    for (uint64_t t0 = t_first + t_step; t0 < total; t0 += t_step) trip(t0, std::false_type{});
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;
+}
+
+constexpr uint32_t kNil = 0xFFFFFFFFu;
+// chain rounds (link / unlink kernels and the description: ce_slice.hip)
+template <int DIM, int SREC, bool F64>
+__global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next) {
+    constexpr int KP = (SREC - 1) / 2, KREG = KP < 32 ? KP : 32;
+    const CeDev c = a.c;
+    const uint32_t sub = blockIdx.y;
+    const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);
+    const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap;
+    const Pending* src = a.lists + (uint64_t)a.src_list * kSub * a.cap;  // position = sub-list * cap + index
+    const bool hub = c.hub_odds != nullptr;
+    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
+    unsigned long long done = 0;
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
+        const Pending p0 = a.lists[so + t];
+        const uint32_t pos = (uint32_t)((uint64_t)sub * a.cap + t);
+        if (head[p0.j] != pos) continue;  // the head of its target's list walks it
+        float yj[DIM];
+        load_row<DIM>(c.y, p0.j, yj);
+        uint32_t cur = pos, nxt = next[pos];
+        Pending e = p0;
+        for (;;) {
+            Pending en{0u, 0u, 0u, 0u};
+            uint32_t nn = kNil;
+            if (nxt != kNil) { en = src[nxt]; nn = next[nxt]; }  // the next link travels while this event runs
+            const uint32_t i = e.im >> 5;
+            if (a.owner[i] == e.idx && head[i] == kNil) {
+                float yi[DIM];
+                load_row<DIM>(c.y, i, yi);
+                const float* r = a.srec + (uint64_t)i * SREC;
+                const float scale_f = r[0], w = r[1 + KP + (e.im & 31u)];
+                uint32_t nbr_reg[KREG];
+#pragma unroll
+                for (int q = 0; q < KREG; q++) nbr_reg[q] = __float_as_uint(r[1 + q]);
+                uint32_t neg[5];
+                const uint32_t got = draw_negatives<DIM, KREG, false>(c, hub, nullptr, pcg_hash(nkey + e.idx), i, nbr_reg, neg);
+                run_sample<DIM, F64, false>(c, nullptr, yi, yj, w, scale_f, a.step, neg, got);
+                store_row<DIM>(c.y, i, yi);  // :1301
+                done++;
+            } else {  // the source is claimed by another event or is a target of this round: next round
+                const uint32_t dsub = (cur + blockIdx.x) % (uint32_t)kSub;
+                const uint32_t at = atomicAdd(&a.counts[a.dst_list * kSub + dsub], 1u);
+                if (at < a.cap) a.lists[((uint64_t)a.dst_list * kSub + dsub) * a.cap + at] = e;
+                else atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
+            }
+            if (nxt == kNil) break;
+            cur = nxt; e = en; nxt = nn;
+        }
+        store_row<DIM>(c.y, p0.j, yj);  // :1239
+    }
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[a.zero_list * kSub + sub] = 0;
+}
+template <int DIM, bool F64>
+void launch_chain_run2(const SliceArgs& a, unsigned grid, uint32_t srec, const uint32_t* head, const uint32_t* next) {
+    if (srec == 16) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 16, F64>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else if (srec == 32) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 32, F64>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else if (srec == 64) hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 64, F64>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+    else hipLaunchKernelGGL((sl_chain_run_kernel<DIM, 128, F64>), dim3(grid, kSub), dim3(256), 0, stream(), a, head, next);
+}
+template <int DIM>
+void launch_chain_run(const SliceArgs& a, unsigned grid, uint32_t srec, bool f64, const uint32_t* head, const uint32_t* next) {
+    if (f64) launch_chain_run2<DIM, true>(a, grid, srec, head, next); else launch_chain_run2<DIM, false>(a, grid, srec, head, next);
+}
+
+template <int DIM, bool F64, bool TILE>
+void launch_exec3(const SliceArgs& a, unsigned grid, uint32_t srec) {
+    if (srec == 16) hipLaunchKernelGGL((sl_exec_kernel<DIM, 16, F64, TILE>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+    else if (srec == 32) hipLaunchKernelGGL((sl_exec_kernel<DIM, 32, F64, TILE>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+    else if (srec == 64) hipLaunchKernelGGL((sl_exec_kernel<DIM, 64, F64, TILE>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+    else hipLaunchKernelGGL((sl_exec_kernel<DIM, 128, F64, TILE>), dim3(grid, kSub), dim3(256), 0, stream(), a);
+}
+template <int DIM>
+void launch_exec(const SliceArgs& a, unsigned grid, uint32_t srec, bool f64) {
+    const bool tile = a.tile && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    if (f64) { if (tile) launch_exec3<DIM, true, true>(a, grid, srec); else launch_exec3<DIM, true, false>(a, grid, srec); }
+    else { if (tile) launch_exec3<DIM, false, true>(a, grid, srec); else launch_exec3<DIM, false, false>(a, grid, srec); }
+}
+template <int DIM, bool F64, bool TILE>
+void launch_direct3(const DirectArgs& a, uint32_t srec) {
+    const unsigned grid = (a.end - a.begin + 256u * a.ept - 1u) / (256u * a.ept);
+    if (srec == 16) hipLaunchKernelGGL((sl_direct_kernel<DIM, 16, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else if (srec == 32) hipLaunchKernelGGL((sl_direct_kernel<DIM, 32, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else if (srec == 64) hipLaunchKernelGGL((sl_direct_kernel<DIM, 64, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else hipLaunchKernelGGL((sl_direct_kernel<DIM, 128, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+}
+// workgroups of the step kernel that one CU holds at a time (registers / LDS of the instantiation that would run)
+template <int DIM, bool F64, bool TILE>
+int direct_blocks_per_cu3(uint32_t srec) {
+    int nb = 0;
+    hipError_t e;
+    if (srec == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sl_direct_kernel<DIM, 16, F64, TILE>, 256, 0);
+    else if (srec == 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sl_direct_kernel<DIM, 32, F64, TILE>, 256, 0);
+    else if (srec == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sl_direct_kernel<DIM, 64, F64, TILE>, 256, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sl_direct_kernel<DIM, 128, F64, TILE>, 256, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+template <int DIM>
+void direct_blocks_per_cu(uint32_t srec, bool f64, bool tile, int* out) {
+    if (f64) *out = tile ? direct_blocks_per_cu3<DIM, true, true>(srec) : direct_blocks_per_cu3<DIM, true, false>(srec);
+    else *out = tile ? direct_blocks_per_cu3<DIM, false, true>(srec) : direct_blocks_per_cu3<DIM, false, false>(srec);
+}
+template <int DIM>
+void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
+    const bool tile = a.tile && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    if (f64) { if (tile) launch_direct3<DIM, true, true>(a, srec); else launch_direct3<DIM, true, false>(a, srec); }
+    else { if (tile) launch_direct3<DIM, false, true>(a, srec); else launch_direct3<DIM, false, false>(a, srec); }
+}
+
+// The launchers are instantiated one row stride per translation unit (ce_slice_dim*.hip define AE_SL_INSTANTIATE_DIM); everybody else
+// only sees the declarations.
+#define AE_SL_LAUNCHERS(PREFIX, D)                                                                                                        \
+    PREFIX template void launch_direct<D>(const DirectArgs&, uint32_t, bool);                                                             \
+    PREFIX template void direct_blocks_per_cu<D>(uint32_t, bool, bool, int*);                                                             \
+    PREFIX template void launch_exec<D>(const SliceArgs&, unsigned, uint32_t, bool);                                                      \
+    PREFIX template void launch_chain_run<D>(const SliceArgs&, unsigned, uint32_t, bool, const uint32_t*, const uint32_t*);
+#ifdef AE_SL_INSTANTIATE_DIM
+AE_SL_LAUNCHERS(, AE_SL_INSTANTIATE_DIM)
+#else
+AE_SL_LAUNCHERS(extern, 2)
+AE_SL_LAUNCHERS(extern, 3)
+AE_SL_LAUNCHERS(extern, 4)
+AE_SL_LAUNCHERS(extern, 8)
+AE_SL_LAUNCHERS(extern, 16)
+AE_SL_LAUNCHERS(extern, 32)
+AE_SL_LAUNCHERS(extern, 64)
+#endif
+
+}  // namespace sl
+}  // namespace ae

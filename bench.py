@@ -117,10 +117,19 @@ MODE_KERNEL = {0: "ce_round_node_kernel (one launch per round)",
                5: "sl_direct_kernel (one launch per colour class and time slice) / sl_exec_kernel (optimistic passes of the overflow class); whole batch incl. event generation and sort"}
 
 
-def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo=0, hi=None, comm=None, exchanges=1, fence=None, hub=None):
+def mode_dtype(mode, precision=0):
+    """the arithmetic a CE mode computes in (coordinates / scalar coefficients); the reference: f32 coordinates, f64 scalars (embedder.rs:1207-1229)"""
+    if mode == 0:
+        return "f32 coordinates, f32 scalars (rounds mode: narrower than the reference)"
+    if mode == 5 and precision == 1:
+        return "f32 coordinates, f32 scalars (ce_precision = AE_PRECISION_F32: an explicit opt-in, narrower than the reference)"
+    return "f32 coordinates, f64 scalars (the reference's)"
+
+
+def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo=0, hi=None, comm=None, exchanges=1, fence=None, hub=None, precision=0):
     """`warmup` untimed + `steps` timed CE batches of one mode; returns timing and the per-launch roofline inputs"""
     params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=mode,
-                              hubness_weighting=hub is not None)
+                              hubness_weighting=hub is not None, ce_precision=precision)
     eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi, hub_counts=hub)
     if comm is not None:
         comm.attach(eo, exchanges)
@@ -148,11 +157,12 @@ def time_mode(A, L, kg, node_params, y0, d, mode, steps, warmup, nb_batch=25, lo
     sliced = None
     if resolved == 5:
         cl, ovf, crounds, slices = eo.slice_info()
-        sliced = {"matching_classes": cl, "overflow_mass_fraction": ovf, "colouring_rounds": crounds, "slices_per_batch": slices,
-                  "step_launches_per_batch": slices * cl}
+        indeg_max, chain_len = eo.slice_hub_info()
+        sliced = {"classes": cl, "overflow_mass_fraction": ovf, "colouring_rounds": crounds, "slices_per_batch": slices,
+                  "step_launches_per_batch": slices * cl, "max_in_degree": indeg_max, "longest_chain_per_step_expected": chain_len}
     dominant_ms = eo.dataflow_time()[0] if resolved in (1, 6) else None  # the dataflow kernel alone (the batch also plans, sorts, searches)
     return dict(eo=eo, elapsed=elapsed, ms_per_step=elapsed / steps * 1e3, kernel_ms=kernel_ms, batches_timed=int(launches), rounds=rounds,
-                mode=resolved, nb_sample=nb_sample, ce_before=ce_before, ce_after=eo.ce_compute_threaded(), dominant_ms=dominant_ms, sliced=sliced)
+                mode=resolved, nb_sample=nb_sample, dtype=mode_dtype(resolved, precision), ce_before=ce_before, ce_after=eo.ce_compute_threaded(), dominant_ms=dominant_ms, sliced=sliced)
 
 
 def roofline_of(run, k, d):
@@ -181,7 +191,7 @@ def full_schedule(A, kg, node_params, y0, d, mode, nb_batch=25):
     return y, ce
 
 
-def higgs_shaped_points(n, dim=28, ncomp=64, seed=2):
+def higgs_shaped_points(n, dim=28, ncomp=64, seed=2, with_labels=False):
     """configs[2] stand-in: mixture of 64 Gaussians in 28-D with per-column standardisation (examples/higgs.rs:158-176)"""
     rng = np.random.default_rng(seed)
     means = rng.normal(size=(ncomp, dim)) * 2.0
@@ -189,54 +199,165 @@ def higgs_shaped_points(n, dim=28, ncomp=64, seed=2):
     lab = rng.integers(0, ncomp, n)
     x = means[lab] + scales[lab] * rng.normal(size=(n, dim))
     x = (x - x.mean(0)) / x.std(0)
-    return np.ascontiguousarray(x.astype(np.float32))
+    x = np.ascontiguousarray(x.astype(np.float32))
+    return (x, lab) if with_labels else x
 
 
-def scale_shape(A, L, name, n, k, d, steps, with_sequential, knn_points=None):
-    """configs[2] / configs[3] shapes on one GPU.  Default: the node-permuted lattice graph (uniform in-degree).  knn_points: the
-    EXACT kNN graph of those points instead -- real in-degree skew (hubs), hubness-weighted negative sampling as examples/higgs.rs
-    switches it on (:204-242)."""
+def mixture_points_gpu(n, dim, ncomp, seed, mean_sigma, higgs_like=False):
+    """Gaussian-mixture points generated on the GPU, SORTED BY COMPONENT -> (host float32[n, dim], component bounds int64[ncomp + 1]).
+    higgs_like: configs[3]'s generator (per-component scales 0.5-1.5, means N(0, 2^2), columns standardised -- higgs_shaped_points'
+    law); else configs[4]'s (means N(0, mean_sigma^2), sigma 1, equal-size components)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    means = rng.normal(size=(ncomp, dim)) * (2.0 if higgs_like else mean_sigma)
+    scales = (0.5 + rng.random((ncomp, dim))) if higgs_like else np.ones((ncomp, dim))
+    if higgs_like:
+        counts = np.bincount(rng.integers(0, ncomp, n), minlength=ncomp)
+    else:
+        counts = np.full(ncomp, n // ncomp)
+        counts[:n - counts.sum()] += 1
+    bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    for c in range(ncomp):
+        b, e = int(bounds[c]), int(bounds[c + 1])
+        x[b:e] = torch.randn((e - b, dim), generator=g, device="cuda") * torch.from_numpy(scales[c].astype(np.float32)).cuda() \
+            + torch.from_numpy(means[c].astype(np.float32)).cuda()
+    if higgs_like:
+        x = (x - x.mean(0)) / x.std(0)
+    xh = x.cpu().numpy()
+    del x
+    torch.cuda.empty_cache()
+    return xh, bounds
+
+
+def component_knn_graph(A, x, bounds, k, permute_seed):
+    """Exact kNN graph INSIDE every mixture component (the blocks of rows `bounds`), one brute-force pass on the matrix cores per
+    component.  SURVEY 8d prescribes this for configs[4] (1 000 well separated components: it equals the global kNN graph w.h.p.; the
+    separation is checked below where it holds by construction); for the Higgs-shaped points, whose components overlap, it is the kNN
+    graph restricted to the component -- as approximate as the reference's own HNSW graph, with the in-degree skew (hubs) of the data.
+    permute_seed: node ids are randomly permuted afterwards (positive edges not memory-local, as for a graph in arbitrary order); None
+    keeps the component order (what a component partition over GPUs wants).  -> indptr, nbr, dist (host CSR)"""
+    n = len(x)
+    nbr = np.empty((n, k), np.uint32)
+    dist = np.empty((n, k), np.float32)
+    for c in range(len(bounds) - 1):
+        b, e = int(bounds[c]), int(bounds[c + 1])
+        if e - b <= k:
+            raise ValueError("component smaller than k")
+        g = A.KGraph.bruteforce_l2(x[b:e], k)
+        _, nb, ds = g.get_neighbours()
+        nbr[b:e] = nb.reshape(e - b, k) + np.uint32(b)
+        dist[b:e] = ds.reshape(e - b, k)
+        del g
+    if permute_seed is not None:
+        perm = np.random.default_rng(permute_seed).permutation(n).astype(np.uint32)  # old id -> new id
+        inv = np.empty(n, np.int64)
+        inv[perm] = np.arange(n)
+        nbr = perm[nbr][inv]
+        dist = dist[inv]
+    indptr = np.arange(n + 1, dtype=np.uint64) * np.uint64(k)
+    return indptr, np.ascontiguousarray(nbr.reshape(-1)), np.ascontiguousarray(dist.reshape(-1))
+
+
+def scale_shape(A, L, name, n, k, d, steps, with_sequential, graph=None, hub_weighting=False, dmap_start=None):
+    """configs[2] / [3] / [4]-shard shapes on one GPU.  graph None: the node-permuted ring lattice (uniform in-degree: the best case of
+    every faithful mode), started from its diffusion-map initialisation.  graph = dict(indptr, nbr, dist, desc, build_s): a kNN graph of
+    the config's own data (real in-degree skew: hubs), started from a random layout in the 10-box (a component-wise kNN graph is
+    disconnected: no diffusion-map start); hub_weighting: hubness-weighted negative sampling as examples/higgs.rs switches it on
+    (:204-242).  Every mode: `steps` timed batches after one warm-up (the rounds and bit-exact modes: 2), same start, so ce_after is
+    comparable across the modes of a shape."""
     import torch
     hub = None
-    if knn_points is None:
+    if graph is None:
         indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)
         kg = A.KGraph(indptr, nbr, dst, k)
-        graph = "ring lattice, node ids randomly permuted"
+        desc = "ring lattice, node ids randomly permuted (uniform in-degree: best case)"
     else:
+        kg = A.KGraph(graph["indptr"], graph["nbr"], graph["dist"], k)
+        desc = graph["desc"]
+    out = {"nodes": n, "k": k, "asked_dim": d, "graph": desc}
+    hubv = kg.hubness()
+    out["max_in_degree"] = int(hubv.max())
+    out["in_degree_q999"] = int(np.quantile(hubv, 0.999))
+    if hub_weighting:
+        hub = hubv
+        out["negative_sampling"] = "hubness-weighted (NodeSampler, embedder.rs:915-930)"
+    if dmap_start if dmap_start is not None else graph is None:
         t0 = time.perf_counter()
-        kg = A.KGraph.bruteforce_l2(knn_points, k)
-        knn_s = time.perf_counter() - t0
-        hub = kg.hubness()
-        graph = "exact kNN graph of %d Higgs-shaped points (28-D, 64 components), hubness-weighted negatives; max in-degree %d (mean %d); built in %.1f s" % (
-            n, int(hub.max()), k, knn_s)
-    t0 = time.perf_counter()
-    y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
-    L.check(L.load().ae_synchronize())
-    init_s = time.perf_counter() - t0
+        y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
+        L.check(L.load().ae_synchronize())
+        out["dmap_init_s"] = time.perf_counter() - t0
+        out["start"] = "diffusion-map initialisation"
+    else:
+        y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
+        out["start"] = "random normal layout in the 10-box"
+    if graph is not None:
+        out["graph_build_s"] = graph.get("build_s")
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
-    out = {"nodes": n, "k": k, "asked_dim": d, "graph": graph, "dmap_init_s": init_s}
-    if hub is not None:
-        out["max_in_degree"] = int(hub.max())
+
     def entry(r, faithful):
-        return {"faithful": faithful, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
-                "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "ce_after": r["ce_after"], "roofline": roofline_of(r, k, d)}
-    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, 2, 1, hub=hub)
-    r.pop("eo")
-    out["rounds_mode"] = entry(r, False)
-    r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SLICED, 2, 1, hub=hub)
-    r.pop("eo")
-    out["sliced_mode"] = entry(r, "statistically")
-    auto = A.EntropyOptim(kg, node_params, A.EmbedderParams(asked_dim=d, hubness_weighting=hub is not None), y0, hub_counts=hub)
-    out["default_mode_resolves_to"] = MODE_NAMES.get(auto.get_ce_mode())
-    del auto
-    if with_sequential:
-        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, 2, 1, hub=hub)
+        e = {"faithful": faithful, "ce_mode": MODE_NAMES.get(r["mode"]), "dtype": r["dtype"], "ms_per_step": r["ms_per_step"], "steps_timed": r["steps"],
+             "points_per_s": n / (r["ms_per_step"] * 1e-3), "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "ce_after": r["ce_after"],
+             "roofline": roofline_of(r, k, d)}
+        return e
+
+    def run(mode, nsteps, precision=0):
+        r = time_mode(A, L, kg, node_params, y0, d, mode, nsteps, 1, hub=hub, precision=precision)
         r.pop("eo")
-        out["exact_mode"] = entry(r, True)
-    out["note"] = "same number of batches from the same start in every mode: ce_after is comparable across the modes of a shape"
+        r["steps"] = nsteps
+        return r
+
+    out["rounds_mode"] = entry(run(A.AE_CE_HOGWILD, 2), False)
+    rs = run(A.AE_CE_SLICED, steps)
+    out["sliced_mode"] = entry(rs, "statistically")
+    out["sliced_mode_f32_scalars"] = entry(run(A.AE_CE_SLICED, 2, precision=1), "statistically (f32 scalars: an explicit opt-in, narrower than the reference)")
+    # what AE_CE_AUTO runs at this size, timed like every other mode
+    auto = A.EntropyOptim(kg, node_params, A.EmbedderParams(asked_dim=d, hubness_weighting=hub is not None), y0, hub_counts=hub)
+    resolved = auto.get_ce_mode()
+    del auto
+    if resolved == A.AE_CE_SLICED:
+        out["default_mode"] = dict(entry(rs, "statistically"), note="AE_CE_AUTO resolves to AE_CE_SLICED at this size: the sliced_mode run above")
+    else:
+        out["default_mode"] = entry(run(A.AE_CE_AUTO, max(5, steps)), "statistically")
+    if with_sequential:
+        out["parity_mode"] = entry(run(A.AE_CE_SEQUENTIAL, 2), True)
+    out["note"] = "same start and the same schedule in every mode: ce_after is comparable across the modes of a shape whose steps_timed agree"
     del kg, node_params
     torch.cuda.empty_cache()
     return out
+
+
+def exact_knn_graph(A, x, k, what):
+    """the EXACT kNN graph of all the points (one brute-force pass on the matrix cores)"""
+    t0 = time.perf_counter()
+    kg = A.KGraph.bruteforce_l2(x, k)
+    indptr, nbr, dist = kg.get_neighbours()
+    del kg
+    dt = time.perf_counter() - t0
+    return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": dt, "desc": "exact kNN graph (k = %d) of %d %s; built in %.1f s" % (k, len(x), what, dt)}
+
+
+def config_graphs(A, which):
+    """the configs' own kind of graph for the scale shapes (SURVEY 8d generators; exact kNN inside every mixture component, node ids
+    randomly permuted): 'c4' = configs[3] (11 M Higgs-shaped points, k 6), 'c5' = one GPU's eighth of configs[4] (6.25 M points of the
+    128-D mixture: 125 of its 1 000 components of 50 000 points, k 10)."""
+    t0 = time.perf_counter()
+    if which == "c4":
+        n, dim, ncomp, k = 11_000_000, 28, 64, 6
+        x, bounds = mixture_points_gpu(n, dim, ncomp, seed=3, mean_sigma=2.0, higgs_like=True)
+        what = "Higgs-shaped points (28-D, 64 overlapping Gaussian components, columns standardised; SURVEY 8d, seed 3)"
+    else:
+        n, dim, ncomp, k = 6_250_000, 128, 125, 10
+        x, bounds = mixture_points_gpu(n, dim, ncomp, seed=4, mean_sigma=10.0)
+        what = "points of the 128-D mixture (125 of configs[4]'s 1 000 components of 50 000 points: means N(0, 10^2), sigma 1; SURVEY 8d, seed 4)"
+    t1 = time.perf_counter()
+    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=9)
+    del x
+    t2 = time.perf_counter()
+    return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0,
+            "desc": "kNN graph (k = %d) of %d %s, exact inside every component, node ids randomly permuted; points %.1f s, graph %.1f s" % (
+                k, n, what, t1 - t0, t2 - t1)}
 
 
 def main():
@@ -421,10 +542,14 @@ def main():
         scale_shapes = {
             "c3_shape": scale_shape(A, L, "c3", 1_650_000, 6, 2, 6, with_sequential=True),
             # configs[2] again on a graph with REAL in-degree skew: exact kNN of the Higgs-shaped points, hubness weighting on
-            "c3_knn_shape": scale_shape(A, L, "c3knn", 1_650_000, 6, 2, 6, with_sequential=True, knn_points=higgs_shaped_points(1_650_000)),
-            "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 4, with_sequential=True),
-            # configs[4]: one GPU's eighth of the 50 M nodes as a graph of its own (k = 10, 16-D)
-            "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 4, with_sequential=False),
+            "c3_knn_shape": scale_shape(A, L, "c3knn", 1_650_000, 6, 2, 6, with_sequential=True, hub_weighting=True, dmap_start=True,
+                                        graph=exact_knn_graph(A, higgs_shaped_points(1_650_000), 6, "Higgs-shaped points (28-D, 64 components)")),
+            # configs[3] on its own kind of graph: 11 M Higgs-shaped points, hubness weighting on as examples/higgs.rs:204-242
+            "c4_knn_shape": scale_shape(A, L, "c4knn", 11_000_000, 6, 8, 5, with_sequential=False, hub_weighting=True, graph=config_graphs(A, "c4")),
+            "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 5, with_sequential=True),
+            # configs[4]: one GPU's eighth of the 50 M nodes as a graph of its own (k = 10, 16-D) -- the mixture's kNN graph, then the lattice
+            "c5_shard_knn_shape": scale_shape(A, L, "c5knn", 6_250_000, 10, 16, 5, with_sequential=False, graph=config_graphs(A, "c5")),
+            "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 5, with_sequential=False),
         }
 
     roof = roofline_of(head, k, d)

@@ -130,12 +130,14 @@ enum {
        AE_CE_AUTO refuses it with AE_ERR_INVALID_ARG -- ask for AE_CE_HOGWILD by name.  ae_entropy_optim_get_ce_mode reports
        the choice. */
     AE_CE_AUTO = 4,
-    /* Time-sliced execution on conflict-free matchings (ce_slice.hip): the batch's events (the same edge-keyed Poisson process
-       as AE_CE_EVENT) are cut into thin time slices; the graph's edges are coloured once (a proper edge colouring: every class is
-       a matching), and a step = the events of one class in one slice is one launch in which no two samples share a row: every
-       lane applies its sample exactly as src/embedder.rs:1207-1301 (both rows, one gradient), class order drawn afresh per slice.
-       Edges without a colour (hubs) and, on graphs of a few million edges, all of them run optimistically instead: an event that
-       holds both its rows exclusively runs, the others are deferred to the next pass.  Scalar arithmetic as `ce_precision` says (default:
+    /* Time-sliced execution on conflict-free classes (ce_slice.hip): the batch's events (the same edge-keyed Poisson process
+       as AE_CE_EVENT) are cut into thin time slices; the graph's edges are coloured once so that every class is a forest of in-stars
+       (no node is the source of two edges of a class, none source of one and target of another; max row length + 5 classes whatever
+       the in-degrees), and a step = the events of one class in one slice is one launch: every lane applies its sample exactly as
+       src/embedder.rs:1207-1301 (both rows, one gradient); the events of a step that share their target run as a chain through the
+       target's row (the reference: the row's lock); class order drawn afresh per slice.  The few edges without a colour and, on
+       graphs of a few million edges, all of them run optimistically instead: an event that holds both its rows exclusively runs,
+       the others are deferred to the next pass.  Scalar arithmetic as `ce_precision` says (default:
        the reference's f64 scalars).  Statistical
        parity like AE_CE_EVENT, throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes, one device. */
     AE_CE_SLICED = 5,
@@ -392,6 +394,11 @@ int32_t ae_entropy_optim_get_ce_mode(const ae_entropy_optim *o, uint32_t *ce_mod
    rounds the colouring took, and the time slices of the last batch.  AE_ERR_STATE for a handle in another mode. */
 int32_t ae_entropy_optim_slice_info(const ae_entropy_optim *o, uint32_t *classes, double *overflow_fraction,
                                     uint32_t *colouring_rounds, uint32_t *slices_last_batch);
+/* AE_CE_SLICED: hubs.  The classes of the colouring are forests of in-stars: the events of a step that share their TARGET run as a
+   chain through the target's row, as the row's lock serialises them in the reference (embedder.rs:942,1185-1186,1239,1301).
+   max_in_degree: the largest in-degree of the graph (the reference's hubness count, src/fromhnsw/hubness.rs:39-76);
+   busiest_row_events_per_step: the expected length of the longest chain of a step (0 when everything runs optimistically). */
+int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim *o, uint32_t *max_in_degree, double *busiest_row_events_per_step);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);
 /* gradient_iteration_threaded(nb_sample, grad_step) (embedder.rs:1311-1315).  `iter` keys the RNG
