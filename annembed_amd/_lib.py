@@ -130,6 +130,7 @@ SIGNATURES = {
     "ae_comm_destroy": [_vp],
     "ae_comm_all_reduce_sum": [_vp, _P(C.c_double)],
     "ae_entropy_optim_set_comm": [_vp, _vp, C.c_uint32],
+    "ae_entropy_optim_comm_bytes": [_vp, _P(_u64)],
     "ae_entropy_optim_slice_info": [_vp, _P(C.c_uint32), _P(C.c_double), _P(C.c_uint32), _P(C.c_uint32)],
     "ae_entropy_optim_slice_hub_info": [_vp, _P(C.c_uint32), _P(_f64)],
     "ae_entropy_optim_ce": [_vp, _P(_f64)],

@@ -323,6 +323,12 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_slice_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
 
+    def comm_bytes(self):
+        """bytes of coordinate rows received through the exchanges of this handle's batches (multi-GPU)"""
+        v = C.c_uint64()
+        check(L.load().ae_entropy_optim_comm_bytes(self._h, C.byref(v)))
+        return v.value
+
     def slice_hub_info(self):
         """AE_CE_SLICED: (largest in-degree of the graph, expected length of the longest chain of a step)"""
         a, b = C.c_uint32(), C.c_double()

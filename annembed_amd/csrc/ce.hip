@@ -945,19 +945,22 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 // samples the ordered dataflow (AE_CE_ORDERED: the sequential order, end points sequentially consistent, negatives as the memory
 // system has them -- half the latency of the bit-exact AE_CE_SEQUENTIAL, which stays the parity mode, by name), beyond that the
 // time-sliced mode (throughput-bound, a tenth of the memory).  The cross-over depends on the graph: ~30 M samples per batch on the
-// node-permuted lattice of the scale benchmarks (uniform in-degree: few conflicts, the time-sliced mode's best case), ~250 M on the
-// exact kNN graph of Higgs-shaped points with hubness weighting (1.65 M nodes / 100 M samples: ordered 50 ms, sliced 67; 3.3 M / 200 M:
-// 102 against 110 ms) -- the rule follows the real graph.  Every asked_dim in
-// [1, 64] has both (rows are stored zero-padded, ce_internal.h).  A sharded node range has no faithful schedule: AUTO refuses it
-// -- the caller asks for the approximate rounds mode (AE_CE_HOGWILD) by name.
+// node-permuted lattice of the scale benchmarks (uniform in-degree: few conflicts), ~250 M on the exact kNN graph of Higgs-shaped points
+// with hubness weighting as round 3 measured it -- the rule follows the real graph.  Every asked_dim in [1, 64] has both (rows are stored
+// zero-padded, ce_internal.h).  A SHARDED node range (multi-GPU) resolves to the time-sliced mode: it runs a shard's own events on
+// current rows and reads the other shards' rows as of the last exchange -- faithful where few edges cross shards (a partition by
+// connected components / locality; ce_slice_prepare refuses a shard with more than 10 % of its edge mass on cross-shard edges, and
+// the caller then asks for the approximate rounds mode, AE_CE_HOGWILD, by name).
 constexpr uint64_t kAutoOrderedSamples = 1ull << 27;
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
     if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;
-    if (sharded)
-        fail(AE_ERR_INVALID_ARG, "AE_CE_AUTO does not shard: no schedule over several devices reproduces the reference's loop "
-                                 "(DESIGN 5); ask for the approximate rounds mode by name (ce_mode = AE_CE_HOGWILD) or run the whole graph on one device");
     const bool sliced_ok = max_nbng <= 32 && nnz < 0xFFFFFFFFull;
+    if (sharded) {
+        if (!sliced_ok) fail(AE_ERR_INVALID_ARG, "AE_CE_AUTO on a sharded node range needs the time-sliced mode (rows of <= 32 neighbours, < 2^32 edges); "
+                                                 "ask for the approximate rounds mode by name (ce_mode = AE_CE_HOGWILD)");
+        return AE_CE_SLICED;
+    }
     // (the ordered dataflow's scratch: 92 bytes of plan, sorted events and predecessors per sample + two published rows; long rows
     // at the top of the range would ask for more than a sixth of the device: 48 GB is the line)
     const uint64_t ordered_scratch = samples_per_batch * (92ull + 8ull * ae_pad_dim((uint32_t)dim));

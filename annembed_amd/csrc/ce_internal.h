@@ -128,7 +128,11 @@ struct ae_entropy_optim {
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
     DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)
+    uint64_t sl_gen_edges = 0;                  // edges this handle generates events for (a shard: those with an end in its node range)
+    double sl_gen_mass = 0.;                    // their probability mass (the whole graph: n)
+    double sl_cross_frac = 0.;                  // share of it on cross-shard edges (one end here, one elsewhere)
     DevBuf<float> sl_node_ov;                   // per node: probability mass of its overflow edges
+    float sl_node_ov_max = 0.f;                 // its maximum (the busiest row of the overflow class)
     DevBuf<float> sl_srec;                      // per node: static record {embedded scale, neighbour ids, edge probabilities}
     uint32_t sl_srec_floats = 16;
     uint32_t sl_classes = 0, sl_color_rounds = 0;
@@ -138,6 +142,7 @@ struct ae_entropy_optim {
     std::vector<uint64_t> comm_ranges;
     bool comm_equal = false;
     uint32_t comm_exchanges = 1;
+    uint64_t comm_bytes = 0;                    // bytes of coordinate rows received through exchanges since the handle was created (per rank: n x stride x 4 each)
     ~ae_entropy_optim() {
         if (df_ahead.prep) { (void)hipStreamSynchronize(df_ahead.prep); (void)hipStreamDestroy(df_ahead.prep); }
         if (df_ahead.run) { (void)hipStreamSynchronize(df_ahead.run); (void)hipStreamDestroy(df_ahead.run); }

@@ -171,22 +171,48 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
         if (s_m[t] != 0.) atomicAdd(&mass[t], s_m[t]);
 }
 // per node: the probability mass of its overflow edges (sizes the pending lists); per edge: the key that puts the edges of a class
-// that share a target side by side in the event-generation order (0: overflow edges, in graph order)
-__global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
+// that share a target side by side in the event-generation order (0: overflow edges, in graph order).  A sharded node range
+// [lo, hi) (multi-GPU): the edges this shard generates events for are those whose SOURCE it owns and -- as half events, flagged -- those
+// whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
+// mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
+constexpr uint32_t kDropKey = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                               float* __restrict__ node_ov, uint32_t* __restrict__ group_key, uint32_t* __restrict__ ident,
-                                                              int by_source) {
+                                                              int by_source, uint64_t lo, uint64_t hi, double* __restrict__ mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    if (e >= nnz) return;
-    const EdgeRec r = erec[e];
-    uint32_t key = 0;
-    if (color[e] == kOverflowColor) {
-        atomicAdd(&node_ov[r.im >> 5], r.w);
-        atomicAdd(&node_ov[r.j], r.w);
-    } else {
-        key = (by_source ? (r.im >> 5) : r.j) + 1u;   // (by_source: a timing experiment only -- chains would be torn apart)
+    double m_gen = 0., m_cross = 0.;
+    if (e < nnz) {
+        EdgeRec r = erec[e];
+        const uint32_t src = r.im >> 5;
+        const bool s_in = src >= lo && src < hi, t_in = r.j >= lo && r.j < hi;
+        uint32_t key = kDropKey;
+        if (s_in || t_in) {
+            r.flags = s_in ? 0u : kHalfEvent;
+            erec[e].flags = r.flags;
+            m_gen = (double)r.w;
+            if (!(s_in && t_in)) m_cross = (double)r.w;
+            if (color[e] == kOverflowColor) {
+                atomicAdd(&node_ov[src], r.w);
+                atomicAdd(&node_ov[r.j], r.w);
+                key = 0;
+            } else {
+                key = (by_source ? src : r.j) + 1u;   // (by_source: a timing experiment only -- chains would be torn apart)
+            }
+        }
+        group_key[e] = key;
+        ident[e] = (uint32_t)e;
     }
-    group_key[e] = key;
-    ident[e] = (uint32_t)e;
+    for (int off = 32; off > 0; off >>= 1) { m_gen += __shfl_xor(m_gen, off); m_cross += __shfl_xor(m_cross, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (m_gen != 0.) atomicAdd(&mass[0], m_gen);
+        if (m_cross != 0.) atomicAdd(&mass[1], m_cross);
+    }
+}
+__global__ void __launch_bounds__(256) sl_count_below_kernel(uint64_t nnz, const uint32_t* __restrict__ keys, uint32_t bound, unsigned long long* __restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t e = blockIdx.x * 256ull + threadIdx.x; e < nnz; e += (uint64_t)gridDim.x * 256ull) c += keys[e] < bound ? 1ull : 0ull;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 // the edges in event-generation order: out[x] = in[perm[x]]
 __global__ void __launch_bounds__(256) sl_permute_edges_kernel(uint64_t nnz, const uint32_t* __restrict__ perm, const EdgeRec* __restrict__ erec,
@@ -212,9 +238,9 @@ __global__ void __launch_bounds__(256) sl_backlog_kernel(uint64_t n, const float
 // events of a batch segment
 // ------------------------------------------------------------------------------------------------------------------
 // (e: position in the event-generation order of the edges, slice_color_edges)
-__global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, const EdgeRec* __restrict__ erec, float unit, uint32_t key, uint32_t* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, const EdgeRec* __restrict__ erec, float unit, uint32_t key, uint32_t* __restrict__ cnt) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    if (e >= c.nnz) return;
+    if (e >= n_gen) return;
     const uint32_t ck = round_hash_key(key, c.seed) ^ kTagSlCount;
     const float mu = unit * erec[e].w;
     const float u = edge_uniform(e, ck);
@@ -232,18 +258,18 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, const EdgeRec* _
 // edge fires at most once per slice -- a second event of the edge in a slice moves to the next one (its repeats would otherwise
 // run back to back inside the step, with no other event of their end points in between; with thin slices this touches < 1 %
 // of the events).
-__global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread,
                                                       uint32_t* __restrict__ keys, Event* __restrict__ vals) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    if (e >= c.nnz) return;
+    if (e >= n_gen) return;
     const uint32_t k = cnt[e], o = offs[e];
     if (!k) return;
     const uint32_t tk = pcg_hash(round_hash_key(key, c.seed) ^ kTagSlTime);
     const uint8_t cl = color[e];
     const EdgeRec er = erec[e];
-    const Event evv{er.im, er.j};
+    const Event evv{er.im, er.j | (er.flags & kHalfEvent)};
     constexpr uint32_t kSortMax = 24;
     __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge (dynamic indexing: LDS, not scratch)
     uint32_t* sl = s_sl + threadIdx.x;
@@ -331,7 +357,7 @@ __global__ void __launch_bounds__(256) sl_mark_kernel(SliceArgs a) {
         if (t < a.cap) {
             a.lists[dof + t] = p;
             a.owner[(uint64_t)a.owner_mark * a.c.n + (p.im >> 5)] = p.idx;
-            a.owner[(uint64_t)a.owner_mark * a.c.n + p.j] = p.idx;
+            a.owner[(uint64_t)a.owner_mark * a.c.n + ev_node(p.j)] = p.idx;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -362,8 +388,8 @@ __global__ void __launch_bounds__(256) sl_chain_link_kernel(SliceArgs a, uint32_
         // straight to the next list.  Two pending events i -> j and j -> i would otherwise wait for each other's row for ever (each
         // source is the target of a walked list); with the coin one of the two rows is free in half of the rounds.  (Tossing the coin
         // only for targets that are also sources of pending events was tried: more rounds, not fewer.)
-        if (pcg_hash(p.j ^ coin) & 1u) {
-            next[pos] = atomicExch(&head[p.j], pos);
+        if (pcg_hash(ev_node(p.j) ^ coin) & 1u) {
+            next[pos] = atomicExch(&head[ev_node(p.j)], pos);
             a.owner[p.im >> 5] = p.idx;
         } else {
             next[pos] = kNil;
@@ -378,7 +404,7 @@ __global__ void __launch_bounds__(256) sl_chain_unlink_kernel(SliceArgs a, uint3
     const uint32_t sub = blockIdx.y;
     const uint32_t total = min(a.counts[a.src_list * kSub + sub], (uint32_t)a.cap);
     const uint64_t so = ((uint64_t)a.src_list * kSub + sub) * a.cap;
-    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) head[a.lists[so + t].j] = kNil;
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) head[ev_node(a.lists[so + t].j)] = kNil;
 }
 
 // stable (LSD radix) sort of (step key, event) pairs on the key bits [0, end_bit)
@@ -404,8 +430,9 @@ bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event*
 
 namespace ae {
 
+constexpr double kMaxCrossShardMass = 0.10;
+
 const char* ce_slice_unsupported(const ae_entropy_optim* o) {
-    if (o->dev.node_lo != 0 || o->dev.node_hi != o->dev.n) return "a sharded node range (both rows of a sample must be on the device)";
     if (o->dev.nnz >= 0xFFFFFFFFull) return "more than 2^32 edges";
     if (o->dev.n > (1ull << 27)) return "more than 2^27 nodes";
     if (o->g->max_nbng > 32) return "rows of more than 32 neighbours";
@@ -416,7 +443,7 @@ const char* ce_slice_unsupported(const ae_entropy_optim* o) {
 // order of the edges (the edges of a class that share a target side by side)
 static void slice_color_edges(ae_entropy_optim* o) {
     const uint64_t n = o->dev.n, nnz = o->dev.nnz;
-    const EdgeRec* erec = reinterpret_cast<const EdgeRec*>(o->sl_erec.p);
+    EdgeRec* erec = reinterpret_cast<EdgeRec*>(o->sl_erec.p);
     o->sl_color.alloc(nnz);
     AE_HIP(hipMemsetAsync(o->sl_color.p, kNoColor, nnz, stream()));
     o->sl_node_ov.alloc(n);
@@ -424,17 +451,63 @@ static void slice_color_edges(ae_entropy_optim* o) {
     o->sl_classes = 0;
     o->sl_ov_frac = 1.0;
     o->sl_max_in_degree = 0;
+    o->sl_gen_edges = nnz;
+    o->sl_gen_mass = (double)n;
+    o->sl_cross_frac = 0.;
     o->sl_erec_gen.release();
     o->sl_color_gen.release();
     const unsigned grid = blocks_for(nnz, 256), ngrid = blocks_for(n, 256);
     DevBuf<uint32_t> group_key, ident;
     group_key.alloc_pooled(nnz); ident.alloc_pooled(nnz);
+    // Tail of both paths: overflow masses per node, the shard's edges (multi-GPU: node range [node_lo, node_hi)) with their half-event
+    // flags, and the event-generation order -- the overflow edges in graph order, then the class edges sorted by target (stable sort:
+    // the events of a step that share a target end up side by side); the edges of other shards are cut off.
+    auto finish = [&] {
+        DevBuf<double> gm;
+        gm.alloc_pooled(2);
+        gm.zero();
+        hipLaunchKernelGGL(sl_color_finish_kernel, dim3(grid), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, o->sl_node_ov.p,
+                           group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0, o->dev.node_lo, o->dev.node_hi, gm.p);
+        check_launch("sl_color_finish");
+        const std::vector<double> hg = gm.to_host();
+        {   // the busiest row of the overflow class (its events run one per pass)
+            DevBuf<uint32_t> mx;
+            mx.alloc_pooled(1);
+            mx.zero();
+            hipLaunchKernelGGL(sl_max_u32_kernel, dim3(grid_cap(n, 256, 1024)), dim3(256), 0, stream(), n, reinterpret_cast<const uint32_t*>(o->sl_node_ov.p), mx.p);
+            uint32_t bits = 0;   // (non-negative floats order like their bit patterns)
+            mx.download(&bits, 1);
+            memcpy(&o->sl_node_ov_max, &bits, 4);
+        }
+        o->sl_gen_mass = hg[0];
+        o->sl_cross_frac = hg[0] > 0. ? hg[1] / hg[0] : 0.;
+        const bool sharded = o->dev.node_lo != 0 || o->dev.node_hi != n;
+        if (!o->sl_classes && !sharded) { sync(); return; }   // (everything optimistic on one device: graph order as it is)
+        DevBuf<uint32_t> key_out, perm;
+        key_out.alloc_pooled(nnz); perm.alloc_pooled(nnz);
+        sort_pairs_u32_u32(group_key.p, key_out.p, ident.p, perm.p, nnz, 32);
+        // edges of this shard = keys below kDropKey (sorted: a binary search on the device would do; the count comes with the masses)
+        DevBuf<unsigned long long> cnt;
+        cnt.alloc_pooled(1);
+        cnt.zero();
+        hipLaunchKernelGGL(sl_count_below_kernel, dim3(grid_cap(nnz, 256, 2048)), dim3(256), 0, stream(), nnz, (const uint32_t*)key_out.p, kDropKey, cnt.p);
+        unsigned long long n_gen = 0;
+        cnt.download(&n_gen, 1);
+        o->sl_gen_edges = n_gen;
+        o->sl_erec_gen.alloc(std::max<uint64_t>(1, n_gen) * 4);
+        o->sl_color_gen.alloc(std::max<uint64_t>(1, n_gen));
+        if (n_gen)
+            hipLaunchKernelGGL(sl_permute_edges_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), (uint64_t)n_gen, (const uint32_t*)perm.p,
+                               (const EdgeRec*)erec, (const uint8_t*)o->sl_color.p, reinterpret_cast<EdgeRec*>(o->sl_erec_gen.p), o->sl_color_gen.p);
+        check_launch("sl_permute_edges");
+        sync();
+        o->sl_erec.release();   // (the generation order is what the batches read)
+        o->sl_color.release();
+    };
     auto all_optimistic = [&] {
         hipLaunchKernelGGL(sl_color_giveup_kernel, dim3(grid), dim3(256), 0, stream(), nnz, o->sl_color.p);
-        hipLaunchKernelGGL(sl_color_finish_kernel, dim3(grid), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, o->sl_node_ov.p,
-                           group_key.p, ident.p, 0);
         check_launch("sl_color");
-        sync();
+        finish();
     };
     // in-degrees (the reference's hubness counts, hubness.rs:39-76)
     DevBuf<uint32_t> indeg, dmax;
@@ -500,33 +573,14 @@ static void slice_color_edges(ae_entropy_optim* o) {
     DevBuf<double> mass;
     mass.alloc_pooled(kMaxClasses + 1);
     mass.zero();
-    hipLaunchKernelGGL(sl_class_mass_kernel, dim3(grid_cap(nnz, 256, 2048)), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, mass.p);
+    hipLaunchKernelGGL(sl_class_mass_kernel, dim3(grid_cap(nnz, 256, 2048)), dim3(256), 0, stream(), nnz, (const EdgeRec*)erec, (const uint8_t*)o->sl_color.p, mass.p);
     std::vector<double> hm = mass.to_host();
     double total = 0.;
     for (double v : hm) total += v;
-    hipLaunchKernelGGL(sl_color_finish_kernel, dim3(grid), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, o->sl_node_ov.p,
-                       group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0);
-    check_launch("sl_color_finish");
     o->sl_classes = classes;
     o->sl_ov_frac = total > 0. ? hm[kMaxClasses] / total : 0.;
     o->sl_color_rounds = round;
-    {
-        // event-generation order: the overflow edges in graph order, then the class edges sorted by target (stable): the events of a
-        // step that share a target end up side by side
-        DevBuf<uint32_t> key_out, perm;
-        key_out.alloc_pooled(nnz); perm.alloc_pooled(nnz);
-        unsigned bits = 1;
-        while (bits < 32 && ((n + 1) >> bits)) bits++;
-        sort_pairs_u32_u32(group_key.p, key_out.p, ident.p, perm.p, nnz, bits);
-        o->sl_erec_gen.alloc(nnz * 4);
-        o->sl_color_gen.alloc(nnz);
-        hipLaunchKernelGGL(sl_permute_edges_kernel, dim3(grid), dim3(256), 0, stream(), nnz, (const uint32_t*)perm.p, erec,
-                           (const uint8_t*)o->sl_color.p, reinterpret_cast<EdgeRec*>(o->sl_erec_gen.p), o->sl_color_gen.p);
-        check_launch("sl_permute_edges");
-        sync();
-        o->sl_erec.release();   // (the generation order is what the batches read)
-        o->sl_color.release();
-    }
+    finish();
     if (debug_knob("AE_CE_PROF"))
         fprintf(stderr, "CESLICE colouring: largest in-degree %u, %u classes (in-stars), %u rounds, overflow mass %.4f\n", indeg_max, classes, round, o->sl_ov_frac);
 }
@@ -547,6 +601,12 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     for (float v : hp) pmax = std::max(pmax, v);
     o->sl_pmax = pmax;
     slice_color_edges(o);
+    // A sharded range runs a cross-shard edge as two half events, each against a replica of the far end that is as old as the last
+    // exchange: fine for a few per cent of the edges (a partition by connected components has none), not for a graph in arbitrary order.
+    if ((o->dev.node_lo != 0 || o->dev.node_hi != g->n) && o->sl_cross_frac > kMaxCrossShardMass && !debug_knob("AE_SL_ANY_PARTITION"))
+        fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED on nodes [%llu, %llu): %.1f %% of the shard's edge probability mass lies on cross-shard edges (limit %.0f %%): "
+                                 "order the nodes by locality / connected component before sharding, or ask for the approximate rounds mode (AE_CE_HOGWILD)",
+             (unsigned long long)o->dev.node_lo, (unsigned long long)o->dev.node_hi, 100. * o->sl_cross_frac, 100. * kMaxCrossShardMass);
     o->sl_owner.alloc(2 * g->n);
     AE_HIP(hipMemsetAsync(o->sl_owner.p, 0xFF, sizeof(uint32_t) * 2 * g->n, stream()));
     o->sl_counts.alloc(3 * kSub);
@@ -560,13 +620,26 @@ void ce_slice_prepare(ae_entropy_optim* o) {
 void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
     if (const char* why = ce_slice_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: %s", why);
     const uint64_t n = o->dev.n, nnz = o->dev.nnz;
-    const double per_node = (double)nb_sample / (double)n;
+    // A sharded node range (multi-GPU): nb_sample counts this shard's samples (nb_sampling_by_edge x its edges); everything that shapes
+    // the batch -- segments, slices, exchange points -- follows the WHOLE graph's total so that every rank cuts the batch alike, and the
+    // per-edge Poisson means are the whole graph's law (edges are drawn in proportion to p_e over the whole graph, embedder.rs:987).
+    const bool sharded = o->dev.node_lo != 0 || o->dev.node_hi != n;
+    double total_samples = (double)nb_sample;
+    if (sharded) {
+        if (nb_sample % o->dev.shard_edges) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED on a sharded range: nb_sample must be a multiple of the shard's edges (nb_sampling_by_edge x edges)");
+        total_samples = (double)(nb_sample / o->dev.shard_edges) * (double)nnz;
+    }
+    const uint64_t n_gen = o->sl_gen_edges;   // edges this handle generates events for
+    const int world = o->comm ? comm_world(o->comm) : 1;
+    const double per_node = total_samples / (double)n;
     // segments of the batch: per-edge Poisson mean <= 64 (f32 inversion: exp(-64) is a normal number, the count is capped at 255),
     // at most 2^30 events per segment
     uint32_t segments = (uint32_t)std::max(1.0, std::ceil(per_node * (double)o->sl_pmax / 64.0));
-    segments = std::max(segments, (uint32_t)(nb_sample / (1ull << 30)) + 1u);
+    segments = std::max(segments, (uint32_t)(total_samples / (double)(1ull << 30)) + 1u);
     if (iter >= (1u << 20) || segments >= 4096) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: batch / segment index too large for the RNG key");
-    const double seg_samples = (double)nb_sample / segments;
+    const double seg_samples = total_samples / segments;                                        // the whole graph's events of a segment
+    const double seg_local = seg_samples * o->sl_gen_mass / (double)n;                          // this handle's (half events included)
+    const double seg_rank = o->comm ? seg_samples / (double)world : seg_local;                  // what every rank sizes its steps by
     // slices of a segment: about half an event per node and slice (a sample is an event at two nodes)
     const double lambda_s = debug_knob("AE_SL_LAMBDA") ? atof(debug_knob("AE_SL_LAMBDA")) : 0.5;
     uint32_t n_slices = (uint32_t)std::max(1.0, std::ceil(2.0 * seg_samples / (double)n / lambda_s));
@@ -582,13 +655,22 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (uint64_t)n * o->dev.dim * 4ull > (4ull << 20);
         AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
         const double resident = 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;   // (3 %: the classes' sizes and the Poisson totals scatter)
-        const double per_step = seg_samples * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
+        const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
         if (per_step > resident && per_step < 4.0 * resident)
-            n_slices = (uint32_t)std::ceil(seg_samples * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
+            n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
     }
     // passes per slice of the overflow class: a thin one (a few per cent of the events: conflicts among them are rare) runs once and
     // carries its losers into the next slice
     int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
+    // ... and as many as the BUSIEST row of the class needs: a pass runs one event per row, and a row that receives more overflow
+    // events per slice than the slice has passes runs its events late -- at the end of the batch, all of them after everybody else's.
+    // Measured on a graph of 16 tight components (64 k nodes, k = 6, in-degrees up to ~100, everything optimistic): 3 passes for ~4
+    // events per slice on the busiest rows ended at CE 0.90-0.96x the sequential mode's (edge lengths +5 ... +20 %) although the late
+    // events were < 1 % of all (the round-3 criterion for draining inside the slice); 6-8 passes: 1.000.
+    if (!debug_knob("AE_SL_PASSES") && o->sl_ov_frac > 0.) {
+        const double busiest = (double)o->sl_node_ov_max * (seg_samples / (double)n) / (double)n_slices;
+        passes = std::max(passes, (int)std::min(16.0, std::ceil(1.5 * busiest + 1.0)));
+    }
     const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : 1;
     // scalar arithmetic: the reference's f64 (embedder.rs:1207-1229) unless the caller opted into f32 (ae_embedder_params.ce_precision)
     const bool f64 = o->params.ce_precision != AE_PRECISION_F32;
@@ -597,10 +679,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint64_t n_keys = (uint64_t)n_slices * (classes + 1u);
     if (n_keys >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: too many steps in a batch");
     o->rounds = segments * n_slices;
-    const uint64_t ev_cap = (uint64_t)(seg_samples + 8.0 * std::sqrt(seg_samples) + 1024.0);
+    const uint64_t ev_cap = (uint64_t)(seg_local + 8.0 * std::sqrt(seg_local) + 1024.0);
     // pending lists of the overflow class: a slice's overflow events (+ 16 sigma) four times over, plus what the rows that receive
     // more overflow events than a slice's passes can run (hubs) accumulate until the drain
-    const double per_slice_ov = seg_samples / n_slices * o->sl_ov_frac;
+    const double per_slice_ov = seg_local / n_slices * o->sl_ov_frac;
     double backlog = 0.;
     if (has_overflow && passes == 1 && !debug_knob("AE_SL_PASSES")) {
         // One pass per slice serves a thin overflow class only while no ROW is busy in it: a row that receives more than a quarter of
@@ -625,7 +707,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_backlog.download(&backlog, 1);
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list
-    if (o->sl_cnt.n < nnz) { o->sl_cnt.alloc(nnz); o->sl_offs.alloc(nnz); }
+    if (o->sl_cnt.n < n_gen + 1) { o->sl_cnt.alloc(n_gen + 1); o->sl_offs.alloc(n_gen + 1); }
     if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(2 * ev_cap); o->sl_vals1.alloc(2 * ev_cap); }
     if (o->sl_sptr.n < n_keys + 2) o->sl_sptr.alloc(n_keys + 2);
     if (has_overflow && o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4);
@@ -688,6 +770,15 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         hipLaunchKernelGGL(sl_chain_unlink_kernel, dim3(grid, kSub), dim3(256), 0, stream(), a, o->sl_chain_head.p);
         cur = (cur + 1) % 3;
     };
+    // Multi-GPU: the owned rows are all-gathered `comm_exchanges` times per segment at equal runs of slices (the last one after the
+    // segment's drain): between two exchanges a shard reads the other shards' rows -- negatives, the far ends of its cross-shard
+    // edges -- as of the last one.  Every rank has the same slices (they follow the whole graph's totals), hence the same exchange points.
+    const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
+    auto exchange_after = [&](uint32_t s) {
+        if (exchanges < 2u) return;
+        const uint32_t q = (uint32_t)(((uint64_t)(s + 1u) * exchanges) / n_slices), q0 = (uint32_t)(((uint64_t)s * exchanges) / n_slices);
+        if (q != q0 && q < exchanges) { ce_comm_exchange(o); o->comm_bytes += o->dev.n * o->dev.dim * sizeof(float); }
+    };
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
@@ -702,24 +793,24 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             }
             if (classes) o->sl_class_pos.upload(class_pos.data(), class_pos.size());
         }
-        hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(nnz, 256)), dim3(256), 0, stream(), o->dev, gen_erec, (float)(seg_samples / (double)n), key, o->sl_cnt.p);
+        hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, (float)(seg_samples / (double)n), key, o->sl_cnt.p);
         {
             size_t tmp_bytes = 0;
-            if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, nnz, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+            if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
                 fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan (size query) failed");
             DevBuf<char> tmp;
             tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-            if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, nnz, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+            if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
                 fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan failed");
         }
         uint32_t last[2];
-        AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
-        AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (nnz - 1), 4, hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
         sync();
         const double t_cnt = wall();
         const uint32_t total = last[0] + last[1];
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
-        hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(nnz, 256)), dim3(256), 0, stream(), o->dev, key, (const uint32_t*)o->sl_cnt.p,
+        hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
                            (const uint8_t*)o->sl_class_pos.p, classes, spread, o->sl_keys0.p, ev0);
         if (prof) sync();
@@ -757,7 +848,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 da.step_seq = step_seq++;
                 AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
             }
-            if (!has_overflow) continue;
+            if (!has_overflow) { exchange_after(s); continue; }
             a.f0 = sp[classes];
             a.f1 = sp[classes + 1u];
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
@@ -817,6 +908,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             }
             // the next slice's mark kernel marks in owner[0]; the last pass above marked in owner[(passes + extra) & 1]: the mark
             // kernel re-marks everything that is pending anyway
+            exchange_after(s);
         }
         const double t_enq = wall();
         t_enqueue += t_enq - t_ev;
@@ -867,6 +959,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 cur = (cur + 1) % 3;
             }
         }
+        if (exchanges) { ce_comm_exchange(o); o->comm_bytes += o->dev.n * o->dev.dim * sizeof(float); }   // (after the drain: the segment's last exchange)
         t_drain += wall() - t_enq;
     }
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,

@@ -21,15 +21,22 @@ constexpr uint8_t kNoColor = 0xFFu, kOverflowColor = 0xFEu;
 struct EdgeRec {       // per edge, 16 bytes (colouring, event generation)
     uint32_t j;        // target
     float w;           // probability
-    uint32_t pad;
+    uint32_t flags;    // kHalfEvent: the source belongs to another shard (multi-GPU)
     uint32_t im;       // source << 5 | slot of the edge in the source's row
 };
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;                // (<= 2^27 nodes: ce_slice_unsupported)
+constexpr uint32_t kNodeMask = 0x07FFFFFFu;
+// Multi-GPU (a sharded node range): an edge whose SOURCE belongs to another shard fires here as a HALF event -- the owner of its
+// target applies the attraction to the target's row against its replica of the source's row (which it neither stores nor repulses:
+// the owner of the source runs the other half, with the negatives, against ITS replica of the target).  Bit 31 of Event::j.
+constexpr uint32_t kHalfEvent = 0x80000000u;
+__host__ __device__ __forceinline__ uint32_t ev_node(uint32_t j) { return j & kNodeMask; }
+__host__ __device__ __forceinline__ bool ev_half(uint32_t j) { return (j & kHalfEvent) != 0u; }
 // An event in the sorted arrays: 8 bytes {source << 5 | slot of the edge in the source's row, target} -- the rows of both end
 // points and the source's static record are requested in ONE hop after the (coalesced) event load.  The events of a step are sorted
 // by target: those that share one are adjacent and run as a chain through the target's row (sl_step_body).
 struct Event {
-    uint32_t im, j;
+    uint32_t im, j;   // j: target, kHalfEvent in bit 31
 };
 struct Pending {       // a pending event of the overflow class: 16 bytes, read and written coalesced
     uint32_t idx, im, j, pad;
@@ -519,14 +526,15 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         }
         TileFetch<DIM> ft;
         if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
-        const uint32_t i = e.im >> 5, j = act0 ? e.j : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
+        const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
+        const bool half = act0 && ev_half(e.j);   // (multi-GPU) the source is another shard's: attraction on the target's row only
         // chains: this event has the previous one's target / the next one has this one's
-        const bool inrun = act0 && pv.j == j;
-        const bool next_inrun = act0 && nx.j == j;
+        const bool inrun = act0 && p > a.begin && ev_node(pv.j) == j;
+        const bool next_inrun = act0 && p + 1u < a.end && ev_node(nx.j) == j;
         const bool absorbed = inrun && pv.im == e.im;   // a repeat of the previous event's edge: its first lane runs the repeats
         const bool cmp = act0 && !absorbed;
         uint32_t rep = 1;
-        if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < a.end && a.ev[p + rep].im == e.im && a.ev[p + rep].j == j) rep++; }
+        if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < a.end && a.ev[p + rep].im == e.im && ev_node(a.ev[p + rep].j) == j) rep++; }
         const unsigned long long run_mask = __ballot(inrun);
         const bool cont = (run_mask & 1ull) != 0ull;          // lane 0 continues a chain of the previous chunk (uniform over the wave)
         const unsigned long long heads = ~run_mask | 1ull;   // first lanes of the chunk's chain segments (a lone event is its own)
@@ -554,7 +562,7 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         // now; its attraction runs in the lane's turn, its repulsions -- they move y_i only -- after the turns, all lanes side by side
         SplitSample<DIM, F64, TILE> sm;
         uint32_t neg[5], got = 0;
-        if (cmp) {
+        if (cmp && !half) {
             got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
             if (a.dbg & 4) { got = 0; for (int g = 0; g < 5; g++) neg[g] = TILE ? 0u : i; }
             sm.fetch(c, sh.tile, neg);
@@ -581,27 +589,27 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
             }
             if (cmp && runpos == t && !(a.dbg & 1)) {
                 for (uint32_t q = 0; q + 1u < rep; q++) {   // earlier repetitions of the edge: whole samples, one after the other
-                    uint32_t ng[5];
-                    const uint32_t gt = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng);
+                    uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
+                    const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng);
                     run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
                 }
                 sm.attract(c, yi, yj, w, scale_f, a.step);
             }
             if (!__ballot(act0 && runpos > t)) break;
         }
-        if (cmp) {
+        if (cmp && !half) {
             if (!(a.dbg & 1)) sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
             else if (got == 77u) yi[0] += (float)neg[0];
-            done += rep;
+            done += rep;   // (a half event is counted by the shard that owns its source)
         }
         // stores: the source's row by every lane that computed, the target's row by the last lane of its chain segment -- written through
         // and announced where the chain goes on in the next chunk
         const bool store_j = act0 && last_in_seg && !hand_over;
         if (!(a.dbg & 2)) {
             row_store<DIM>(c.y, j, store_j, stage, yj);  // :1239
-            row_store<DIM>(c.y, i, cmp, stage, yi);      // :1301
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi);      // :1301
         } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
-            row_store<DIM>(c.y, i, cmp, stage, yi);
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi);
         }
         if (hand_over) {
             store_row_agent<DIM>(c.y, j, yj);
@@ -653,7 +661,9 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         const bool have = t < total;
         Pending p = a.lists[so + (have ? t : 0)];
         if (!have) p = Pending{0, 0, 0, 0};
-        const uint32_t o1 = own_chk[p.im >> 5], o2 = own_chk[p.j];
+        const uint32_t pj = ev_node(p.j);
+        const bool half = ev_half(p.j);
+        const uint32_t o1 = own_chk[p.im >> 5], o2 = own_chk[pj];
         TileFetch<DIM> ft;
         if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
         const bool win = have && o1 == p.idx && o2 == p.idx;
@@ -667,19 +677,19 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         RowFetch<DIM> fi, fj;
         fr.issue(a.srec, i, p.im & 31u, win, scale_f, w, nbr_reg);
         fi.issue(c.y, i, win, yi);
-        fj.issue(c.y, p.j, win, yj);
+        fj.issue(c.y, pj, win, yj);
         if constexpr (TILE && FIRST) ft.land(s_tile, s_tnode);
         fr.land(stage, p.im & 31u, win, scale_f, w, nbr_reg);
         fi.land(stage, yi);
         fj.land(stage, yj);
         if (win) {
-            uint32_t neg[5];
-            const uint32_t got = draw_negatives<DIM, KREG, TILE>(c, hub, s_tnode, pcg_hash(nkey + idx), i, nbr_reg, neg);
+            uint32_t neg[5] = {0u, 0u, 0u, 0u, 0u};
+            const uint32_t got = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, s_tnode, pcg_hash(nkey + idx), i, nbr_reg, neg);
             run_sample<DIM, F64, TILE>(c, s_tile, yi, yj, w, scale_f, a.step, neg, got);
-            done++;
+            done += half ? 0u : 1u;
         }
-        row_store<DIM>(c.y, p.j, win, stage, yj);  // :1239
-        row_store<DIM>(c.y, i, win, stage, yi);    // :1301
+        row_store<DIM>(c.y, pj, win, stage, yj);           // :1239
+        row_store<DIM>(c.y, i, win && !half, stage, yi);   // :1301
         // deferred: append to the next list (one atomic per workgroup, on one of kSub counters), mark for the next pass
         const bool defer = have && !win;
         const unsigned long long m = __ballot(defer);
@@ -700,7 +710,7 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
                 const bool mark = !a.backoff || (pcg_hash(idx ^ pcg_hash(a.pass_seq ^ kTagSlCoin)) & 1u);
                 if (mark) {
                     own_mark[i] = idx;
-                    own_mark[p.j] = idx;
+                    own_mark[pj] = idx;
                 }
             } else {
                 atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 1u);
@@ -733,9 +743,10 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
     for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256ull) {
         const Pending p0 = a.lists[so + t];
         const uint32_t pos = (uint32_t)((uint64_t)sub * a.cap + t);
-        if (head[p0.j] != pos) continue;  // the head of its target's list walks it
+        const uint32_t tj = ev_node(p0.j);
+        if (head[tj] != pos) continue;  // the head of its target's list walks it
         float yj[DIM];
-        load_row<DIM>(c.y, p0.j, yj);
+        load_row<DIM>(c.y, tj, yj);
         uint32_t cur = pos, nxt = next[pos];
         Pending e = p0;
         for (;;) {
@@ -751,11 +762,11 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
                 uint32_t nbr_reg[KREG];
 #pragma unroll
                 for (int q = 0; q < KREG; q++) nbr_reg[q] = __float_as_uint(r[1 + q]);
-                uint32_t neg[5];
-                const uint32_t got = draw_negatives<DIM, KREG, false>(c, hub, nullptr, pcg_hash(nkey + e.idx), i, nbr_reg, neg);
+                uint32_t neg[5] = {0u, 0u, 0u, 0u, 0u};
+                const bool half = ev_half(e.j);
+                const uint32_t got = half ? 0u : draw_negatives<DIM, KREG, false>(c, hub, nullptr, pcg_hash(nkey + e.idx), i, nbr_reg, neg);
                 run_sample<DIM, F64, false>(c, nullptr, yi, yj, w, scale_f, a.step, neg, got);
-                store_row<DIM>(c.y, i, yi);  // :1301
-                done++;
+                if (!half) { store_row<DIM>(c.y, i, yi); done++; }  // :1301
             } else {  // the source is claimed by another event or is a target of this round: next round
                 const uint32_t dsub = (cur + blockIdx.x) % (uint32_t)kSub;
                 const uint32_t at = atomicAdd(&a.counts[a.dst_list * kSub + dsub], 1u);
@@ -765,7 +776,7 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
             if (nxt == kNil) break;
             cur = nxt; e = en; nxt = nn;
         }
-        store_row<DIM>(c.y, p0.j, yj);  // :1239
+        store_row<DIM>(c.y, tj, yj);  // :1239
     }
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);

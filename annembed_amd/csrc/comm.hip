@@ -210,8 +210,9 @@ void ce_comm_exchange(ae_entropy_optim* o) {
 // attaches the communicator to a shard handle: the ranks' node ranges must tile [0, n) in rank order
 void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchanges_per_batch) {
     if (!c) { o->comm = nullptr; return; }
-    if (o->params.ce_mode != AE_CE_HOGWILD)
-        fail(AE_ERR_INVALID_ARG, "only the rounds mode (AE_CE_HOGWILD) shards over devices; this handle runs mode %u", o->params.ce_mode);
+    if (o->params.ce_mode != AE_CE_HOGWILD && o->params.ce_mode != AE_CE_SLICED)
+        fail(AE_ERR_INVALID_ARG, "the time-sliced mode (AE_CE_SLICED: faithful, for node orders with few cross-shard edges) and the rounds mode (AE_CE_HOGWILD: approximate) "
+                                 "shard over devices; this handle runs mode %u", o->params.ce_mode);
     const uint64_t h[2] = {o->dev.node_lo, o->dev.node_hi};
     o->comm_ranges = comm_all_gather_u64x2(c, h);  // every rank learns every rank's node range
     uint64_t expect = 0;
@@ -345,6 +346,13 @@ int32_t ae_comm_all_reduce_sum(ae_comm* c, double* value) {
         require_device();
         if (!c || !value) fail(AE_ERR_INVALID_ARG, "null argument");
         *value = comm_all_reduce_sum(c, *value);
+    });
+}
+
+int32_t ae_entropy_optim_comm_bytes(const ae_entropy_optim* o, uint64_t* bytes) {
+    return guard([&] {
+        if (!o || !bytes) fail(AE_ERR_INVALID_ARG, "null argument");
+        *bytes = o->comm_bytes;
     });
 }
 

@@ -111,9 +111,9 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
     }
     uint64_t lo = 0, hi = g->n;
     if (dist.active()) {
-        if (params.ce_mode != AE_CE_HOGWILD)
-            fail(AE_ERR_INVALID_ARG, "a multi-GPU embedding runs the rounds mode, whose output is not the reference's (DESIGN 5): ask for it by name "
-                                     "(ce_mode = AE_CE_HOGWILD); every faithful mode needs the whole graph on one device");
+        if (params.ce_mode != AE_CE_HOGWILD && params.ce_mode != AE_CE_AUTO && params.ce_mode != AE_CE_SLICED)
+            fail(AE_ERR_INVALID_ARG, "a multi-GPU embedding runs the time-sliced mode (ce_mode = AE_CE_AUTO / AE_CE_SLICED: faithful, for node orders with few cross-shard "
+                                     "edges) or the approximate rounds mode (AE_CE_HOGWILD, by name); the other modes need the whole graph on one device");
         const uint64_t world = (uint64_t)comm_world(dist.comm), rank = (uint64_t)comm_rank(dist.comm);
         if (g->n < world * ((uint64_t)g->max_nbng + 8)) fail(AE_ERR_INVALID_ARG, "graph too small for %llu ranks", (unsigned long long)world);
         const uint64_t base = g->n / world, rem = g->n % world;  // contiguous ranges, the remainder spread over the first ranks

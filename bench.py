@@ -497,24 +497,31 @@ def main():
     nb_batch = max(25, args.warmup + args.steps + 1)
     del head_eo
 
-    # secondary figures on the same graph and start
-    rounds_mode = exact_mode = event_mode = fidelity = None
+    # the same graph and start in the other modes.  parity_mode: AE_CE_SEQUENTIAL, the mode that meets the north star's tolerance (the
+    # reference's sequential loop bit for bit: 1e-4 relative on the coordinates holds trivially) -- first class beside `value`
+    def mode_entry(r, name, faithful):
+        return {"ce_mode": name, "faithful": faithful, "dtype": r["dtype"], "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
+                "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
+    rounds_mode = parity_mode = event_mode = fidelity = None
     if head["mode"] != A.AE_CE_EVENT and not args.lattice_graph:
         r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_EVENT, max(3, args.steps // 2), 1)
         r.pop("eo")
-        event_mode = {"ce_mode": MODE_NAMES[3], "faithful": "statistically (see fidelity)", "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
-                      "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
+        event_mode = mode_entry(r, MODE_NAMES[3], "statistically (see fidelity)")
     if head["mode"] != A.AE_CE_HOGWILD:
         r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_HOGWILD, args.steps, args.warmup)
         r.pop("eo")
-        rounds_mode = {"ce_mode": MODE_NAMES[0], "faithful": False, "ms_per_step": r["ms_per_step"], "points_per_s": n / (r["ms_per_step"] * 1e-3),
-                       "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3), "roofline": roofline_of(r, k, d)}
-    if not args.no_exact_mode and head["mode"] != A.AE_CE_SEQUENTIAL:  # (only when the headline was asked in another mode)
-        r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, 3, 1)
-        r.pop("eo")
-        exact_mode = {"ce_mode": "sequential (device-scheduled dataflow, bit-exact vs the oracle)", "faithful": True, "ms_per_step": r["ms_per_step"],
-                      "points_per_s": n / (r["ms_per_step"] * 1e-3), "samples_per_s": r["nb_sample"] / (r["ms_per_step"] * 1e-3),
-                      "roofline": roofline_of(r, k, d)}
+        rounds_mode = mode_entry(r, MODE_NAMES[0], False)
+    if not args.no_exact_mode:
+        if head["mode"] == A.AE_CE_SEQUENTIAL:
+            r = head
+        else:
+            r = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL, max(5, args.steps // 2), 2)
+            r.pop("eo")
+        parity_mode = mode_entry(r, MODE_NAMES[1], True)
+        parity_mode["tolerance"] = ("bit-identical to the CPU oracle's sequential loop (tests/test_gpu_parity.py: every row stride, both samplers, the whole "
+                                    "25-batch schedule at this size): the north star's 1e-4 relative on the coordinates at fixed seed is met by this mode")
+        parity_mode["roofline"]["latency_bound_note"] = "4305 dependency levels deep on this graph (tools/dependency_depth.py): %.2f us per level" % (
+            parity_mode["roofline"]["launch_avg_ms"] * 1e3 / 4305.0)
     if not args.no_fidelity:
         # the full 25-batch schedule from the dmap initialisation in the three modes: what each mode converges to
         ys, ces = full_schedule(A, kg, node_params, y0, d, A.AE_CE_SEQUENTIAL)
@@ -571,7 +578,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",  # the --gpus N series is strong scaling of the configs[3] shape; its one-GPU point is scale_shapes.c4_shape (this line's value is configs[1])
         "vs_baseline": None,
-        "dtype": "f32 coordinates, f64 scalars" if head["mode"] in (1, 3, 6) else "f32",
+        "dtype": head["dtype"],
         "cpu_baseline": cpu,
         "data": "synthetic",
         "config": {
@@ -580,12 +587,13 @@ def main():
                         ("MNIST-fashion-shaped %dx%d -> %dD, k=%d, dmap init + CE loop (configs[1])" % (n, args.dim, d, k)),
             "nb_sampling_by_edge": 10, "samples_per_step": int(head["nb_sample"]), "ce_mode": MODE_NAMES.get(head["mode"]),
             "ce_mode_requested": args.ce_mode,
+            "value_is": "the default mode (AE_CE_AUTO); the figure at the north star's coordinate tolerance is parity_mode, beside it",
         },
         "roofline": roof,
+        "parity_mode": parity_mode,
         "fidelity": fidelity,
         "event_mode": event_mode,
         "rounds_mode": rounds_mode,
-        "exact_mode": exact_mode,
         "scale_shapes": scale_shapes,
         "multi_gpu_note": ("--gpus N shards the APPROXIMATE rounds mode only (by name; AE_CE_AUTO refuses a sharded node range, DESIGN 5): output that is the "
                            "reference's comes from one GPU -- scale_shapes.c4_shape.sliced_mode is configs[3]'s shape, c5_shard_shape one eighth of configs[4]'s"),

@@ -365,8 +365,12 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * host channel; every rank calls ae_comm_init on its own device (ae_set_device first).  A communicator attached to an
  * EntropyOptim created on this rank's node range [node_lo, node_hi) -- the ranges of the ranks must tile [0, n) in rank
  * order -- makes ae_entropy_optim_gradient_iteration exchange the owned coordinate rows itself: in place, on the library's
- * stream, `exchanges_per_batch` times per batch at equal runs of rounds (1 = once per batch, at its end).  Only the rounds
- * mode (AE_CE_HOGWILD, asked for by name: AE_CE_AUTO refuses a sharded range) shards.  The final cross entropy is the sum of the
+ * stream, `exchanges_per_batch` times per batch at equal runs of rounds / time slices (1 = once per batch, at its end).  Two modes
+ * shard: the time-sliced mode (AE_CE_SLICED; what AE_CE_AUTO resolves to on a sharded range) runs a shard's own events on current rows
+ * and reads the other shards' rows -- negatives, the far ends of cross-shard edges, which fire as two half events -- as of the last
+ * exchange: faithful for node orders with few cross-shard edges (connected components / locality; more than 10 % of a shard's edge mass
+ * on cross-shard edges is refused with AE_ERR_INVALID_ARG) and with enough exchanges per batch (measured: DESIGN 5); the rounds mode
+ * (AE_CE_HOGWILD, by name) is approximate whatever the partition.  The final cross entropy is the sum of the
  * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
 typedef struct ae_comm ae_comm;
 int32_t ae_comm_unique_id(uint8_t *id128);
@@ -379,6 +383,9 @@ int32_t ae_comm_init_hostmem(int32_t rank, int32_t world, const char *name, uint
 int32_t ae_comm_destroy(ae_comm *c);
 int32_t ae_comm_all_reduce_sum(ae_comm *c, double *value);
 int32_t ae_entropy_optim_set_comm(ae_entropy_optim *o, ae_comm *c, uint32_t exchanges_per_batch);
+/* bytes of coordinate rows this rank has RECEIVED through the exchanges of its batches since the handle was created (n x row stride x 4
+   per exchange) -- the volume a scaling estimate needs */
+int32_t ae_entropy_optim_comm_bytes(const ae_entropy_optim *o, uint64_t *bytes);
 /* The sharded protocol on ONE device (validation; no reference counterpart): one batch of `world` rounds-mode handles of
  * the same graph whose node ranges tile [0, n) in order, run in lockstep -- round r of every shard, then, at the exchange
  * points, every shard's owned rows copied into the other shards' coordinate arrays.  Kernel for kernel and exchange for

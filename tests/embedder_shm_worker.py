@@ -25,7 +25,7 @@ def main():
     else:
         e = A.Embedder(g, par)
     e.set_comm(comm, 2)
-    bad = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2))  # AE_CE_AUTO: a multi-GPU embedding must ask for the rounds mode by name
+    bad = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2))  # AE_CE_AUTO shards through the time-sliced mode, which refuses this node order (random: half of the edge mass crosses the two shards)
     bad.set_comm(comm, 1)
     try:
         bad.embed()

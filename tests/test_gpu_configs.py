@@ -383,3 +383,120 @@ def test_fashion_mnist_published_quality_if_data_present(A):
         assert abs(r["nb_without_match"] - pub["nb_without_match"]) < 0.35 * pub["nb_without_match"]
         assert abs(r["mean_nbmatch"] - pub["mean_nbmatch"]) < 0.10 * pub["mean_nbmatch"]
         assert abs(r["ratio_quantiles"][2] - pub["ratio_quantiles"][2]) < 0.35 * pub["ratio_quantiles"][2]
+
+
+def test_high_dimensional_hubs_1m_nodes(A):
+    """configs[4]'s kind of graph at a size the sequential mode still runs: 1 M points of the 128-D Gaussian mixture (20 components of
+    50 000 points, SURVEY 8d's generator), exact kNN inside every component, k = 10, asked_dim 16.  Hubness is of another order in 128-D:
+    in-degrees in the thousands (round 3: every faithful mode serialised a hub's events at one launch or ~3 us each -- 6x the lattice's
+    time at the shard size).  The time-sliced mode runs them as chains through the hub's row: CE within 5 % of the sequential mode's
+    after the same batches, every sample executed, bounded time."""
+    import time
+    sys_argv = sys.argv
+    sys.argv = ["bench.py"]
+    import bench
+    sys.argv = sys_argv
+    n, k, d = 1_000_000, 10, 16
+    x, bounds = bench.mixture_points_gpu(n, 128, 20, seed=4, mean_sigma=10.0)
+    indptr, nbr, dist = bench.component_knn_graph(A, x, bounds, k, permute_seed=9)
+    del x
+    g = A.KGraph(indptr, nbr, dist, k)
+    hub = g.hubness()
+    print("128-D mixture, 1 M nodes: max in-degree %d, 99.9 %% quantile %d, nodes nobody points at %d" % (hub.max(), np.quantile(hub, 0.999), (hub == 0).sum()))
+    assert hub.max() >= 2000
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
+    S = 10 * n * k
+    out = {}
+    for name, mode in (("sliced", A.AE_CE_SLICED), ("sequential", A.AE_CE_SEQUENTIAL)):
+        eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=mode, nb_grad_batch=10), y0)
+        eo.gradient_iteration_threaded(S, 0.9, 1)
+        eo.get_embedded()
+        t0 = time.perf_counter()
+        for it in (2, 3):
+            eo.gradient_iteration_threaded(S, 1.0 - it / 10, it)
+        y = eo.get_embedded()
+        out[name] = (eo.ce_compute_threaded(), y, (time.perf_counter() - t0) / 2)
+        if name == "sliced":
+            cl, ovf, _, _ = eo.slice_info()
+            drawn, _ = eo.samples_drawn()
+            print("128-D mixture: classes %d overflow %.4f, hub info %s" % (cl, ovf, eo.slice_hub_info()))
+            assert cl >= 14 and ovf < 0.05     # the class path (k + 8 classes), not the optimistic one
+            assert abs(drawn - 3 * S) < 6 * np.sqrt(3 * S), (drawn, 3 * S)
+    (ce_s, y_s, t_s), (ce_q, y_q, t_q) = out["sliced"], out["sequential"]
+    print("128-D mixture: sliced %.3f s/batch (CE %.5g), sequential %.3f s/batch (CE %.5g), ratio %.4f" % (t_s, ce_s, t_q, ce_q, ce_s / ce_q))
+    assert np.isfinite(y_s).all()
+    assert abs(ce_s - ce_q) < 0.05 * ce_q, (ce_s, ce_q)
+    assert t_s < 0.25, "time-sliced batch on the 128-D kNN graph took %.2f s (sequential %.2f s)" % (t_s, t_q)
+
+
+def _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, scale_rho, world, exchanges, nb_batch, tag):
+    """`world` processes on this box's one GPU, the library's communicator over shared memory: the faithful sharded schedule"""
+    import subprocess
+    np.savez(tmp_path / "graph.npz", indptr=indptr, nbr=nbr, dist=dist, k=k, y0=y0, scale_rho=scale_rho)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "annembed_sl_%d_%s" % (os.getpid(), tag)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "sliced_shm_worker.py"), str(tmp_path), str(r), str(world), name,
+                               str(exchanges), str(nb_batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for r in range(world)]
+    outs = [p.communicate(timeout=1200) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1500:], se[-3000:])
+    ys = [np.load(tmp_path / ("y_rank%d.npy" % r)) for r in range(world)]
+    infos = [np.load(tmp_path / ("info_rank%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(ys[0], ys[r])          # every batch ends with an exchange: the replicas agree
+        assert infos[r][0] == infos[0][0]            # the cross-entropy sums run in rank order on every rank
+    for inf in infos:                                 # every shard executed its own samples (half events are the other shard's)
+        assert abs(inf[1] - inf[2]) < 6 * np.sqrt(inf[2]), inf
+    return ys[0], float(infos[0][0]), float(infos[0][3])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_sliced_component_partition(A, tmp_path, world):
+    """The faithful sharded CE loop (verdict r3, item 3) on a graph that partitions: 16 well separated components, node ids in component
+    order, `world` shards whose boundaries are component boundaries -- no cross-shard edge; every rank runs AE_CE_AUTO (-> the time-sliced
+    mode) on its own rows, negatives of other shards' nodes are read from the replica, refreshed 8 times per batch by the in-place
+    all-gather.  Held against the un-sharded SEQUENTIAL mode (the reference's loop) on the full 20-batch schedule: final CE within 3 %,
+    edge-length quartiles within 5 %.  The reference: one gradient on the current rows of both end points (embedder.rs:1228-1239),
+    negatives through try_read (:1257-1265)."""
+    sys_argv = sys.argv
+    sys.argv = ["bench.py"]
+    import bench
+    sys.argv = sys_argv
+    n, k, d, nb_batch = 64000, 6, 2, 20
+    x, bounds = bench.mixture_points_gpu(n, 28, 16, seed=5, mean_sigma=10.0)
+    indptr, nbr, dist = bench.component_knn_graph(A, x, bounds, k, permute_seed=None)
+    y0 = A.set_data_box(np.random.default_rng(2).normal(size=(n, d)).astype(np.float32), 10.0)
+    y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 8, nb_batch, "comp%d" % world)
+    g = A.KGraph(indptr, nbr, dist, k)
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    ref = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL)
+    print("sharded sliced, %d shards, component partition: %d bytes received per rank and batch" % (world, nbytes / nb_batch))
+    assert nbytes == nb_batch * 8 * n * d * 4
+    _assert_close(A, indptr, nbr, (y, ce, None), ref, tol_ce=0.03, tol_q=0.05)
+
+
+def test_sharded_sliced_locality_partition_with_cross_edges(A, tmp_path):
+    """The same with edges that DO cross shards: Higgs-shaped blobs (64 overlapping components, exact GLOBAL kNN graph, k = 6,
+    scale_rho 0.75 -- the stiff graph on which the sharded rounds mode ends at 1.3-1.7x the reference's CE), node ids in
+    component order, 8 shards: a few per cent of the edge mass crosses; such an edge fires as two half events, each shard moving its own
+    end against its replica of the other.  16 exchanges per batch, 40 batches: CE within 4 %, quartiles within 8 % of the un-sharded
+    sequential mode (the un-sharded time-sliced mode's own bars on this graph)."""
+    n, k, d, nb_batch, world = 60000, 6, 2, 40, 8
+    sys_argv = sys.argv
+    sys.argv = ["bench.py"]
+    import bench
+    sys.argv = sys_argv
+    x, lab = bench.higgs_shaped_points(n, with_labels=True)
+    order = np.argsort(lab, kind="stable")
+    g = A.KGraph.bruteforce_l2(np.ascontiguousarray(x[order]), k)
+    indptr, nbr, dist = g.get_neighbours()
+    src = np.repeat(np.arange(n), k)
+    cross = (src * world // n) != (nbr.astype(np.int64) * world // n)
+    print("locality partition: %.2f %% of the edges cross shards" % (100 * cross.mean()))
+    assert 0.001 < cross.mean() < 0.10
+    y0 = (np.random.default_rng(5).random(size=(n, d)).astype(np.float32) - 0.5)
+    y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 0.75, world, 16, nb_batch, "loc")
+    npar = A.to_proba_edges(g, 0.75, 1.0)
+    ref = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL)
+    _assert_close(A, indptr, nbr, (y, ce, None), ref, tol_ce=0.04, tol_q=0.08)

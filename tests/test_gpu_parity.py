@@ -541,7 +541,7 @@ def test_unsupported_shape_fails_loudly(A, oracle):
     with pytest.raises(A.AnnembedError) as e:  # the rounds mode has no kernel for 64 columns: no silent fall-back to the racy per-sample kernel
         eo.gradient_iteration_threaded(1000, 1.0, 1)
     assert e.value.code == 1
-    with pytest.raises(A.AnnembedError) as e:  # AE_CE_AUTO never shards (no faithful schedule does): refused at create
+    with pytest.raises(A.AnnembedError) as e:  # AE_CE_AUTO shards through the time-sliced mode -- which refuses a partition with most of its edge mass across shards (random order)
         A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=40), y0, node_lo=0, node_hi=300)
     assert e.value.code == 1
     y0 = y0[:, :2].copy()
@@ -909,7 +909,7 @@ def test_device_coords_alias_and_sharded_hogwild(A, oracle, graph):
     shards = []
     for r in range(2):
         lo, hi = shard_range(2500, 2, r)
-        with pytest.raises(A.AnnembedError):  # AE_CE_AUTO refuses a sharded range: no faithful schedule shards
+        with pytest.raises(A.AnnembedError):  # AE_CE_AUTO on a shard = the time-sliced mode, which refuses a node order with > 10 % of the edge mass across shards
             A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0, node_lo=lo, node_hi=hi)
         shards.append((lo, hi, A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=lo, node_hi=hi)))
     views = [device_tensor(eo) for _, _, eo in shards]
@@ -1124,7 +1124,7 @@ def test_library_communicator_world_one(A, oracle, graph):
     assert abs(a.ce_compute_threaded() - b.ce_compute_threaded()) < 0.05 * b.ce_compute_threaded()  # same mode, same draws; float order of the rounds differs
     assert comm.all_reduce_sum(1.25) == 1.25
     with pytest.raises(A.AnnembedError):
-        comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # the default (sequential) mode does not shard
+        comm.attach(A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0), 1)  # on the whole graph AE_CE_AUTO is the ordered dataflow, which does not shard
     with pytest.raises(A.AnnembedError):
         comm.attach(A.EntropyOptim(g, npar, par, y0, node_lo=0, node_hi=1000), 1)  # one rank must own [0, n)
     comm.close()
