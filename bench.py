@@ -338,13 +338,13 @@ def exact_knn_graph(A, x, k, what):
     return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": dt, "desc": "exact kNN graph (k = %d) of %d %s; built in %.1f s" % (k, len(x), what, dt)}
 
 
-def config_graphs(A, which):
+def config_graphs(A, which, permute_seed=9, n_override=None):
     """the configs' own kind of graph for the scale shapes (SURVEY 8d generators; exact kNN inside every mixture component, node ids
     randomly permuted): 'c4' = configs[3] (11 M Higgs-shaped points, k 6), 'c5' = one GPU's eighth of configs[4] (6.25 M points of the
     128-D mixture: 125 of its 1 000 components of 50 000 points, k 10)."""
     t0 = time.perf_counter()
     if which == "c4":
-        n, dim, ncomp, k = 11_000_000, 28, 64, 6
+        n, dim, ncomp, k = n_override or 11_000_000, 28, 64, 6
         x, bounds = mixture_points_gpu(n, dim, ncomp, seed=3, mean_sigma=2.0, higgs_like=True)
         what = "Higgs-shaped points (28-D, 64 overlapping Gaussian components, columns standardised; SURVEY 8d, seed 3)"
     else:
@@ -352,12 +352,12 @@ def config_graphs(A, which):
         x, bounds = mixture_points_gpu(n, dim, ncomp, seed=4, mean_sigma=10.0)
         what = "points of the 128-D mixture (125 of configs[4]'s 1 000 components of 50 000 points: means N(0, 10^2), sigma 1; SURVEY 8d, seed 4)"
     t1 = time.perf_counter()
-    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=9)
+    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed)
     del x
     t2 = time.perf_counter()
-    return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0,
-            "desc": "kNN graph (k = %d) of %d %s, exact inside every component, node ids randomly permuted; points %.1f s, graph %.1f s" % (
-                k, n, what, t1 - t0, t2 - t1)}
+    return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0, "k": k, "n": n,
+            "desc": "kNN graph (k = %d) of %d %s, exact inside every component, node ids %s; points %.1f s, graph %.1f s" % (
+                k, n, what, "randomly permuted" if permute_seed is not None else "in component order", t1 - t0, t2 - t1)}
 
 
 def main():
@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--ce-mode", default="auto", choices=["auto", "event", "rounds", "sequential", "ordered"], help="mode of the headline figure at N = 1")
     ap.add_argument("--lattice-graph", action="store_true",
                     help="N = 1 scale runs: ring-lattice kNN graph (node ids permuted) with --points-per-gpu nodes instead of the MNIST-shaped points")
+    ap.add_argument("--rounds", action="store_true", help="N > 1: the approximate rounds mode on the node-permuted lattice (rounds 1-3's strong-scaling series) instead of the "
+                    "faithful time-sliced mode on the component-ordered kNN graph of the Higgs-shaped points")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling on 60 k MNIST-shaped points per GPU (round-1 arrangement) instead of the strong-scaling configs[3] shape")
     ap.add_argument("--scale-nodes", type=int, default=11_000_000, help="N > 1 strong scaling: nodes of the fixed graph (k = 6, asked_dim 8)")
     ap.add_argument("--exchanges", type=int, default=1, help="N > 1: all-gathers of the owned rows per CE batch (1 = the north star's once per batch; more often "
@@ -595,8 +597,9 @@ def main():
         "event_mode": event_mode,
         "rounds_mode": rounds_mode,
         "scale_shapes": scale_shapes,
-        "multi_gpu_note": ("--gpus N shards the APPROXIMATE rounds mode only (by name; AE_CE_AUTO refuses a sharded node range, DESIGN 5): output that is the "
-                           "reference's comes from one GPU -- scale_shapes.c4_shape.sliced_mode is configs[3]'s shape, c5_shard_shape one eighth of configs[4]'s"),
+        "multi_gpu_note": ("--gpus N shards the source nodes of configs[3]'s kNN graph (component order) over the ranks in the default mode: AE_CE_AUTO on a node range is "
+                           "the time-sliced mode, faithful where few edges cross shards (DESIGN 5); scale_shapes.c4_knn_shape is the same graph (node ids permuted) on one "
+                           "GPU, c5_shard_knn_shape one eighth of configs[4]'s"),
         "svd_init": {"gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5},
         "svd_dense": svd_dense,
         "knn_producer": knn_producer,
@@ -631,19 +634,40 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
         del nbr_all, dist_all, nbr_l, dist_l
         workload = "MNIST-fashion-shaped %dx%d -> %dD, k=%d, %d points per GPU (weak scaling)" % (n, args.dim, d, k, ppg)
         scaling = "weak"
-    else:
+    elif args.rounds:
         n, k, d = args.scale_nodes, 6, 8
         lo, hi = shard_range(n, world, rank)
         indptr, nbr, dst = lattice_graph(n, k, seed=7, permute=True)  # the same graph on every rank
-        workload = "Higgs-11M-shaped ring lattice (node ids permuted) %d nodes -> %dD, k=%d, source nodes sharded over %d GPUs (configs[3], strong scaling)" % (n, d, k, world)
+        workload = "Higgs-11M-shaped ring lattice (node ids permuted) %d nodes -> %dD, k=%d, source nodes sharded over %d GPUs (configs[3], strong scaling, rounds mode)" % (n, d, k, world)
         scaling = "strong"
+    else:
+        # configs[3] on its own kind of graph, FAITHFUL: the kNN graph of the Higgs-shaped points in COMPONENT order (a locality order: the
+        # contiguous node ranges of the ranks cut a few of the 64 components, nothing else crosses shards), hubness-weighted negatives
+        d = 8
+        gr = config_graphs(A, "c4", permute_seed=None, n_override=args.scale_nodes)
+        n, k, indptr, nbr, dst = gr["n"], gr["k"], gr["indptr"], gr["nbr"], gr["dist"]
+        lo, hi = shard_range(n, world, rank)
+        chk = torch.tensor([float(nbr[::1009].astype(np.float64).sum())], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if world > 1:  # every rank built the graph itself: it must be the same graph
+            lo_hi = [chk.clone() for _ in range(world)]
+            dist.all_gather(lo_hi, chk)
+            if any(float(v) != float(chk) for v in lo_hi):
+                raise SystemExit("the ranks built different graphs")
+        workload = "%s -> %dD, source nodes sharded over %d GPUs in contiguous ranges (configs[3], strong scaling, faithful time-sliced mode)" % (gr["desc"], d, world)
+        scaling = "strong"
+    faithful = not args.weak and not args.rounds
     torch.cuda.empty_cache()
     kg = A.KGraph(indptr, nbr, dst, k)
-    y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)  # replicated
+    hub = kg.hubness() if faithful else None
+    if faithful:
+        y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)   # (a component-wise kNN graph is disconnected: no diffusion-map start)
+    else:
+        y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)  # replicated
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
     nb_batch = max(25, args.warmup + args.steps + 1)
-    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0, ce_mode=A.AE_CE_HOGWILD)
-    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi)
+    params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0,
+                              ce_mode=A.AE_CE_AUTO if faithful else A.AE_CE_HOGWILD, hubness_weighting=hub is not None)
+    eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi, hub_counts=hub)
     nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
     library_comm = args.backend == "nccl"
     comm = sharded = None
@@ -710,14 +734,18 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             dist.all_reduce(t2)
         ce_after, ce0 = float(t2[0]), float(t2[1])
     if rank == 0:
-        rounds = int(eo.samples_drawn()[1])
-        run = dict(rounds=rounds, kernel_ms=kernel_ms_max, ms_per_step=elapsed / args.steps * 1e3, nb_sample=nb_sample, batches_timed=int(launches), mode=0)
+        resolved = eo.get_ce_mode()
+        rounds = int(eo.samples_drawn()[1]) if resolved == 0 else 1
+        run = dict(rounds=rounds, kernel_ms=kernel_ms_max, ms_per_step=elapsed / args.steps * 1e3, nb_sample=nb_sample, batches_timed=int(launches), mode=resolved)
+        if resolved == 5:
+            cl, ovf, crounds, slices = eo.slice_info()
+            run["sliced"] = {"classes": cl, "overflow_mass_fraction": ovf, "slices_per_batch": slices, "max_in_degree": eo.slice_hub_info()[0]}
         roof = roofline_of(run, k, d)
         roof["note"] = "per GPU: bytes of this rank's samples / the slowest rank's batch time, collectives included"
-        points = n if not args.weak else n
+        exch = args.exchanges if library_comm else 1
         out = {
             "metric": "embedded_points_per_sec_ce_epoch",
-            "value": points * args.steps / elapsed,
+            "value": n * args.steps / elapsed,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -726,22 +754,24 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": mode_dtype(resolved),
             "data": "synthetic" if args.backend == "nccl" else "synthetic (VALIDATION RUN over gloo, ranks sharing a GPU: not a result)",
-            "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * len(nbr)), "ce_mode": MODE_NAMES[0] + " -- the only mode that shards; approximate (see fidelity in the N = 1 line)",
-                       "exchanges_per_batch": args.exchanges if library_comm else 1,
+            "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * len(nbr)), "ce_mode": MODE_NAMES.get(resolved),
+                       "exchanges_per_batch": exch,
+                       "bytes_received_per_rank_and_batch": int(exch * n * d * 4),
                        "collective": "in-place RCCL all-gather of the owned rows inside ae_entropy_optim_gradient_iteration (library communicator)" if library_comm
                        else ("in-place RCCL all-gather through torch.distributed on the library stream (the library communicator failed: %s)" % comm_error if torch_gather is not None
                              else "torch/gloo (validation)")},
             "roofline": roof,
             "per_rank_batch_ms_max": kernel_ms_max,
-            "faithful": False,
-            "multi_gpu_note": ("only the APPROXIMATE rounds mode shards (AE_CE_AUTO refuses a sharded node range: no schedule over devices reproduces the "
-                               "reference's loop at a viable exchange volume, DESIGN 5); for output that IS the reference's, configs[3] / [4] run on ONE GPU "
-                               "(the --gpus 1 line's scale_shapes.c4_shape.sliced_mode)"),
-            "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the default faithful mode (its `value` is NOT the one-GPU point of this series); "
-                                 "the same graph and mode as here on ONE GPU is its key scale_shapes.c4_shape.rounds_mode (points_per_s, ms_per_step)"
-                                 if not args.weak else "the --gpus 1 line's key rounds_mode (same shape and mode on one GPU)"),
+            "faithful": "statistically (the time-sliced mode on node ranges: tests/test_gpu_configs.py::test_sharded_sliced_*, DESIGN 5)" if resolved == 5 else False,
+            "multi_gpu_note": ("every rank runs the time-sliced mode on its own node range: its events on current rows, the other ranks' rows (negatives, the far ends of the "
+                               "few cross-shard edges) as of the last all-gather; measured on one GPU with 2 and 8 processes: the result does not depend on the exchanges "
+                               "per batch (1 ... 240), DESIGN 5" if resolved == 5 else
+                               "the rounds mode (asked for with --rounds / --weak) is approximate: its output is not the reference's (DESIGN 4.2)"),
+            "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the default mode (its `value` is NOT the one-GPU point of this series); the same mode on ONE GPU on "
+                                 "the node-permuted graph of the same points is its key scale_shapes.c4_knn_shape.default_mode (points_per_s, ms_per_step)" if resolved == 5 else
+                                 "the --gpus 1 line's key scale_shapes.c4_shape.rounds_mode / rounds_mode (same shape and mode on one GPU)"),
             "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
             "ce_before": ce0, "ce_after": ce_after,
         }

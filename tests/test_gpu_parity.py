@@ -1074,12 +1074,13 @@ def test_range_approx_epsil_stops_at_the_rank(A, oracle):
     assert np.linalg.norm(a64 - q64 @ (q64.T @ a64)) < 1e-4 * np.linalg.norm(a64)
 
 
-@pytest.mark.parametrize("strong", [False, True])
-def test_bench_sharded_path_two_ranks_on_one_gpu(strong):
+@pytest.mark.parametrize("kind", ["weak", "rounds", "faithful"])
+def test_bench_sharded_path_two_ranks_on_one_gpu(kind):
     """bench.py's N > 1 path end to end -- two processes, sharded node ranges, the owned rows exchanged once per batch,
     max-over-ranks timing, one JSON line from rank 0 -- with the two ranks sharing this box's single GPU over gloo (RCCL
-    refuses duplicate devices; the collective is the only difference to the 8-GPU launch of the driver).  Both arrangements:
-    weak scaling on MNIST-shaped shards and strong scaling of one fixed (here: small) lattice graph."""
+    refuses duplicate devices; the collective is the only difference to the 8-GPU launch of the driver).  The default arrangement
+    (faithful): strong scaling of the component-ordered kNN graph of Higgs-shaped points (here: small) in the default mode -- AE_CE_AUTO on
+    a node range = the time-sliced mode; --rounds / --weak: the approximate rounds mode on a lattice / on MNIST-shaped shards."""
     import json
     import socket
     import subprocess
@@ -1091,15 +1092,21 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(strong):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo"]
-    cmd += ["--scale-nodes", "20001"] if strong else ["--weak", "--points-per-gpu", "6000", "--dim", "64"]
+    cmd += {"weak": ["--weak", "--points-per-gpu", "6000", "--dim", "64"], "rounds": ["--rounds", "--scale-nodes", "20001"],
+            "faithful": ["--scale-nodes", "64000"]}[kind]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == ("strong" if strong else "weak")
-    assert j["config"]["samples_per_step"] == (20001 * 6 * 10 if strong else 2 * 6000 * 12 * 10)
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == ("weak" if kind == "weak" else "strong")
+    assert j["config"]["samples_per_step"] == {"weak": 2 * 6000 * 12 * 10, "rounds": 20001 * 6 * 10, "faithful": 64000 * 6 * 10}[kind]
     assert j["value"] > 0 and np.isfinite(j["ce_after"]) and j["roofline"]["launches_per_batch"] >= 1
+    if kind == "faithful":
+        assert "AE_CE_SLICED" in j["config"]["ce_mode"] and str(j["faithful"]).startswith("statistically")
+        assert j["dtype"].startswith("f32 coordinates, f64 scalars")
+    else:
+        assert j["faithful"] is False
 
 
 def test_library_communicator_world_one(A, oracle, graph):
