@@ -1,6 +1,7 @@
 """worker of tests/test_gpu_parity.py::test_embedder_multi_gpu_entry_two_ranks_one_gpu: one rank of a two-rank embedding through
 the library's Embedder-level entry (ae_embedder_set_comm) over the shared-memory communicator; both ranks share this box's GPU.
-usage: embedder_shm_worker.py <dir> <rank> <world> <segment name> <flat|hier>"""
+usage: embedder_shm_worker.py <dir> <rank> <world> <segment name> <flat|hier|faithful>
+(faithful: the default mode -- AE_CE_AUTO on the ranks' node ranges = the time-sliced mode -- on a graph whose node ids are in locality order)"""
 import os
 import sys
 
@@ -19,6 +20,16 @@ def main():
     n = len(g0["indptr"]) - 1
     comm = HostMemComm(rank, world, name, n * 64 * 4)
     par = A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD, grad_step=1.0)
+    if kind == "faithful":
+        par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=False)   # ce_mode = AE_CE_AUTO
+        e = A.Embedder(g, par)
+        e.set_comm(comm, 2)
+        assert e.embed() == 1
+        np.save(os.path.join(out_dir, "y_%s_rank%d.npy" % (kind, rank)), e.get_embedded())
+        np.save(os.path.join(out_dir, "y0_%s_rank%d.npy" % (kind, rank)), e.get_initial_embedding())
+        np.save(os.path.join(out_dir, "ce_%s_rank%d.npy" % (kind, rank)), np.array(e.get_cross_entropy()))
+        comm.close()
+        return
     if kind == "hier":
         small = A.KGraph(g0["s_indptr"], g0["s_nbr"], g0["s_dist"])
         e = A.Embedder.from_hkgraph(A.KGraphProjection(small, g, g0["proj_node"], g0["proj_dist"]), par)
