@@ -171,14 +171,23 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
         if (s_m[t] != 0.) atomicAdd(&mass[t], s_m[t]);
 }
 // per node: the probability mass of its overflow edges (sizes the pending lists); per edge: the key that puts the edges of a class
-// that share a target side by side in the event-generation order (0: overflow edges, in graph order).  A sharded node range
+// that share a target side by side in the event-generation order (below 2^31: overflow edges, shuffled; see `finish`).  A sharded node range
 // [lo, hi) (multi-GPU): the edges this shard generates events for are those whose SOURCE it owns and -- as half events, flagged -- those
 // whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
 // mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
+// a bijection of the node ids (28 bits: kNodeMask has 27): targets in an order that has nothing to do with their labels
+__device__ __forceinline__ uint32_t mix_node(uint32_t v) {
+    constexpr uint32_t kM = (1u << 28) - 1u;
+    v = (v * 0x9E3779B1u) & kM;
+    v ^= v >> 15;
+    v = (v * 0x85EBCA6Bu) & kM;
+    v ^= v >> 13;
+    return v;
+}
 __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                               float* __restrict__ node_ov, uint32_t* __restrict__ group_key, uint32_t* __restrict__ ident,
-                                                              int by_source, uint64_t lo, uint64_t hi, double* __restrict__ mass) {
+                                                              int by_source, int label_order, uint64_t lo, uint64_t hi, double* __restrict__ mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
     double m_gen = 0., m_cross = 0.;
     if (e < nnz) {
@@ -194,9 +203,10 @@ __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, Edge
             if (color[e] == kOverflowColor) {
                 atomicAdd(&node_ov[src], r.w);
                 atomicAdd(&node_ov[r.j], r.w);
-                key = 0;
+                key = label_order ? 0u : pcg_hash((uint32_t)e) >> 1;
             } else {
-                key = (by_source ? src : r.j) + 1u;   // (by_source: a timing experiment only -- chains would be torn apart)
+                const uint32_t g = by_source ? src : r.j;   // (by_source: a timing experiment only -- chains would be torn apart)
+                key = label_order ? g + 1u : 0x80000000u | mix_node(g);
             }
         }
         group_key[e] = key;
@@ -460,14 +470,22 @@ static void slice_color_edges(ae_entropy_optim* o) {
     DevBuf<uint32_t> group_key, ident;
     group_key.alloc_pooled(nnz); ident.alloc_pooled(nnz);
     // Tail of both paths: overflow masses per node, the shard's edges (multi-GPU: node range [node_lo, node_hi)) with their half-event
-    // flags, and the event-generation order -- the overflow edges in graph order, then the class edges sorted by target (stable sort:
-    // the events of a step that share a target end up side by side); the edges of other shards are cut off.
+    // flags, and the event-generation order -- the overflow edges in a random order, then the class edges grouped by target (stable
+    // sort: the events of a step that share a target end up side by side), the targets in the order of a HASH of their labels
+    // (mix_node); the edges of other shards are cut off.  Why not the order of the labels: a workgroup runs 256 consecutive events and
+    // shares a tile of negatives among them (ce_slice_kernels.h: TileShape).  With labels that carry locality (a graph stored component
+    // by component) those 256 samples then sit in one or two clusters and all meet the same few tile windows in a launch: measured CE
+    // 1.06 of the exact mode's, lower quartile of the edge lengths 0.70 on 1 M Higgs-shaped points in component order, against
+    // 1.015 / 0.92 with gathered negatives -- the result depended on how the caller had numbered the nodes.  Hashed, a workgroup's
+    // samples are unrelated whatever the labels say (same graph: 1.016 / 0.88); the batch time did not move (the targets of a step
+    // were ~44 rows apart in label order too: no line was ever shared).
+    const bool label_order = debug_knob("AE_SL_LABEL_ORDER") != nullptr;   // A/B: targets in the order of their labels (rounds 3-4)
     auto finish = [&] {
         DevBuf<double> gm;
         gm.alloc_pooled(2);
         gm.zero();
         hipLaunchKernelGGL(sl_color_finish_kernel, dim3(grid), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, o->sl_node_ov.p,
-                           group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0, o->dev.node_lo, o->dev.node_hi, gm.p);
+                           group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0, label_order ? 1 : 0, o->dev.node_lo, o->dev.node_hi, gm.p);
         check_launch("sl_color_finish");
         const std::vector<double> hg = gm.to_host();
         {   // the busiest row of the overflow class (its events run one per pass)
@@ -482,7 +500,7 @@ static void slice_color_edges(ae_entropy_optim* o) {
         o->sl_gen_mass = hg[0];
         o->sl_cross_frac = hg[0] > 0. ? hg[1] / hg[0] : 0.;
         const bool sharded = o->dev.node_lo != 0 || o->dev.node_hi != n;
-        if (!o->sl_classes && !sharded) { sync(); return; }   // (everything optimistic on one device: graph order as it is)
+        if (!o->sl_classes && !sharded && label_order) { sync(); return; }   // (everything optimistic on one device: graph order as it is)
         DevBuf<uint32_t> key_out, perm;
         key_out.alloc_pooled(nnz); perm.alloc_pooled(nnz);
         sort_pairs_u32_u32(group_key.p, key_out.p, ident.p, perm.p, nnz, 32);

@@ -232,15 +232,22 @@ struct RecFetch {
 // over the nodes (wrapping) and fresh per workgroup and launch, staged in LDS with coalesced loads.  A negative is then "window
 // uniform, row uniform": every node has the same probability 1/n, as in embedder.rs:1121; the rows are as fresh as the launch
 // (it started after every earlier launch's writes).  What differs from the reference: the negatives of the samples a workgroup
-// runs in a launch come from the same kW windows (the marginals are exact, the joint law is not).
+// runs in a launch come from the same kW windows.  Across samples that is harmless (measured: samples sharing all their candidates
+// four by four, or a pool of 256 nodes per workgroup, leave the result where independent draws put it).  INSIDE a sample it is not:
+// the reference's five negatives are five different nodes at five unrelated places (a repeat has probability 25 / n), while five
+// slots out of 256 repeat a row in 4% of the samples and fall into the same window -- neighbouring ids, on a graph whose ids carry
+// locality neighbouring points -- in 62%: two coherent pushes on y_i.  Round 2-4's tile did exactly that and biased clustered graphs
+// (1 M Higgs-shaped points, 8 columns: CE 0.90 of the exact mode's, the shortest edges 2.5x longer; with component-ordered ids CE
+// 0.61), which lattices and single blobs never showed.  draw_negatives therefore takes no window twice in a sample (with
+// hubness weighting: no row twice): the sample's joint law is again "five different, unrelated nodes", every node still has
+// probability 1 / n by symmetry.  tools/run_tile_bias.py, DESIGN.md 4.3.
 template <int DIM>
 struct TileShape {
     // 256 rows (16 windows of 16 consecutive rows) serve the 5 x 256 draws of a workgroup: staging costs one coalesced row read per
     // sample instead of five random ones (a tile of 1024 rows costs as much as the gathers it replaces)
     static constexpr int kRows = DIM <= 16 ? 256 : 128;
-    static constexpr int kL = 16;
+    static constexpr int kL = 16;   // (draw_negatives: window = slot >> 4)
     static constexpr int kW = kRows / kL;
-    static constexpr int kRowBits = DIM <= 16 ? 8 : 7;
     static constexpr int kPieces = kRows * (DIM % 4 == 0 ? DIM / 4 : DIM) / 256;  // loads per thread: 16-byte pieces (single floats for 3 columns)
 };
 __device__ __forceinline__ uint32_t tile_window_start(uint32_t wkey, uint32_t w, uint32_t n) { return __umulhi(pcg_hash(wkey + w * 0x9E3779B9u), n); }
@@ -292,21 +299,29 @@ struct TileFetch {
 
 // the five negatives (embedder.rs:1241-1253): uniform / NodeSampler (:927-930) draws, rejected when k = i, k = j or k in N(i)
 // (nodeparam.rs:83-85; j is in N(i)).  TILE: a draw is a slot of the staged tile (one hash: window and row from its top bits), `out`
-// receives the slots; otherwise node ids (uniform, or hubness-weighted through the alias table), eight candidates at a time so that
+// receives the slots, no window is used twice by a sample (TileShape); otherwise node ids (uniform, or hubness-weighted through the alias table), eight candidates at a time so that
 // the alias look-ups overlap.  Returns the number accepted (5 unless the graph is tiny).
 template <int DIM, int KMAX, bool TILE>
 __device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, const uint32_t* s_tnode, uint32_t nb, uint32_t i,
                                                    const uint32_t (&nbr_reg)[KMAX], uint32_t (&out)[5]) {
     using T = TileShape<DIM>;
     uint32_t got = 0;
+    // the units a sample may use once: windows of T::kL = 16 rows; with hubness weighting single rows (every tile row is a draw of its own)
+    const uint32_t wshift = hub ? 0u : 4u, units = hub ? (uint32_t)T::kRows : (uint32_t)T::kW;
+    static_assert(T::kL == 16 && (T::kW & (T::kW - 1)) == 0 && (T::kRows & (T::kRows - 1)) == 0, "draw_negatives: windows of 16 rows, power-of-two counts");
 #pragma unroll
     for (int g = 0; g < 5; g++) out[g] = TILE ? 0u : i;
     for (uint32_t round = 0; round < 8u && got < 5u; round++) {
         uint32_t cand[8], slot[8];
         if constexpr (TILE) {
+            // candidate number q of the sample sits in unit (u0 + q * stride) mod units, stride odd: a walk that visits every unit once
+            // before it repeats -- consecutive candidates are in different windows by construction; the row inside the window is a
+            // nibble of one more hash
+            const uint32_t rows16 = pcg_hash(nb ^ (round * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int z = 0; z < 8; z++) {
-                const uint32_t row = pcg_hash(nb + (round * 8u + (uint32_t)z) * 0x9E3779B9u) >> (32 - T::kRowBits);
+                const uint32_t unit = ((nb >> 8) + (round * 8u + (uint32_t)z) * ((nb >> 16) | 1u)) & (units - 1u);
+                const uint32_t row = hub ? unit : (unit << 4) | ((rows16 >> (4 * z)) & 15u);
                 cand[z] = s_tnode[row];
                 slot[z] = row;
             }
@@ -333,7 +348,14 @@ __device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, con
             uint32_t acc = cand[z] ^ i;
 #pragma unroll
             for (int m = 0; m < KMAX; m++) { const uint32_t x = nbr_reg[m] ^ cand[z]; acc = x < acc ? x : acc; }
-            const bool ok = acc != 0u && got < 5u;
+            bool dup = false;
+            if constexpr (TILE) {   // no window twice in a sample (TileShape): only once the walk has been round all units
+                if (round * 8u + 8u > units) {
+#pragma unroll
+                    for (int g = 0; g < 5; g++) dup = dup || ((uint32_t)g < got && (out[g] >> wshift) == (slot[z] >> wshift));
+                }
+            }
+            const bool ok = acc != 0u && got < 5u && !dup;
 #pragma unroll
             for (int g = 0; g < 5; g++) out[g] = (ok && got == (uint32_t)g) ? slot[z] : out[g];  // (static indexing keeps `out` in registers)
             got += ok ? 1u : 0u;
