@@ -176,6 +176,12 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
 // whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
 // mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
+// probability mass that arrives at every node (its out-edges carry 1): with it, the rate of the events that touch a node
+__global__ void __launch_bounds__(256) sl_in_mass_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, float* __restrict__ in_mass) {
+    const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
+    if (e < nnz) atomicAdd(&in_mass[erec[e].j], erec[e].w);
+}
+constexpr uint32_t kEndMassMask = 0xFFFFu;   // EdgeRec.flags, low bits: mass of both end points (in + out) in 1/256, saturating
 // a bijection of the node ids (28 bits: kNodeMask has 27): targets in an order that has nothing to do with their labels
 __device__ __forceinline__ uint32_t mix_node(uint32_t v) {
     constexpr uint32_t kM = (1u << 28) - 1u;
@@ -186,7 +192,8 @@ __device__ __forceinline__ uint32_t mix_node(uint32_t v) {
     return v;
 }
 __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
-                                                              float* __restrict__ node_ov, uint32_t* __restrict__ group_key, uint32_t* __restrict__ ident,
+                                                              float* __restrict__ node_ov, const float* __restrict__ in_mass,
+                                                              uint32_t* __restrict__ group_key, uint32_t* __restrict__ ident,
                                                               int by_source, int label_order, uint64_t lo, uint64_t hi, double* __restrict__ mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
     double m_gen = 0., m_cross = 0.;
@@ -196,7 +203,8 @@ __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, Edge
         const bool s_in = src >= lo && src < hi, t_in = r.j >= lo && r.j < hi;
         uint32_t key = kDropKey;
         if (s_in || t_in) {
-            r.flags = s_in ? 0u : kHalfEvent;
+            const float ends = 2.f + in_mass[src] + in_mass[r.j];
+            r.flags = (s_in ? 0u : kHalfEvent) | min((uint32_t)(ends * 256.f + 0.5f), kEndMassMask);
             erec[e].flags = r.flags;
             m_gen = (double)r.w;
             if (!(s_in && t_in)) m_cross = (double)r.w;
@@ -264,13 +272,17 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
     cnt[e] = k;
 }
 // (step key, event) of every event, at the edge's offset.  step key = slice * (classes + 1) + position of the edge's class in the
-// slice's class order (class_pos[slice][class]; overflow last).  The slices of an edge's events are i.i.d. uniform; `spread`: an
-// edge fires at most once per slice -- a second event of the edge in a slice moves to the next one (its repeats would otherwise
-// run back to back inside the step, with no other event of their end points in between; with thin slices this touches < 1 %
-// of the events).
+// slice's class order (class_pos[slice][class]; overflow last).  The slices of an edge's events are i.i.d. uniform.  REPEATS of an
+// edge inside a slice are where a slice differs from the stretch of the i.i.d. sequence it stands for: they land in the same step and
+// run back to back, with no other event of their end points in between -- in the sequence that happens with probability p_stay (below)
+// only.  Rounds 3-4 moved every repeat to the next slice (`spread` 1: never back to back); leaving them (`spread` 0) errs the other
+// way, and both show: 1 M Higgs-shaped points, 8 columns, against the exact mode: lambda 1/8: CE 0.992 / 0.990 (moved / left),
+// 1/4: 0.995 / 0.991, 1/2: 1.008 / 0.967, 1: 1.051 / 0.949 -- clipped attractions are violent (a pair moves to 2 % of its distance),
+// so how two of them on one edge are spaced matters although < 3 % of the events are repeats.  `spread` 2 (the default): a repeat
+// stays with probability p_stay and moves on otherwise.
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
-                                                      const uint8_t* __restrict__ class_pos, uint32_t classes, int spread,
+                                                      const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
                                                       uint32_t* __restrict__ keys, Event* __restrict__ vals) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
     if (e >= n_gen) return;
@@ -285,18 +297,27 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     uint32_t* sl = s_sl + threadIdx.x;
 #define SL(r) sl[(r) * 256u]
     const bool sorted = spread && k > 1 && k <= kSortMax && k <= n_slices;
-    if (sorted) {  // the k slices in ascending order (insertion sort), then made strictly increasing
+    if (sorted) {  // the k slices in ascending order (insertion sort); then the repeats inside a slice are dealt with
         for (uint32_t r = 0; r < k; r++) {
             const uint32_t s = __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
             uint32_t q = r;
             while (q > 0 && SL(q - 1) > s) { SL(q) = SL(q - 1); q--; }
             SL(q) = s;
         }
-        for (uint32_t r = 1; r < k; r++) SL(r) = max(SL(r), SL(r - 1) + 1u);
+        // p_stay: the probability that NO other event of the edge's end points falls between two events of the edge that share a slice,
+        // in the i.i.d. sequence the slices stand for: the two at uniform places of the slice (distance x: density 2 (1 - x)), the
+        // others a Poisson stream of rate rho per slice: 2 (rho - 1 + exp(-rho)) / rho^2
+        const float rho = (float)(er.flags & kEndMassMask) * (1.0f / 256.0f) * ev_per_mass;
+        const float p_stay = spread == 1 ? 0.f : (rho < 0.05f ? 1.f - rho * (1.0f / 3.0f) : 2.f * (rho - 1.f + __expf(-rho)) / (rho * rho));
+        for (uint32_t r = 1; r < k; r++) {
+            if (SL(r) > SL(r - 1)) continue;
+            const float u = (float)(pcg_hash((pcg_hash((uint32_t)e) ^ 0x5851F42Du) + r * 0x9E3779B9u + tk) >> 8) * (1.0f / 16777216.0f);
+            SL(r) = SL(r - 1) + (u < p_stay ? 0u : 1u);
+        }
         // what ran past the end of the segment is pulled back from the top
         if (SL(k - 1) >= n_slices) {
             SL(k - 1) = n_slices - 1u;
-            for (uint32_t r = k - 1; r > 0 && SL(r - 1) >= SL(r); r--) SL(r - 1) = SL(r) - 1u;
+            for (uint32_t r = k - 1; r > 0 && SL(r - 1) > SL(r); r--) SL(r - 1) = SL(r);
         }
     }
     for (uint32_t r = 0; r < k; r++) {
@@ -484,8 +505,12 @@ static void slice_color_edges(ae_entropy_optim* o) {
         DevBuf<double> gm;
         gm.alloc_pooled(2);
         gm.zero();
+        DevBuf<float> in_mass;
+        in_mass.alloc_pooled(n);
+        in_mass.zero();
+        hipLaunchKernelGGL(sl_in_mass_kernel, dim3(grid), dim3(256), 0, stream(), nnz, (const EdgeRec*)erec, in_mass.p);
         hipLaunchKernelGGL(sl_color_finish_kernel, dim3(grid), dim3(256), 0, stream(), nnz, erec, (const uint8_t*)o->sl_color.p, o->sl_node_ov.p,
-                           group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0, label_order ? 1 : 0, o->dev.node_lo, o->dev.node_hi, gm.p);
+                           (const float*)in_mass.p, group_key.p, ident.p, debug_knob("AE_SL_SORT_SRC") ? 1 : 0, label_order ? 1 : 0, o->dev.node_lo, o->dev.node_hi, gm.p);
         check_launch("sl_color_finish");
         const std::vector<double> hg = gm.to_host();
         {   // the busiest row of the overflow class (its events run one per pass)
@@ -689,7 +714,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         const double busiest = (double)o->sl_node_ov_max * (seg_samples / (double)n) / (double)n_slices;
         passes = std::max(passes, (int)std::min(16.0, std::ceil(1.5 * busiest + 1.0)));
     }
-    const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : 1;
+    const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : (debug_knob("AE_SL_SPREAD_ALL") ? 1 : 2);
     // scalar arithmetic: the reference's f64 (embedder.rs:1207-1229) unless the caller opted into f32 (ae_embedder_params.ce_precision)
     const bool f64 = o->params.ce_precision != AE_PRECISION_F32;
     const uint32_t classes = o->sl_classes;
@@ -830,7 +855,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
-                           (const uint8_t*)o->sl_class_pos.p, classes, spread, o->sl_keys0.p, ev0);
+                           (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices), o->sl_keys0.p, ev0);
         if (prof) sync();
         const double t_fill = wall();
         const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbits);

@@ -47,10 +47,18 @@ def run(mode, knobs=None, seed=4664397):
 seeds = [int(x) for x in os.environ.get("SEEDS", "11,22,33,44").split(",")]
 cases = {"sequential": (A.AE_CE_SEQUENTIAL, {}), "sliced, no tile": (A.AE_CE_SLICED, {"AE_SL_NO_TILE": "1"}), "sliced (tile where it applies)": (A.AE_CE_SLICED, {}),
          "sliced classes, no tile": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1"}),
-         "event-ordered": (A.AE_CE_EVENT, {}),
-         "sliced classes, no tile, lambda 0.125": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_LAMBDA": "0.125"}),
-         "sliced classes, no tile, lambda 2": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_LAMBDA": "2", "AE_SL_NO_FIT": "1"}),
-         "sliced classes, no tile, no spread": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_SPREAD": "1"}),
+         "lambda 0.125": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.125"}),
+         "lambda 0.125 every repeat moved": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.125", "AE_SL_SPREAD_ALL": "1"}),
+         "lambda 0.125 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.125", "AE_SL_NO_SPREAD": "1"}),
+         "lambda 0.25": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.25"}),
+         "lambda 0.25 every repeat moved": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.25", "AE_SL_SPREAD_ALL": "1"}),
+         "lambda 0.25 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.25", "AE_SL_NO_SPREAD": "1"}),
+         "lambda 0.5": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.5"}),
+         "lambda 0.5 every repeat moved": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.5", "AE_SL_SPREAD_ALL": "1"}),
+         "lambda 0.5 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "0.5", "AE_SL_NO_SPREAD": "1"}),
+         "lambda 1": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1"}),
+         "lambda 1 every repeat moved": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1", "AE_SL_SPREAD_ALL": "1"}),
+         "lambda 1 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1", "AE_SL_NO_SPREAD": "1"}),
          "sliced classes, tile forced": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1"})}
 only = os.environ.get("CASES")
 res = {}
