@@ -9,6 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
 # counters: their own passes, the C2 workload only (the scale shapes instantiate the same kernel templates)
 PMCARGS="--no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd"
+# kernel stats of the C2 workload alone: every dispatch of the headline kernel is a warm-up or a timed batch of the bench line (in
+# the full run above its average also holds the fidelity schedule's 25 batches from the dmap start, which are deeper chains)
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_c2 -o trace -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_trace_c2.log 2>&1
 AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace -d $OUT/pmc_sq -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_sq.log 2>&1
 AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_fetch.log 2>&1
 AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_pmc_write.log 2>&1
