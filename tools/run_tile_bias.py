@@ -17,6 +17,9 @@ gr = bench.config_graphs(A, "c4", permute_seed=int(os.environ.get("PERMUTE", "9"
 indptr, nbr, dist = gr["indptr"], gr["nbr"], gr["dist"]
 g = A.KGraph(indptr, nbr, dist, k)
 hub = g.hubness() if os.environ.get("HUBW", "1") == "1" else None
+if os.environ.get("HUBSYN") == "1":   # a heavy-tailed synthetic weighting (1 % of the nodes 500x as likely): a wrong negative law shows
+    hub = np.ones(n, np.uint32)
+    hub[np.random.default_rng(5).choice(n, n // 100, replace=False)] = 500
 npar = A.to_proba_edges(g, 1.0, 1.0)
 y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
 
