@@ -127,6 +127,7 @@ struct ae_entropy_optim {
     DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
     DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
+    DevBuf<uint32_t> sl_hub_pool;               // (hubness weighting) the batch's pool of NodeSampler draws for the tiles of negatives
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)
     uint64_t sl_gen_edges = 0;                  // edges this handle generates events for (a shard: those with an end in its node range)
     double sl_gen_mass = 0.;                    // their probability mass (the whole graph: n)

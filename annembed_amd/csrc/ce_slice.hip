@@ -328,6 +328,16 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     }
 #undef SL
 }
+// (hubness weighting) the batch's pool of i.i.d. draws of the NodeSampler (embedder.rs:927-930), ce_slice_kernels.h: TileFetch
+__global__ void __launch_bounds__(256) sl_hub_pool_kernel(CeDev c, uint32_t key, uint32_t count, uint32_t* __restrict__ pool) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= count) return;
+    const uint32_t w0 = pcg_hash(pcg_hash(round_hash_key(key, c.seed) ^ kTagSlPool) + x * 0x9E3779B9u);
+    const uint32_t xs = __umulhi(w0, (uint32_t)c.n);
+    const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+    const uint2 he = c.hub_tab[xs];
+    pool[x] = (uu < __uint_as_float(he.x)) ? xs : he.y;
+}
 __global__ void sl_sptr_kernel(const uint32_t* __restrict__ keys, uint32_t total, uint32_t n_keys, uint32_t* __restrict__ sptr) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_keys) return;
@@ -786,6 +796,15 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_chunk_flag.n < (ev_cap >> 6) + 4) o->sl_chunk_flag.alloc((ev_cap >> 6) + 4);
     o->sl_chunk_flag.zero();
     da.chunk_flag = o->sl_chunk_flag.p;
+    a.hub_pool = da.hub_pool = nullptr;
+    a.hub_pool_n = da.hub_pool_n = 0;
+    if (o->dev.hub_odds) {   // fresh every batch
+        const uint32_t pool_n = n >= (1ull << 20) ? (1u << 24) : (1u << 20);
+        if (o->sl_hub_pool.n < pool_n) o->sl_hub_pool.alloc(pool_n);
+        hipLaunchKernelGGL(sl_hub_pool_kernel, dim3(blocks_for(pool_n, 256)), dim3(256), 0, stream(), o->dev, (uint32_t)(iter << 12), pool_n, o->sl_hub_pool.p);
+        a.hub_pool = da.hub_pool = o->sl_hub_pool.p;
+        a.hub_pool_n = da.hub_pool_n = pool_n;
+    }
     // the edges in event-generation order (the edges of a class sorted by target: slice_color_edges) and their classes
     const EdgeRec* gen_erec = reinterpret_cast<const EdgeRec*>(o->sl_erec_gen.n ? o->sl_erec_gen.p : o->sl_erec.p);
     const uint8_t* gen_color = o->sl_color_gen.n ? o->sl_color_gen.p : o->sl_color.p;

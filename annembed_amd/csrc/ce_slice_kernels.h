@@ -11,7 +11,7 @@
 namespace ae {
 namespace sl {
 
-constexpr uint32_t kTagSlCount = 0xFFFF0031u, kTagSlTime = 0xFFFF0032u, kTagSlNeg = 0xFFFF0033u, kTagSlCoin = 0xFFFF0034u, kTagSlColor = 0xFFFF0035u;
+constexpr uint32_t kTagSlCount = 0xFFFF0031u, kTagSlTime = 0xFFFF0032u, kTagSlNeg = 0xFFFF0033u, kTagSlCoin = 0xFFFF0034u, kTagSlColor = 0xFFFF0035u, kTagSlPool = 0xFFFF0036u;
 // the pending list is kept as kSub sub-lists with a counter each: appends (one atomic per WORKGROUP) spread over kSub addresses --
 // one counter serialises at ~12 ns per atomic, which with one atomic per wave was 2/3 of a pass at the C3 shape
 constexpr int kSub = 16;
@@ -58,6 +58,8 @@ struct SliceArgs {
     int backoff;                // 1: a deferred event marks only with probability 1/2
     double step;
     unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = overflow flag
+    const uint32_t* hub_pool;   // (hubness weighting) the batch's pool of NodeSampler draws, see TileFetch
+    uint32_t hub_pool_n;
 };
 
 struct DirectArgs {
@@ -73,6 +75,8 @@ struct DirectArgs {
     double step;
     unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = error flags (1: pending list overflow, 2: hand-over poll budget)
     uint32_t* chunk_flag;       // hand-over of a target's row between the 64-event chunks of a step: [chunk] = step token once the chunk's tail is through
+    const uint32_t* hub_pool;   // (hubness weighting) the batch's pool of NodeSampler draws, see TileFetch
+    uint32_t hub_pool_n;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -255,24 +259,23 @@ __device__ __forceinline__ uint32_t tile_window_start(uint32_t wkey, uint32_t w,
 // The tile's loads are ISSUED at the start of the kernel (next to the event load) and LANDED in LDS when the sample's own loads
 // are in flight: staging is off the critical path.  Hubness-weighted sampling (NodeSampler, embedder.rs:915-930: what
 // examples/higgs.rs switches on) cannot use runs of consecutive rows: there every tile row is an independent draw of the alias
-// table (one 8-byte look-up, then the row) -- a slot picked uniformly afterwards is again a draw of the reference's law; two
-// requests per tile row instead of ten per sample.
+// table -- a slot picked uniformly afterwards is again a draw of the reference's law.  The draws themselves are made ahead, once
+// per batch: a POOL of 2^24 (small graphs: 2^20) i.i.d. draws (sl_hub_pool_kernel), of which a tile takes kRows consecutive ones at
+// a uniform offset -- again kRows independent draws, read with one coalesced request where every row used to cost a random 8-byte
+// look-up of its own.
 template <int DIM>
 struct TileFetch {
     using T = TileShape<DIM>;
     static constexpr int Q = DIM % 4 == 0 ? DIM / 4 : DIM;  // pieces per row
     f4 pc[T::kPieces];
     uint32_t node[T::kPieces];
-    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub) {
+    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n) {
+        const uint32_t pool_at = hub ? __umulhi(pcg_hash(wkey), hub_pool_n - (uint32_t)T::kRows) : 0u;
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
             const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = x / Q;
             if (hub) {
-                const uint32_t w0 = pcg_hash(wkey + r * 0x9E3779B9u);
-                const uint32_t xs = __umulhi(w0, (uint32_t)c.n);
-                const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
-                const uint2 he = c.hub_tab[xs];
-                node[z] = (uu < __uint_as_float(he.x)) ? xs : he.y;
+                node[z] = hub_pool[pool_at + r];   // a run of the batch's pool: kRows independent draws of the alias table, one coalesced read
             } else {
                 node[z] = tile_window_start(wkey, r / T::kL, (uint32_t)c.n) + r % T::kL;
                 node[z] -= node[z] >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
@@ -547,7 +550,7 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
             if (p + 1 < a.end) nx = a.ev[p + 1];
         }
         TileFetch<DIM> ft;
-        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
         const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
         const bool half = act0 && ev_half(e.j);   // (multi-GPU) the source is another shard's: attraction on the target's row only
         // chains: this event has the previous one's target / the next one has this one's
@@ -687,7 +690,7 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         const bool half = ev_half(p.j);
         const uint32_t o1 = own_chk[p.im >> 5], o2 = own_chk[pj];
         TileFetch<DIM> ft;
-        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub);
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
         const bool win = have && o1 == p.idx && o2 == p.idx;
         const uint32_t i = p.im >> 5, idx = p.idx;
         // everything that depends only on (i, j): both rows, the static record of i -- in flight together.  Plain (cached) loads: a
