@@ -260,6 +260,31 @@ def component_knn_graph(A, x, bounds, k, permute_seed):
     return indptr, np.ascontiguousarray(nbr.reshape(-1)), np.ascontiguousarray(dist.reshape(-1))
 
 
+def full_size_shape(A, L, which, d, steps):
+    """A config's own graph at FULL size on this one GPU, the mode AE_CE_AUTO resolves to only (no rounds / f32 / parity variants: at
+    50 M nodes each of them is a minute): random start, one warm-up batch, `steps` timed ones.  configs[4] is specified over 8 GPUs;
+    one MI355X holds it whole (55 GB)."""
+    import torch
+    gr = config_graphs(A, which)
+    n, k = gr["n"], gr["k"]
+    indeg = np.bincount(gr["nbr"], minlength=n)
+    kg = A.KGraph(gr["indptr"], gr["nbr"], gr["dist"], k)
+    node_params = A.to_proba_edges(kg, 1.0, 1.0)
+    y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
+    run = time_mode(A, L, kg, node_params, y0, d, A.AE_CE_AUTO, steps, 1)
+    out = {"nodes": n, "k": k, "asked_dim": d, "graph": gr["desc"], "graph_build_s": gr["build_s"], "max_in_degree": int(indeg.max()),
+           "in_degree_q999": float(np.quantile(indeg, 0.999)), "start": "random normal layout in the 10-box",
+           "default_mode": {"faithful": "statistically", "ce_mode": MODE_NAMES.get(run["mode"], str(run["mode"])), "dtype": run["dtype"],
+                            "ms_per_step": run["ms_per_step"], "steps_timed": steps, "points_per_s": n / (run["ms_per_step"] * 1e-3),
+                            "samples_per_s": run["nb_sample"] / (run["ms_per_step"] * 1e-3), "ce_before": run["ce_before"], "ce_after": run["ce_after"],
+                            "roofline": roofline_of(run, k, d)}}
+    free, total = torch.cuda.mem_get_info()
+    out["hbm_used_gb"] = round((total - free) / 1e9, 1)
+    del run, kg, node_params
+    torch.cuda.empty_cache()
+    return out
+
+
 def scale_shape(A, L, name, n, k, d, steps, with_sequential, graph=None, hub_weighting=False, dmap_start=None):
     """configs[2] / [3] / [4]-shard shapes on one GPU.  graph None: the node-permuted ring lattice (uniform in-degree: the best case of
     every faithful mode), started from its diffusion-map initialisation.  graph = dict(indptr, nbr, dist, desc, build_s): a kNN graph of
@@ -348,9 +373,12 @@ def config_graphs(A, which, permute_seed=9, n_override=None):
         x, bounds = mixture_points_gpu(n, dim, ncomp, seed=3, mean_sigma=2.0, higgs_like=True)
         what = "Higgs-shaped points (28-D, 64 overlapping Gaussian components, columns standardised; SURVEY 8d, seed 3)"
     else:
-        n, dim, ncomp, k = 6_250_000, 128, 125, 10
+        if which == "c5_full" and not n_override:
+            n_override = 50_000_000
+        n, dim, k = n_override or 6_250_000, 128, 10
+        ncomp = max(1, n // 50_000)
         x, bounds = mixture_points_gpu(n, dim, ncomp, seed=4, mean_sigma=10.0)
-        what = "points of the 128-D mixture (125 of configs[4]'s 1 000 components of 50 000 points: means N(0, 10^2), sigma 1; SURVEY 8d, seed 4)"
+        what = "points of the 128-D mixture (%d of configs[4]'s 1 000 components of 50 000 points: means N(0, 10^2), sigma 1; SURVEY 8d, seed 4)" % ncomp
     t1 = time.perf_counter()
     indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed)
     del x
@@ -374,6 +402,7 @@ def main():
     ap.add_argument("--no-exact-mode", action="store_true")
     ap.add_argument("--no-fidelity", action="store_true")
     ap.add_argument("--no-scale-shapes", action="store_true")
+    ap.add_argument("--no-full-size", action="store_true", help="skip the full-size configs[4] shape (50 M nodes: about a minute)")
     ap.add_argument("--ce-mode", default="auto", choices=["auto", "event", "rounds", "sequential", "ordered"], help="mode of the headline figure at N = 1")
     ap.add_argument("--lattice-graph", action="store_true",
                     help="N = 1 scale runs: ring-lattice kNN graph (node ids permuted) with --points-per-gpu nodes instead of the MNIST-shaped points")
@@ -560,6 +589,8 @@ def main():
             "c5_shard_knn_shape": scale_shape(A, L, "c5knn", 6_250_000, 10, 16, 5, with_sequential=False, graph=config_graphs(A, "c5")),
             "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 5, with_sequential=False),
         }
+        if not args.no_full_size:   # configs[4] whole: 50 M points of the 128-D mixture, 5 G samples per batch, on this one GPU (~1 min, mostly the graph)
+            scale_shapes["c5_full_shape"] = full_size_shape(A, L, "c5_full", 16, 2)
 
     roof = roofline_of(head, k, d)
     if head["mode"] in (1, 6):

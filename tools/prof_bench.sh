@@ -6,9 +6,9 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
+AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/bench.py --no-cpu-baseline --no-full-size "$@" > $OUT/bench_trace.log 2>&1
 # counters: their own passes, the C2 workload only (the scale shapes instantiate the same kernel templates)
-PMCARGS="--no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd"
+PMCARGS="--no-cpu-baseline --no-scale-shapes --no-fidelity --no-dense-svd --no-full-size"
 # kernel stats of the C2 workload alone: every dispatch of the headline kernel is a warm-up or a timed batch of the bench line (in
 # the full run above its average also holds the fidelity schedule's 25 batches from the dmap start, which are deeper chains)
 AE_DEBUG_KNOBS=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace_c2 -o trace -- python3 $R/bench.py $PMCARGS "$@" > $OUT/bench_trace_c2.log 2>&1
