@@ -279,8 +279,8 @@ def test_c4_shape_single_gpu_properties(A):
 def test_c5_shape_one_shard_properties(A):
     """configs[4] shape, one GPU's share of it: the full 50 M-node graph (k = 10, ring lattice with randomly PERMUTED node ids)
     and the full 50 M x 16 coordinate replica on the device, this rank owning the first eighth of the nodes (6.25 M sources,
-    62.5 M edges, 625 M samples per batch).  The rounds mode, asked for by name (AE_CE_AUTO refuses a sharded range; the d = 16
-    node kernel with tile negatives); one batch keeps its invariants: samples drawn within 6 sigma of the shard's nb_sample,
+    62.5 M edges, 625 M samples per batch).  The rounds mode, asked for by name (the d = 16 node kernel with tile negatives; the
+    faithful mode at this size: test_c5_full_size_default_mode_one_gpu below, un-sharded); one batch keeps its invariants: samples drawn within 6 sigma of the shard's nb_sample,
     finite rows, every owned row moved, NO row outside the shard touched (owner computes), the box stays bounded."""
     n, k, d, world = 50_000_000, 10, 16, 8
     rng = np.random.default_rng(4)
@@ -298,7 +298,7 @@ def test_c5_shape_one_shard_properties(A):
     npar = A.to_proba_edges(g, 1.0, 1.0)
     y0 = A.set_data_box(rng.standard_normal((n, d), dtype=np.float32), 10.0)
     hi = n // world
-    h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=0, node_hi=hi)  # (AE_CE_AUTO refuses a shard)
+    h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=0, node_hi=hi)
     assert h.get_ce_mode() == A.AE_CE_HOGWILD
     S = 10 * h.get_nb_edges()
     assert S == 10 * hi * k
@@ -309,6 +309,43 @@ def test_c5_shape_one_shard_properties(A):
     assert np.isfinite(y).all() and np.abs(y).max() < 50
     assert (np.abs(y[:hi] - y0[:hi]).max(1) > 0).all()
     assert np.array_equal(y[hi:], y0[hi:])
+
+
+def test_c5_full_size_default_mode_one_gpu(A):
+    """configs[4] WHOLE, in the mode AE_CE_AUTO resolves to, on this one GPU: 50 M points of the 128-D mixture (1 000 components of
+    50 000: SURVEY 8d's generator), exact kNN inside every component (k = 10: 500 M edges, in-degrees to ~5 500), node ids permuted,
+    -> 16-D; 5 G samples per batch in 5 segments, ~55 GB of HBM, ~1.5 s per batch.  No second run is affordable at this size (the exact
+    mode would take minutes per batch): size-independent properties -- the events executed are the Poisson totals (within 6 sigma of
+    nb_sample per batch), every row finite and moved, the layout stays bounded, neighbours come together (median edge length of a
+    2 M-edge sample falls below half its start)."""
+    import bench
+    gr = bench.config_graphs(A, "c5_full")
+    n, k, d = gr["n"], gr["k"], 16
+    assert n == 50_000_000 and k == 10
+    indptr, nbr = gr["indptr"], gr["nbr"]
+    g = A.KGraph(indptr, nbr, gr["dist"], k)
+    del gr["dist"]
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, nb_grad_batch=20, grad_step=1.0), y0)   # ce_mode: AE_CE_AUTO
+    assert eo.get_ce_mode() == A.AE_CE_SLICED
+    S = 10 * eo.get_nb_edges()
+    assert S == 5_000_000_000
+    for it in (1, 2):
+        eo.gradient_iteration_threaded(S, 1.0 * (1 - it / 20), it)
+    drawn, _ = eo.samples_drawn()
+    assert abs(drawn - 2 * S) < 6 * np.sqrt(2 * S), (drawn, 2 * S)
+    classes, ov, _, slices = eo.slice_info()
+    assert classes == 18 and ov < 0.02 and slices >= 5 * 16, (classes, ov, slices)
+    y = eo.get_embedded()
+    assert np.isfinite(y).all() and np.abs(y).max() < 200
+    pick = np.random.default_rng(3).integers(0, n * k, 2_000_000)
+    src = pick // k
+    before = np.median(np.linalg.norm(y0[src] - y0[nbr[pick]], axis=1))
+    after = np.median(np.linalg.norm(y[src] - y[nbr[pick]], axis=1))
+    print("configs[4] whole: median edge length %.3f -> %.3f" % (before, after))
+    assert after < 0.5 * before
+    assert (np.abs(y[::97] - y0[::97]).max(1) > 0).all()
 
 
 def test_hub_stress_sliced_1m_nodes(A):
