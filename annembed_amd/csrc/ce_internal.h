@@ -128,6 +128,11 @@ struct ae_entropy_optim {
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
     DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
     DevBuf<uint32_t> sl_hub_pool;               // (hubness weighting) the batch's pool of NodeSampler draws for the tiles of negatives
+    // internal node numbering of the time-sliced mode (one device): node v lives in row sl_perm[v] of sl_y / the static records during a
+    // batch (a uniform random relabelling: what runs of consecutive rows hold has nothing to do with the caller's labels)
+    DevBuf<uint32_t> sl_perm;
+    DevBuf<float> sl_y;
+    DevBuf<uint2> sl_hub_tab;                   // the NodeSampler's alias table in internal numbering
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)
     uint64_t sl_gen_edges = 0;                  // edges this handle generates events for (a shard: those with an end in its node range)
     double sl_gen_mass = 0.;                    // their probability mass (the whole graph: n)

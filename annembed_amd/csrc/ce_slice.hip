@@ -233,12 +233,19 @@ __global__ void __launch_bounds__(256) sl_count_below_kernel(uint64_t nnz, const
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 // the edges in event-generation order: out[x] = in[perm[x]]
+// (relabel: the internal numbering of the nodes, or null)
 __global__ void __launch_bounds__(256) sl_permute_edges_kernel(uint64_t nnz, const uint32_t* __restrict__ perm, const EdgeRec* __restrict__ erec,
-                                                               const uint8_t* __restrict__ color, EdgeRec* __restrict__ erec_out, uint8_t* __restrict__ color_out) {
+                                                               const uint8_t* __restrict__ color, const uint32_t* __restrict__ relabel,
+                                                               EdgeRec* __restrict__ erec_out, uint8_t* __restrict__ color_out) {
     const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
     if (x >= nnz) return;
     const uint32_t e = perm[x];
-    erec_out[x] = erec[e];
+    EdgeRec r = erec[e];
+    if (relabel) {
+        r.j = relabel[r.j];
+        r.im = (relabel[r.im >> 5] << 5) | (r.im & 31u);
+    }
+    erec_out[x] = r;
     color_out[x] = color[e];
 }
 // expected backlog of the overflow class: what the rows with more than `per_slice_cap` overflow events per slice cannot run
@@ -357,7 +364,9 @@ __global__ void sl_edge_rec_kernel(CeDev c, EdgeRec* __restrict__ out) {
     for (uint64_t e = b; e < e1; e++) out[e] = EdgeRec{c.nbr[e], c.proba[e], 0u, ((uint32_t)i << 5) | (uint32_t)(e - b)};
 }
 // static record of a node: SREC floats = {embedded scale, KP neighbour ids (padded with ~0), KP edge probabilities}, KP = (SREC - 1) / 2
-__global__ void sl_static_rec_kernel(CeDev c, uint32_t srec, float* __restrict__ out) {
+// (perm: the internal numbering, ae_entropy_optim::sl_perm, or null: the record of node i sits in row perm[i] and names its neighbours
+// by their internal numbers)
+__global__ void sl_static_rec_kernel(CeDev c, uint32_t srec, const uint32_t* __restrict__ perm, float* __restrict__ out) {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= c.n) return;
     uint64_t b;
@@ -365,13 +374,37 @@ __global__ void sl_static_rec_kernel(CeDev c, uint32_t srec, float* __restrict__
     if (c.uniform_k) { b = i * c.uniform_k; k = c.uniform_k; }
     else { b = c.indptr[i]; k = (uint32_t)(c.indptr[i + 1] - b); }
     const uint32_t kp = (srec - 1u) / 2u;
-    float* r = out + i * srec;
+    float* r = out + (uint64_t)(perm ? perm[i] : (uint32_t)i) * srec;
     r[0] = c.emb_scale[i];
     for (uint32_t m = 0; m < kp; m++) {
-        r[1 + m] = __uint_as_float(m < k ? c.nbr[b + m] : 0xFFFFFFFFu);
+        r[1 + m] = __uint_as_float(m < k ? (perm ? perm[c.nbr[b + m]] : c.nbr[b + m]) : 0xFFFFFFFFu);
         r[1 + kp + m] = m < k ? c.proba[b + m] : 0.f;
     }
     for (uint32_t m = 1 + 2 * kp; m < srec; m++) r[m] = 0.f;
+}
+
+// internal numbering: keys for the random order, its inverse, and the row moves of a batch's start and end
+__global__ void __launch_bounds__(256) sl_perm_keys_kernel(uint64_t n, uint32_t seed, uint32_t* __restrict__ keys, uint32_t* __restrict__ ident) {
+    const uint64_t v = blockIdx.x * 256ull + threadIdx.x;
+    if (v < n) { keys[v] = pcg_hash((uint32_t)v ^ seed); ident[v] = (uint32_t)v; }
+}
+__global__ void __launch_bounds__(256) sl_perm_invert_kernel(uint64_t n, const uint32_t* __restrict__ order, uint32_t* __restrict__ perm) {
+    const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
+    if (x < n) perm[order[x]] = (uint32_t)x;
+}
+// rows of `dim` floats: to_internal: dst[perm[v]] = src[v]; else dst[v] = src[perm[v]]
+__global__ void __launch_bounds__(256) sl_move_rows_kernel(uint64_t n, uint32_t dim, const uint32_t* __restrict__ perm, const float* __restrict__ src,
+                                                           float* __restrict__ dst, int to_internal) {
+    const uint64_t t = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t v = t / dim, q = t % dim;
+    if (v >= n) return;
+    const uint64_t p = perm[v];
+    if (to_internal) dst[p * dim + q] = src[v * dim + q];
+    else dst[v * dim + q] = src[p * dim + q];
+}
+__global__ void __launch_bounds__(256) sl_hub_tab_kernel(uint64_t n, const uint32_t* __restrict__ perm, const uint2* __restrict__ tab, uint2* __restrict__ out) {
+    const uint64_t v = blockIdx.x * 256ull + threadIdx.x;
+    if (v < n) out[perm[v]] = make_uint2(tab[v].x, perm[tab[v].y]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -482,6 +515,7 @@ const char* ce_slice_unsupported(const ae_entropy_optim* o) {
 
 // the edge colouring of the graph (see the kernels above): sl_color[e] = class of edge e or kOverflowColor, and the event-generation
 // order of the edges (the edges of a class that share a target side by side)
+static double sl_resident_events(ae_entropy_optim* o);
 static void slice_color_edges(ae_entropy_optim* o) {
     const uint64_t n = o->dev.n, nnz = o->dev.nnz;
     EdgeRec* erec = reinterpret_cast<EdgeRec*>(o->sl_erec.p);
@@ -551,7 +585,8 @@ static void slice_color_edges(ae_entropy_optim* o) {
         o->sl_color_gen.alloc(std::max<uint64_t>(1, n_gen));
         if (n_gen)
             hipLaunchKernelGGL(sl_permute_edges_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), (uint64_t)n_gen, (const uint32_t*)perm.p,
-                               (const EdgeRec*)erec, (const uint8_t*)o->sl_color.p, reinterpret_cast<EdgeRec*>(o->sl_erec_gen.p), o->sl_color_gen.p);
+                               (const EdgeRec*)erec, (const uint8_t*)o->sl_color.p, (const uint32_t*)(o->sl_perm.n ? o->sl_perm.p : nullptr),
+                               reinterpret_cast<EdgeRec*>(o->sl_erec_gen.p), o->sl_color_gen.p);
         check_launch("sl_permute_edges");
         sync();
         o->sl_erec.release();   // (the generation order is what the batches read)
@@ -584,8 +619,20 @@ static void slice_color_edges(ae_entropy_optim* o) {
     // Constants measured on MI355X.
     const uint32_t kmax = o->g->max_nbng;
     uint32_t classes = std::min<uint32_t>(kMaxClasses, kmax + std::max<uint32_t>(4u, (4u * kmax + 4u) / 5u));
-    if (debug_knob("AE_SL_CLASS_CAP")) classes = std::min<uint32_t>(kMaxClasses, std::max<int>((int)kmax + 1, atoi(debug_knob("AE_SL_CLASS_CAP"))));
     const double events = (double)o->params.nb_sampling_by_edge * (double)nnz;
+    // More classes where they cost nothing: a batch whose steps are cut to what the device holds at once (ce_slice_gradient_iteration:
+    // "slices as thin as a resident step") runs events / resident steps however many classes share a slice, so the palette may grow
+    // until the slices are back at their lambda thickness -- and a wider palette leaves less to the overflow class (11 M-node kNN
+    // graph, k = 6: 11 classes 1.9 %, 13: 0.4 %, 15: 0.07 %; 166 -> 160 ms per batch).  One device only: the ranks of a sharded run
+    // must cut their batches alike, and the slice count follows the classes.
+    const bool whole = o->dev.node_lo == 0 && o->dev.node_hi == n;
+    if (whole && !debug_knob("AE_SL_NO_FIT") && !debug_knob("AE_SL_BASE_CLASSES")) {
+        const double slices_lambda = std::max(1.0, std::ceil(2.0 * events / (double)n / 0.5));
+        const double fit = events / (sl_resident_events(o) * slices_lambda);
+        if (fit > (double)classes && fit < 4.0 * (double)classes)   // (the regime in which the slices are thinned: a step of 1 ... 4 device loads)
+            classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, classes + 4u), (uint32_t)fit);
+    }
+    if (debug_knob("AE_SL_CLASS_CAP")) classes = std::min<uint32_t>(kMaxClasses, std::max<int>((int)kmax + 1, atoi(debug_knob("AE_SL_CLASS_CAP"))));
     const double slices = std::max(1.0, 4.0 * events / (double)n);
     const double busiest = 0.5 * (double)(indeg_max + kmax) * (double)n / (double)(2 * nnz);   // events per slice on the busiest row
     const double c_match = o->dev.dim <= 8 ? 0.14e-9 : 0.24e-9;
@@ -645,8 +692,33 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     hipLaunchKernelGGL(sl_edge_rec_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), o->dev, reinterpret_cast<EdgeRec*>(o->sl_erec.p));
     // static records: 16 floats serve rows of <= 7 neighbours, 32: <= 15, 64: <= 31, 128: 32
     o->sl_srec_floats = g->max_nbng <= 7 ? 16u : (g->max_nbng <= 15 ? 32u : (g->max_nbng <= 31 ? 64u : 128u));
+    // Internal numbering (one device): a uniform random relabelling of the nodes.  The mode reads RUNS of consecutive rows (the windows
+    // of the tile of negatives); with the caller's labels a run is whatever the caller put side by side -- a graph stored component by
+    // component gave every window to one cluster, and the result moved by 1.5-2.5 % in CE (lower quartile of the edge lengths -9 ...
+    // +12 %, eight seeds a side, 1 M Higgs-shaped points) where the same graph with shuffled labels matched the exact mode.  With the
+    // relabelling the two are the same run.  The coordinates move to the internal order at the start of a batch and back at its
+    // end (two row moves: ~1 % of a batch); everything between the two -- records, events, pending lists -- speaks internal numbers.
+    // A sharded range keeps the caller's labels: its ranks own label ranges and exchange rows in place.
+    o->sl_perm.release();
+    if (o->dev.node_lo == 0 && o->dev.node_hi == g->n && !debug_knob("AE_SL_LABEL_ORDER")) {
+        DevBuf<uint32_t> keys, keys_out, ident, order;
+        keys.alloc_pooled(g->n); keys_out.alloc_pooled(g->n); ident.alloc_pooled(g->n); order.alloc_pooled(g->n);
+        hipLaunchKernelGGL(sl_perm_keys_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n,
+                           pcg_hash((uint32_t)o->dev.seed ^ 0x51ED270Bu), keys.p, ident.p);
+        sort_pairs_u32_u32(keys.p, keys_out.p, ident.p, order.p, g->n, 32);
+        o->sl_perm.alloc(g->n);
+        hipLaunchKernelGGL(sl_perm_invert_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)order.p, o->sl_perm.p);
+        if (o->dev.hub_odds) {
+            o->sl_hub_tab.alloc(g->n);
+            hipLaunchKernelGGL(sl_hub_tab_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)o->sl_perm.p,
+                               o->dev.hub_tab, o->sl_hub_tab.p);
+        }
+        check_launch("sl_perm");
+        sync();
+    }
     o->sl_srec.alloc(g->n * o->sl_srec_floats);
-    hipLaunchKernelGGL(sl_static_rec_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), o->dev, o->sl_srec_floats, o->sl_srec.p);
+    hipLaunchKernelGGL(sl_static_rec_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), o->dev, o->sl_srec_floats,
+                       (const uint32_t*)(o->sl_perm.n ? o->sl_perm.p : nullptr), o->sl_srec.p);
     check_launch("sl_prepare");
     // largest edge probability (segments keep the per-edge Poisson mean below 64)
     std::vector<float> hp = o->np->proba.to_host();
@@ -668,6 +740,18 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     o->sl_done.zero();
     o->sl_chunk_flag.release();
     if (!o->sample_counter.n) { o->sample_counter.alloc(1024); o->sample_counter.zero(); }
+}
+
+// events a step can hold with ALL its workgroups resident at once (the step kernel's occupancy x CUs x 256, less 3 %: the classes'
+// sizes and the Poisson totals scatter)
+static double sl_resident_events(ae_entropy_optim* o) {
+    int dev = 0, bpc = 1;
+    hipDeviceProp_t prop;
+    AE_HIP(hipGetDevice(&dev));
+    AE_HIP(hipGetDeviceProperties(&prop, dev));
+    const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
+    AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
+    return 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;
 }
 
 void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
@@ -701,13 +785,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // workgroups end -- a second chain (measured: 250 k events on 768 resident workgroups of 256: 59 us).  So the slices are made as
     // thin as it takes for a step to fit the device (never thicker than lambda: thinner slices are the more faithful ones).
     if (o->sl_classes && !debug_knob("AE_SL_NO_FIT")) {
-        int dev = 0, bpc = 1;
-        hipDeviceProp_t prop;
-        AE_HIP(hipGetDevice(&dev));
-        AE_HIP(hipGetDeviceProperties(&prop, dev));
-        const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (uint64_t)n * o->dev.dim * 4ull > (4ull << 20);
-        AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
-        const double resident = 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;   // (3 %: the classes' sizes and the Poisson totals scatter)
+        const double resident = sl_resident_events(o);
         const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
         if (per_step > resident && per_step < 4.0 * resident)
             n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
@@ -773,8 +851,18 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) o->sl_class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
     unsigned kbits = 1;
     while (kbits < 32 && (n_keys >> kbits)) kbits++;
+    // internal numbering (ce_slice_prepare): the batch runs on a relabelled copy of the coordinates
+    CeDev cdev = o->dev;
+    const bool relabelled = o->sl_perm.n != 0;
+    if (relabelled) {
+        if (o->sl_y.n < n * o->dev.dim) o->sl_y.alloc(n * o->dev.dim);
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(blocks_for(n * o->dev.dim, 256)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
+                           (const uint32_t*)o->sl_perm.p, (const float*)o->dev.y, o->sl_y.p, 1);
+        cdev.y = o->sl_y.p;
+        if (o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
+    }
     SliceArgs a;
-    a.c = o->dev;
+    a.c = cdev;
     a.srec = o->sl_srec.p;
     a.owner = o->sl_owner.p;
     a.lists = reinterpret_cast<Pending*>(o->sl_lists.p);
@@ -787,7 +875,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     a.step = grad_step;
     a.done_counter = o->sl_done.p;
     DirectArgs da;
-    da.c = o->dev;
+    da.c = cdev;
     da.srec = o->sl_srec.p;
     da.step = grad_step;
     da.dbg = debug_knob("AE_SL_DBG") ? atoi(debug_knob("AE_SL_DBG")) : 0;
@@ -801,7 +889,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->dev.hub_odds) {   // fresh every batch
         const uint32_t pool_n = n >= (1ull << 20) ? (1u << 24) : (1u << 20);
         if (o->sl_hub_pool.n < pool_n) o->sl_hub_pool.alloc(pool_n);
-        hipLaunchKernelGGL(sl_hub_pool_kernel, dim3(blocks_for(pool_n, 256)), dim3(256), 0, stream(), o->dev, (uint32_t)(iter << 12), pool_n, o->sl_hub_pool.p);
+        hipLaunchKernelGGL(sl_hub_pool_kernel, dim3(blocks_for(pool_n, 256)), dim3(256), 0, stream(), cdev, (uint32_t)(iter << 12), pool_n, o->sl_hub_pool.p);
         a.hub_pool = da.hub_pool = o->sl_hub_pool.p;
         a.hub_pool_n = da.hub_pool_n = pool_n;
     }
@@ -1024,6 +1112,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (exchanges) { ce_comm_exchange(o); o->comm_bytes += o->dev.n * o->dev.dim * sizeof(float); }   // (after the drain: the segment's last exchange)
         t_drain += wall() - t_enq;
     }
+    if (relabelled)   // back to the caller's labels
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(blocks_for(n * o->dev.dim, 256)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
+                           (const uint32_t*)o->sl_perm.p, (const float*)o->sl_y.p, o->dev.y, 0);
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");

@@ -74,6 +74,7 @@ for name, (mode, knobs) in cases.items():
         rows.append(np.concatenate([[ce], edge_q(y)]))
     res[name] = np.array(rows)
     ref = res["sequential"].mean(axis=0)
+    print("%-32s (mean CE %.5e)" % (name, res[name][:, 0].mean()))
     print("%-32s CE %.4f +- %.4f   quantiles %s +- %s   (ratios to the sequential mean over %d seeds)" % (
         name, (res[name][:, 0] / ref[0]).mean(), (res[name][:, 0] / ref[0]).std(), np.round((res[name][:, 1:] / ref[1:]).mean(axis=0), 3),
         np.round((res[name][:, 1:] / ref[1:]).std(axis=0), 3), len(seeds)), flush=True)
