@@ -231,13 +231,15 @@ def mixture_points_gpu(n, dim, ncomp, seed, mean_sigma, higgs_like=False):
     return xh, bounds
 
 
-def component_knn_graph(A, x, bounds, k, permute_seed):
+def component_knn_graph(A, x, bounds, k, permute_seed, shuffle_within=None):
     """Exact kNN graph INSIDE every mixture component (the blocks of rows `bounds`), one brute-force pass on the matrix cores per
     component.  SURVEY 8d prescribes this for configs[4] (1 000 well separated components: it equals the global kNN graph w.h.p.; the
     separation is checked below where it holds by construction); for the Higgs-shaped points, whose components overlap, it is the kNN
     graph restricted to the component -- as approximate as the reference's own HNSW graph, with the in-degree skew (hubs) of the data.
     permute_seed: node ids are randomly permuted afterwards (positive edges not memory-local, as for a graph in arbitrary order); None
-    keeps the component order (what a component partition over GPUs wants).  -> indptr, nbr, dist (host CSR)"""
+    keeps the component order (what a component partition over GPUs wants); shuffle_within = [(lo, hi), ...] then shuffles the ids
+    INSIDE each of these ranges (a partitioner hands every rank its components, in no particular order inside the part).
+    -> indptr, nbr, dist (host CSR)"""
     n = len(x)
     nbr = np.empty((n, k), np.uint32)
     dist = np.empty((n, k), np.float32)
@@ -250,6 +252,15 @@ def component_knn_graph(A, x, bounds, k, permute_seed):
         nbr[b:e] = nb.reshape(e - b, k) + np.uint32(b)
         dist[b:e] = ds.reshape(e - b, k)
         del g
+    if permute_seed is None and shuffle_within:
+        rng = np.random.default_rng(17)
+        perm = np.arange(n, dtype=np.uint32)
+        for lo, hi in shuffle_within:
+            perm[lo:hi] = lo + rng.permutation(hi - lo).astype(np.uint32)
+        inv = np.empty(n, np.int64)
+        inv[perm] = np.arange(n)
+        nbr = perm[nbr][inv]
+        dist = dist[inv]
     if permute_seed is not None:
         perm = np.random.default_rng(permute_seed).permutation(n).astype(np.uint32)  # old id -> new id
         inv = np.empty(n, np.int64)
@@ -363,7 +374,7 @@ def exact_knn_graph(A, x, k, what):
     return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": dt, "desc": "exact kNN graph (k = %d) of %d %s; built in %.1f s" % (k, len(x), what, dt)}
 
 
-def config_graphs(A, which, permute_seed=9, n_override=None):
+def config_graphs(A, which, permute_seed=9, n_override=None, shuffle_within_shards=0):
     """the configs' own kind of graph for the scale shapes (SURVEY 8d generators; exact kNN inside every mixture component, node ids
     randomly permuted): 'c4' = configs[3] (11 M Higgs-shaped points, k 6), 'c5' = one GPU's eighth of configs[4] (6.25 M points of the
     128-D mixture: 125 of its 1 000 components of 50 000 points, k 10)."""
@@ -380,12 +391,18 @@ def config_graphs(A, which, permute_seed=9, n_override=None):
         x, bounds = mixture_points_gpu(n, dim, ncomp, seed=4, mean_sigma=10.0)
         what = "points of the 128-D mixture (%d of configs[4]'s 1 000 components of 50 000 points: means N(0, 10^2), sigma 1; SURVEY 8d, seed 4)" % ncomp
     t1 = time.perf_counter()
-    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed)
+    within = None
+    if shuffle_within_shards:
+        from annembed_amd.dist import shard_range
+        within = [shard_range(n, shuffle_within_shards, r) for r in range(shuffle_within_shards)]
+    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed, shuffle_within=within)
     del x
     t2 = time.perf_counter()
     return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0, "k": k, "n": n,
             "desc": "kNN graph (k = %d) of %d %s, exact inside every component, node ids %s; points %.1f s, graph %.1f s" % (
-                k, n, what, "randomly permuted" if permute_seed is not None else "in component order", t1 - t0, t2 - t1)}
+                k, n, what, "randomly permuted" if permute_seed is not None else
+                ("in component order, shuffled inside each of %d contiguous shards" % shuffle_within_shards if shuffle_within_shards else "in component order"),
+                t1 - t0, t2 - t1)}
 
 
 def main():
@@ -675,7 +692,9 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
         # configs[3] on its own kind of graph, FAITHFUL: the kNN graph of the Higgs-shaped points in COMPONENT order (a locality order: the
         # contiguous node ranges of the ranks cut a few of the 64 components, nothing else crosses shards), hubness-weighted negatives
         d = 8
-        gr = config_graphs(A, "c4", permute_seed=None, n_override=args.scale_nodes)
+        # (inside a rank's range the ids are shuffled: the time-sliced mode on a sharded range works in the caller's labels, and a tile
+        # window of consecutive ids should not be one component -- DESIGN 4.3, "internal numbering")
+        gr = config_graphs(A, "c4", permute_seed=None, n_override=args.scale_nodes, shuffle_within_shards=world)
         n, k, indptr, nbr, dst = gr["n"], gr["k"], gr["indptr"], gr["nbr"], gr["dist"]
         lo, hi = shard_range(n, world, rank)
         chk = torch.tensor([float(nbr[::1009].astype(np.float64).sum())], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
