@@ -62,6 +62,8 @@ cases = {"sequential": (A.AE_CE_SEQUENTIAL, {}), "sliced, no tile": (A.AE_CE_SLI
          "lambda 1": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1"}),
          "lambda 1 every repeat moved": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1", "AE_SL_SPREAD_ALL": "1"}),
          "lambda 1 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1", "AE_SL_NO_SPREAD": "1"}),
+         "thick 0.75": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1", "AE_SL_LAMBDA": "0.75"}),
+         "thick 1.0": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1", "AE_SL_LAMBDA": "1.0"}),
          "sliced classes, tile forced": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1"})}
 only = os.environ.get("CASES")
 res = {}
