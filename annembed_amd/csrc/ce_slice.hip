@@ -790,6 +790,19 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (per_step > resident && per_step < 4.0 * resident)
             n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
     }
+    // A rank of a sharded run holds a fraction of every step, and a step costs ~25-30 us however few events it has (one chain of memory
+    // round trips): configs[3] over 8 ranks ran 2 640 steps of 31 k events -- 81 ms per batch and rank where one device takes 160 for
+    // the whole graph.  Under-filled steps of a sharded range get thicker slices, up to lambda = 1 (half the steps; with the repeat rule
+    // of sl_fill_kernel the statistics stay within ~1 % of lambda = 1/2's on one device: DESIGN 4.3): 81 -> 52 ms.  Every rank computes
+    // the same count (whole-graph totals and the world size only).
+    if (sharded && o->sl_classes && !debug_knob("AE_SL_LAMBDA") && !debug_knob("AE_SL_NO_THICK")) {
+        const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
+        const double resident = sl_resident_events(o);   // (a step up to what the device holds at once: 125 k events cost what 190 k do)
+        if (per_step < resident) {
+            const double lam = std::min(1.0, lambda_s * resident / per_step);
+            n_slices = (uint32_t)std::max(1.0, std::ceil(2.0 * seg_samples / (double)n / lam));
+        }
+    }
     // passes per slice of the overflow class: a thin one (a few per cent of the events: conflicts among them are rare) runs once and
     // carries its losers into the next slice
     int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
@@ -868,7 +881,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     a.lists = reinterpret_cast<Pending*>(o->sl_lists.p);
     const bool use_tile = !debug_knob("AE_SL_NO_TILE");
     // the LDS tile pays when a negative's row would come from beyond the L2s and the step has enough events to fill the chip anyway
-    const uint64_t tile_min_events = debug_knob("AE_SL_TILE_MIN") ? (uint64_t)atoll(debug_knob("AE_SL_TILE_MIN")) : 65536ull;
+    // (16 384: a quarter of the chip's workgroup slots; measured on configs[3]'s shards: 62 k events per step 107 -> 85 ms per batch
+    // with the tile, 31 k: 81 -> 73)
+    const uint64_t tile_min_events = debug_knob("AE_SL_TILE_MIN") ? (uint64_t)atoll(debug_knob("AE_SL_TILE_MIN")) : 16384ull;
     const bool y_in_cache = (uint64_t)n * o->dev.dim * 4ull <= (4ull << 20) && !debug_knob("AE_SL_TILE_ALWAYS");
     a.counts = o->sl_counts.p;
     a.cap = cap;
