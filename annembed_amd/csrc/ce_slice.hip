@@ -395,12 +395,12 @@ __global__ void __launch_bounds__(256) sl_perm_invert_kernel(uint64_t n, const u
 // rows of `dim` floats: to_internal: dst[perm[v]] = src[v]; else dst[v] = src[perm[v]]
 __global__ void __launch_bounds__(256) sl_move_rows_kernel(uint64_t n, uint32_t dim, const uint32_t* __restrict__ perm, const float* __restrict__ src,
                                                            float* __restrict__ dst, int to_internal) {
-    const uint64_t t = blockIdx.x * 256ull + threadIdx.x;
-    const uint64_t v = t / dim, q = t % dim;
-    if (v >= n) return;
-    const uint64_t p = perm[v];
-    if (to_internal) dst[p * dim + q] = src[v * dim + q];
-    else dst[v * dim + q] = src[p * dim + q];
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < n * dim; t += (uint64_t)gridDim.x * 256ull) {   // (n x dim may pass 2^32)
+        const uint64_t v = t / dim, q = t % dim;
+        const uint64_t p = perm[v];
+        if (to_internal) dst[p * dim + q] = src[v * dim + q];
+        else dst[v * dim + q] = src[p * dim + q];
+    }
 }
 __global__ void __launch_bounds__(256) sl_hub_tab_kernel(uint64_t n, const uint32_t* __restrict__ perm, const uint2* __restrict__ tab, uint2* __restrict__ out) {
     const uint64_t v = blockIdx.x * 256ull + threadIdx.x;
@@ -869,7 +869,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const bool relabelled = o->sl_perm.n != 0;
     if (relabelled) {
         if (o->sl_y.n < n * o->dev.dim) o->sl_y.alloc(n * o->dev.dim);
-        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(blocks_for(n * o->dev.dim, 256)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap(n * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
                            (const uint32_t*)o->sl_perm.p, (const float*)o->dev.y, o->sl_y.p, 1);
         cdev.y = o->sl_y.p;
         if (o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
@@ -1128,7 +1128,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         t_drain += wall() - t_enq;
     }
     if (relabelled)   // back to the caller's labels
-        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(blocks_for(n * o->dev.dim, 256)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap(n * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
                            (const uint32_t*)o->sl_perm.p, (const float*)o->sl_y.p, o->dev.y, 0);
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
