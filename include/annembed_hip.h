@@ -126,20 +126,27 @@ enum {
        in-degree); both statistically faithful (as the reference's own threaded loop is
        not reproducible sample by sample either) -- the bit-exact replay of the reference's sequential loop is AE_CE_SEQUENTIAL,
        by name.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
-       column adds +0 to every distance and never moves).  A sharded node range (several GPUs) has no faithful schedule:
-       AE_CE_AUTO refuses it with AE_ERR_INVALID_ARG -- ask for AE_CE_HOGWILD by name.  ae_entropy_optim_get_ce_mode reports
-       the choice. */
+       column adds +0 to every distance and never moves).  A sharded node range (several GPUs) runs AE_CE_SLICED whatever the
+       batch size (see there; refused with AE_ERR_INVALID_ARG when more than 10 % of the range's edge mass crosses shards: the
+       approximate AE_CE_HOGWILD still shards, by name).  ae_entropy_optim_get_ce_mode reports the choice. */
     AE_CE_AUTO = 4,
     /* Time-sliced execution on conflict-free classes (ce_slice.hip): the batch's events (the same edge-keyed Poisson process
        as AE_CE_EVENT) are cut into thin time slices; the graph's edges are coloured once so that every class is a forest of in-stars
-       (no node is the source of two edges of a class, none source of one and target of another; max row length + 5 classes whatever
-       the in-degrees), and a step = the events of one class in one slice is one launch: every lane applies its sample exactly as
+       (no node is the source of two edges of a class, none source of one and target of another; max row length + 5 ... + 9 classes
+       whatever the in-degrees), and a step = the events of one class in one slice is one launch: every lane applies its sample exactly as
        src/embedder.rs:1207-1301 (both rows, one gradient); the events of a step that share their target run as a chain through the
        target's row (the reference: the row's lock); class order drawn afresh per slice.  The few edges without a colour and, on
        graphs of a few million edges, all of them run optimistically instead: an event that holds both its rows exclusively runs,
        the others are deferred to the next pass.  Scalar arithmetic as `ce_precision` says (default:
-       the reference's f64 scalars).  Statistical
-       parity like AE_CE_EVENT, throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes, one device. */
+       the reference's f64 scalars).  Negatives: uniform / NodeSampler draws; in crowded steps the samples of a workgroup take them
+       from a shared tile of rows, never two from the same run of consecutive rows.  On one device the nodes are relabelled at
+       random internally: the result does not depend on the caller's numbering (a sharded range works in the caller's labels).
+       Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
+       parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
+       standard error), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
+       sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
+       the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
+       exchange. */
     AE_CE_SLICED = 5,
     /* The samples of AE_CE_SEQUENTIAL (same Philox plan, same order, same f64 arithmetic) with only their two END POINTS as
        dependencies: every attraction is applied to the rows the previous writers of i and j produced, exactly as the sequential
@@ -369,7 +376,8 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * shard: the time-sliced mode (AE_CE_SLICED; what AE_CE_AUTO resolves to on a sharded range) runs a shard's own events on current rows
  * and reads the other shards' rows -- negatives, the far ends of cross-shard edges, which fire as two half events -- as of the last
  * exchange: faithful for node orders with few cross-shard edges (connected components / locality; more than 10 % of a shard's edge mass
- * on cross-shard edges is refused with AE_ERR_INVALID_ARG) and with enough exchanges per batch (measured: DESIGN 5); the rounds mode
+ * on cross-shard edges is refused with AE_ERR_INVALID_ARG); ONE exchange per batch is enough (measured with 1 ... 240: DESIGN 5); a
+ * sharded range makes its time slices as thick as it takes to fill the device (up to one event per node and slice); the rounds mode
  * (AE_CE_HOGWILD, by name) is approximate whatever the partition.  The final cross entropy is the sum of the
  * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
 typedef struct ae_comm ae_comm;
