@@ -7,20 +7,24 @@ nb_sampling_by_edge * nnz SGD samples), plus the SVD-init GFLOP/s of the diffusi
 Workload at N=1: configs[1] "MNIST-fashion 60k x 784 -> 2D, k=12, dmap init + CE loop, fp32"
 (parameters of examples/mnist_fashion.rs:92-110).  The real dataset is absent (no network): a
 synthetic Gaussian mixture of the same shape stands in and the exact kNN graph is built
-on the GPU before the timed region.  The headline `value` is the DEFAULT CE mode (AE_CE_AUTO -> the
-sequential-equivalent dataflow: the reference's loop sample for sample, f64 scalars, bit-exact against the
-oracle), i.e. the mode that reproduces the reference; the same line carries
-  * "event_mode" (AE_CE_EVENT: sequentially consistent attraction steps in an i.i.d. order, statistical parity) and
-    "rounds_mode" (AE_CE_HOGWILD: a throughput mode OUTSIDE the reference's envelope), same graph and start;
-  * "fidelity": final CE and edge-length quartiles of those two modes (and of a second sequential seed: the
-    reference's own spread) after the full 25-batch schedule, as ratios to the sequential mode;
-  * "scale_shapes": the configs[2] / configs[3] shapes (1.65 M x k6 -> 2-D, 11 M x k6 -> 8-D) on a ring-lattice
-    graph whose node ids are randomly permuted, so that positive edges are not memory-local.
+on the GPU before the timed region.  The headline `value` is the DEFAULT CE mode (AE_CE_AUTO -> at this size the ordered
+dataflow AE_CE_ORDERED: the reference's sample sequence and f64 scalars with only a sample's two end points as dependencies:
+statistical parity); the same line carries
+  * "parity_mode": AE_CE_SEQUENTIAL, bit-exact against the oracle (the figure at the north star's coordinate tolerance);
+  * "event_mode" (AE_CE_EVENT) and "rounds_mode" (AE_CE_HOGWILD: a throughput mode OUTSIDE the reference's envelope), same graph
+    and start;
+  * "fidelity": final CE and edge-length quartiles of the modes (and of a second sequential seed: the reference's own spread)
+    after the full 25-batch schedule, as ratios to the sequential mode;
+  * "scale_shapes": configs[2] / configs[3] / one GPU's eighth of configs[4] on the configs' own kind of graph (exact kNN inside
+    the components of a Higgs-shaped / 128-D mixture: real in-degree skew) and on a node-permuted ring lattice (the best case),
+    every mode timed, plus "c5_full_shape": configs[4] WHOLE (50 M nodes, 5 G samples per batch) in the default mode
+    (--no-full-size skips it: about a minute, mostly the graph).
 
-N>1 (default): STRONG scaling of the configs[3] shape -- a fixed 11 M-node graph, its source nodes sharded
-over the ranks, the coordinate rows all-gathered by the library's own RCCL communicator inside
-ae_entropy_optim_gradient_iteration (`--exchanges` times per batch).  Only the rounds mode shards.
-`--weak` keeps the round-1 arrangement (60 k MNIST-shaped points per GPU).
+N>1 (default): strong scaling of configs[3] on its own graph -- the source nodes of the 11 M-node kNN graph (component order, ids
+shuffled inside every rank's range) sharded over the ranks in contiguous ranges, AE_CE_AUTO = the faithful time-sliced mode on a
+sharded range, the owned coordinate rows all-gathered by the library's RCCL communicator inside
+ae_entropy_optim_gradient_iteration (`--exchanges` times per batch; torch's RCCL as the fallback).  `--rounds`: the approximate
+rounds mode on the lattice (round 2-3's series); `--weak`: 60 k MNIST-shaped points per GPU.
 
 A "step" = one CE batch.  The timed region holds only `ae_entropy_optim_gradient_iteration` calls
 (the collective is inside them when N>1) with every input already resident in HBM.
