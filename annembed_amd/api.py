@@ -594,7 +594,7 @@ class Embedder(_Handle):
         check(L.load().ae_embedder_new(kgraph.handle, C.byref(parameters.c()), C.byref(h)))
         super().__init__(h)
 
-    def set_comm(self, comm, exchanges_per_batch=1):
+    def set_comm(self, comm, exchanges_per_batch=4):
         """multi-GPU embedding: this process is one rank of `comm` (annembed_amd.dist.LibraryComm / HostMemComm); embed() then
         shards the CE loop over the ranks (ae_embedder_set_comm).  parameters.ce_mode must be AE_CE_HOGWILD."""
         self._comm = comm  # keep the communicator alive

@@ -749,7 +749,8 @@ static double sl_resident_events(ae_entropy_optim* o) {
     hipDeviceProp_t prop;
     AE_HIP(hipGetDevice(&dev));
     AE_HIP(hipGetDeviceProperties(&prop, dev));
-    const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
+    const bool sharded_range = o->dev.node_lo != 0 || o->dev.node_hi != o->dev.n;
+    const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (!sharded_range || debug_knob("AE_SL_SHARD_TILE")) && (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
     AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
     return 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;
 }
@@ -791,11 +792,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
     }
     // A rank of a sharded run holds a fraction of every step, and a step costs ~25-30 us however few events it has (one chain of memory
-    // round trips): configs[3] over 8 ranks ran 2 640 steps of 31 k events -- 81 ms per batch and rank where one device takes 160 for
-    // the whole graph.  Under-filled steps of a sharded range get thicker slices, up to lambda = 1 (half the steps; with the repeat rule
-    // of sl_fill_kernel the statistics stay within ~1 % of lambda = 1/2's on one device: DESIGN 4.3): 81 -> 52 ms.  Every rank computes
-    // the same count (whole-graph totals and the world size only).
-    if (sharded && o->sl_classes && !debug_knob("AE_SL_LAMBDA") && !debug_knob("AE_SL_NO_THICK")) {
+    // round trips): configs[3] over 8 ranks runs 2 640 steps of 31 k events -- 81 ms per batch and rank where one device takes 160 for
+    // the whole graph.  Thicker slices on a rank's under-filled steps (up to lambda = 1: half the steps, 81 -> 52 ms) were built and
+    // measured and are NOT the default: on one device lambda = 1 stays within ~1 % of lambda = 1/2, but an 11 M-node
+    // 64-component graph in 4 and 8 shards came out with its edges 10-15 % short (CE +2 %), where lambda = 1/2 in 2 shards matched
+    // the exact mode to 0.5 %.  Kept behind a knob for A/B.
+    if (sharded && o->sl_classes && !debug_knob("AE_SL_LAMBDA") && debug_knob("AE_SL_THICK")) {   // (A/B only: see above)
         const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
         const double resident = sl_resident_events(o);   // (a step up to what the device holds at once: 125 k events cost what 190 k do)
         if (per_step < resident) {
@@ -879,7 +881,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     a.srec = o->sl_srec.p;
     a.owner = o->sl_owner.p;
     a.lists = reinterpret_cast<Pending*>(o->sl_lists.p);
-    const bool use_tile = !debug_knob("AE_SL_NO_TILE");
+    // The tile's windows are runs of consecutive rows: harmless under the internal numbering of one device, but a sharded range works
+    // in the caller's labels, and with labels that carry locality (a graph stored component by component) the tile moved the result
+    // of an 11 M-node run in 2 shards by -3 % in CE and +18 % in the edge lengths (gathered negatives: -0.3 % / +1.5 %).  No tile there.
+    const bool use_tile = !debug_knob("AE_SL_NO_TILE") && (!sharded || debug_knob("AE_SL_SHARD_TILE"));
     // the LDS tile pays when a negative's row would come from beyond the L2s and the step has enough events to fill the chip anyway
     // (16 384: a quarter of the chip's workgroup slots; measured on configs[3]'s shards: 62 k events per step 107 -> 85 ms per batch
     // with the tile, 31 k: 81 -> 73)

@@ -171,7 +171,7 @@ class LibraryComm:
         L.check(L.load().ae_comm_init(rank, world, ident, ctypes.byref(h)))
         self._h = h
 
-    def attach(self, entropy_optim, exchanges_per_batch=1):
+    def attach(self, entropy_optim, exchanges_per_batch=4):
         self._L.check(self._L.load().ae_entropy_optim_set_comm(entropy_optim._h, self._h, exchanges_per_batch))
 
     def attach_none(self, entropy_optim):

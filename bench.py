@@ -431,8 +431,9 @@ def main():
                     "faithful time-sliced mode on the component-ordered kNN graph of the Higgs-shaped points")
     ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling on 60 k MNIST-shaped points per GPU (round-1 arrangement) instead of the strong-scaling configs[3] shape")
     ap.add_argument("--scale-nodes", type=int, default=11_000_000, help="N > 1 strong scaling: nodes of the fixed graph (k = 6, asked_dim 8)")
-    ap.add_argument("--exchanges", type=int, default=1, help="N > 1: all-gathers of the owned rows per CE batch (1 = the north star's once per batch; more often "
-                    "costs ~1 ms per exchange at the C4 size and does not buy fidelity: DESIGN 5)")
+    ap.add_argument("--exchanges", type=int, default=4, help="N > 1: all-gathers of the owned rows per CE batch.  4: on an 11 M-node graph in 8 shards one exchange per "
+                    "batch left the edges 12-21 %% short (the other shards' rows a whole batch old during the violent first batches), 4 or 16 "
+                    "matched the one-device run (DESIGN 5); ~1.5 ms per exchange at the C4 size")
     ap.add_argument("--force-dist", action="store_true", help="exercise the communicator path with world size 1 (validation)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend used for rendezvous, barriers and timing reductions (gloo: validation runs with several "

@@ -376,8 +376,11 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * shard: the time-sliced mode (AE_CE_SLICED; what AE_CE_AUTO resolves to on a sharded range) runs a shard's own events on current rows
  * and reads the other shards' rows -- negatives, the far ends of cross-shard edges, which fire as two half events -- as of the last
  * exchange: faithful for node orders with few cross-shard edges (connected components / locality; more than 10 % of a shard's edge mass
- * on cross-shard edges is refused with AE_ERR_INVALID_ARG); ONE exchange per batch is enough (measured with 1 ... 240: DESIGN 5); a
- * sharded range makes its time slices as thick as it takes to fill the device (up to one event per node and slice); the rounds mode
+ * on cross-shard edges is refused with AE_ERR_INVALID_ARG).  Exchanges per batch: on graphs of up to ~10^5 nodes one is enough
+ * (1 ... 240 measured: no trend); at 10^6 ... 10^7 nodes in 8 shards, from a random start, one exchange per batch leaves the edges
+ * 6 ... 21 % short (the other shards' rows are a whole batch old while the layout still moves fast), 4 match the one-device run:
+ * ask for 4 or more.  A sharded range gathers its negatives row by row (no shared tile: it works in the caller's
+ * labels); the rounds mode
  * (AE_CE_HOGWILD, by name) is approximate whatever the partition.  The final cross entropy is the sum of the
  * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
 typedef struct ae_comm ae_comm;

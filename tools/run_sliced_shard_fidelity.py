@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 which = sys.argv[1] if len(sys.argv) > 1 else "comp"
-worlds = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,8").split(",")]
+worlds = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,8").split(",") if v != "none"]   # ("none": the one-device runs only)
 exch = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1,4,16,64,240").split(",")]
 n_arg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 sys.argv = ["bench.py"]
