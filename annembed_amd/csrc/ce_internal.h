@@ -146,6 +146,7 @@ struct ae_entropy_optim {
     // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch
     ae_comm* comm = nullptr;
     std::vector<uint64_t> comm_ranges;
+    float* comm_y = nullptr;                    // the array the in-batch exchanges act on, if not y (the time-sliced mode's internal copy)
     bool comm_equal = false;
     uint32_t comm_exchanges = 1;
     uint64_t comm_bytes = 0;                    // bytes of coordinate rows received through exchanges since the handle was created (per rank: n x stride x 4 each)

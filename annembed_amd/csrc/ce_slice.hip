@@ -388,6 +388,16 @@ __global__ void __launch_bounds__(256) sl_perm_keys_kernel(uint64_t n, uint32_t 
     const uint64_t v = blockIdx.x * 256ull + threadIdx.x;
     if (v < n) { keys[v] = pcg_hash((uint32_t)v ^ seed); ident[v] = (uint32_t)v; }
 }
+// the rank whose range holds node order[x] (ranges: lo_0, hi_0, lo_1, ... tiling [0, n) in order)
+__global__ void __launch_bounds__(256) sl_perm_block_kernel(uint64_t n, const uint32_t* __restrict__ order, const uint64_t* __restrict__ ranges, uint32_t world,
+                                                            uint32_t* __restrict__ block) {
+    const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
+    if (x >= n) return;
+    const uint64_t v = order[x];
+    uint32_t q = 0;
+    while (q + 1u < world && v >= ranges[2u * q + 1u]) q++;
+    block[x] = q;
+}
 __global__ void __launch_bounds__(256) sl_perm_invert_kernel(uint64_t n, const uint32_t* __restrict__ order, uint32_t* __restrict__ perm) {
     const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
     if (x < n) perm[order[x]] = (uint32_t)x;
@@ -700,12 +710,29 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     // end (two row moves: ~1 % of a batch); everything between the two -- records, events, pending lists -- speaks internal numbers.
     // A sharded range keeps the caller's labels: its ranks own label ranges and exchange rows in place.
     o->sl_perm.release();
-    if (o->dev.node_lo == 0 && o->dev.node_hi == g->n && !debug_knob("AE_SL_LABEL_ORDER")) {
+    const bool whole_range = o->dev.node_lo == 0 && o->dev.node_hi == g->n;
+    // (a sharded range: once the communicator is attached and every rank's range is known -- entropy_optim_attach_comm prepares again --
+    // the same relabelling on every rank, inside every rank's range: a rank's rows stay one contiguous run, the exchanges stay in place)
+    const bool ranges_known = !whole_range && o->comm && o->comm_ranges.size() >= 4;
+    if ((whole_range || ranges_known) && !debug_knob("AE_SL_LABEL_ORDER")) {
         DevBuf<uint32_t> keys, keys_out, ident, order;
         keys.alloc_pooled(g->n); keys_out.alloc_pooled(g->n); ident.alloc_pooled(g->n); order.alloc_pooled(g->n);
         hipLaunchKernelGGL(sl_perm_keys_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n,
                            pcg_hash((uint32_t)o->dev.seed ^ 0x51ED270Bu), keys.p, ident.p);
         sort_pairs_u32_u32(keys.p, keys_out.p, ident.p, order.p, g->n, 32);
+        if (ranges_known) {   // stable sort by owner: the random order survives inside every range
+            const uint32_t world = (uint32_t)(o->comm_ranges.size() / 2);
+            DevBuf<uint64_t> d_ranges;
+            d_ranges.alloc_pooled(o->comm_ranges.size());
+            d_ranges.upload(o->comm_ranges.data(), o->comm_ranges.size());
+            hipLaunchKernelGGL(sl_perm_block_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)order.p,
+                               (const uint64_t*)d_ranges.p, world, keys.p);
+            unsigned bits = 1;
+            while ((1u << bits) < world) bits++;
+            sort_pairs_u32_u32(keys.p, keys_out.p, order.p, ident.p, g->n, bits);
+            sync();   // (d_ranges is read by the kernel above)
+            std::swap(order.p, ident.p);
+        }
         o->sl_perm.alloc(g->n);
         hipLaunchKernelGGL(sl_perm_invert_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)order.p, o->sl_perm.p);
         if (o->dev.hub_odds) {
@@ -750,7 +777,8 @@ static double sl_resident_events(ae_entropy_optim* o) {
     AE_HIP(hipGetDevice(&dev));
     AE_HIP(hipGetDeviceProperties(&prop, dev));
     const bool sharded_range = o->dev.node_lo != 0 || o->dev.node_hi != o->dev.n;
-    const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (!sharded_range || debug_knob("AE_SL_SHARD_TILE")) && (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
+    const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (!sharded_range || o->sl_perm.n != 0 || debug_knob("AE_SL_SHARD_TILE")) &&
+                          (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
     AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
     return 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;
 }
@@ -876,6 +904,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         cdev.y = o->sl_y.p;
         if (o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
     }
+    // (a sharded range: the in-batch exchanges act on the internal copy -- a rank's rows are the same contiguous run in both numberings)
+    struct CommY {
+        ae_entropy_optim* o;
+        CommY(ae_entropy_optim* oo, float* y) : o(oo) { o->comm_y = y; }
+        ~CommY() { o->comm_y = nullptr; }
+    } comm_y_scope(o, relabelled ? o->sl_y.p : nullptr);
     SliceArgs a;
     a.c = cdev;
     a.srec = o->sl_srec.p;
@@ -884,7 +918,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // The tile's windows are runs of consecutive rows: harmless under the internal numbering of one device, but a sharded range works
     // in the caller's labels, and with labels that carry locality (a graph stored component by component) the tile moved the result
     // of an 11 M-node run in 2 shards by -3 % in CE and +18 % in the edge lengths (gathered negatives: -0.3 % / +1.5 %).  No tile there.
-    const bool use_tile = !debug_knob("AE_SL_NO_TILE") && (!sharded || debug_knob("AE_SL_SHARD_TILE"));
+    // (... unless the range is relabelled: a communicator is attached and every rank's range known, ce_slice_prepare)
+    const bool use_tile = !debug_knob("AE_SL_NO_TILE") && (!sharded || o->sl_perm.n != 0 || debug_knob("AE_SL_SHARD_TILE"));
     // the LDS tile pays when a negative's row would come from beyond the L2s and the step has enough events to fill the chip anyway
     // (16 384: a quarter of the chip's workgroup slots; measured on configs[3]'s shards: 62 k events per step 107 -> 85 ms per batch
     // with the tile, 31 k: 81 -> 73)

@@ -178,17 +178,18 @@ void ce_comm_exchange(ae_entropy_optim* o) {
     ae_comm* c = o->comm;
     if (!comm_active(c)) return;
     const uint64_t dim = o->dev.dim;
+    float* const yb = o->comm_y ? o->comm_y : o->y.p;   // (rows in the caller's labels, or the time-sliced mode's internal copy: the same ranges)
     if (c->host) {
         HostMem& h = *c->host;
         if (o->dev.n * dim * sizeof(float) > h.data_bytes) fail(AE_ERR_INVALID_ARG, "host-memory communicator: the coordinate array exceeds the segment (max_bytes of ae_comm_init_hostmem)");
         float* seg = reinterpret_cast<float*>(h.data(c->world));
         sync();
-        AE_HIP(hipMemcpy(seg + o->dev.node_lo * dim, o->y.p + o->dev.node_lo * dim, (o->dev.node_hi - o->dev.node_lo) * dim * sizeof(float), hipMemcpyDeviceToHost));
+        AE_HIP(hipMemcpy(seg + o->dev.node_lo * dim, yb + o->dev.node_lo * dim, (o->dev.node_hi - o->dev.node_lo) * dim * sizeof(float), hipMemcpyDeviceToHost));
         h.barrier(c->world);
         for (int q = 0; q < c->world; q++) {
             if (q == c->rank) continue;
             const uint64_t lo = o->comm_ranges[2 * q], hi = o->comm_ranges[2 * q + 1];
-            AE_HIP(hipMemcpy(o->y.p + lo * dim, seg + lo * dim, (hi - lo) * dim * sizeof(float), hipMemcpyHostToDevice));
+            AE_HIP(hipMemcpy(yb + lo * dim, seg + lo * dim, (hi - lo) * dim * sizeof(float), hipMemcpyHostToDevice));
         }
         h.barrier(c->world);
         return;
@@ -196,11 +197,11 @@ void ce_comm_exchange(ae_entropy_optim* o) {
     Rccl& r = rccl();
     if (o->comm_equal) {
         const uint64_t rows = o->comm_ranges[1] - o->comm_ranges[0];
-        nccl_check(r.AllGather(o->y.p + o->dev.node_lo * dim, o->y.p, rows * dim, kNcclFloat32, c->nccl, stream()), "all-gather");
+        nccl_check(r.AllGather(yb + o->dev.node_lo * dim, yb, rows * dim, kNcclFloat32, c->nccl, stream()), "all-gather");
     } else {  // unequal shards: one in-place broadcast per owner, fused by the group
         nccl_check(r.GroupStart(), "group start");
         for (int q = 0; q < c->world; q++) {
-            float* p = o->y.p + o->comm_ranges[2 * q] * dim;
+            float* p = yb + o->comm_ranges[2 * q] * dim;
             nccl_check(r.Broadcast(p, p, (o->comm_ranges[2 * q + 1] - o->comm_ranges[2 * q]) * dim, kNcclFloat32, q, c->nccl, stream()), "broadcast");
         }
         nccl_check(r.GroupEnd(), "group end");
@@ -227,6 +228,9 @@ void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchang
     o->comm_equal = equal;
     o->comm = c;
     o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
+    // the time-sliced mode now knows every rank's range: its internal numbering (a random relabelling inside every rank's range, the
+    // same on every rank) and everything built on it are made afresh
+    if (o->params.ce_mode == AE_CE_SLICED && c->world > 1) ce_slice_prepare(o);
 }
 
 }  // namespace ae

@@ -140,7 +140,8 @@ enum {
        the others are deferred to the next pass.  Scalar arithmetic as `ce_precision` says (default:
        the reference's f64 scalars).  Negatives: uniform / NodeSampler draws; in crowded steps the samples of a workgroup take them
        from a shared tile of rows, never two from the same run of consecutive rows.  On one device the nodes are relabelled at
-       random internally: the result does not depend on the caller's numbering (a sharded range works in the caller's labels).
+       random internally: the result does not depend on the caller's numbering (a sharded range: inside every rank's range, once a
+       communicator is attached).
        Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
        parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
        standard error), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
@@ -379,8 +380,8 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * on cross-shard edges is refused with AE_ERR_INVALID_ARG).  Exchanges per batch: on graphs of up to ~10^5 nodes one is enough
  * (1 ... 240 measured: no trend); at 10^6 ... 10^7 nodes in 8 shards, from a random start, one exchange per batch leaves the edges
  * 6 ... 21 % short (the other shards' rows are a whole batch old while the layout still moves fast), 4 match the one-device run:
- * ask for 4 or more.  A sharded range gathers its negatives row by row (no shared tile: it works in the caller's
- * labels); the rounds mode
+ * ask for 4 or more.  Attaching the communicator prepares the time-sliced mode again (edge colouring included: a
+ * fraction of a second at 10^7 nodes): every rank then knows every rank's range and relabels the nodes at random inside each; the rounds mode
  * (AE_CE_HOGWILD, by name) is approximate whatever the partition.  The final cross entropy is the sum of the
  * ranks' ae_entropy_optim_ce values (ae_comm_all_reduce_sum).  RCCL is loaded on the first ae_comm_* call. */
 typedef struct ae_comm ae_comm;
