@@ -824,7 +824,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // the whole graph.  Thicker slices on a rank's under-filled steps (up to lambda = 1: half the steps, 81 -> 52 ms) were built and
     // measured and are NOT the default: on one device lambda = 1 stays within ~1 % of lambda = 1/2, but an 11 M-node
     // 64-component graph in 4 and 8 shards came out with its edges 10-15 % short (CE +2 %), where lambda = 1/2 in 2 shards matched
-    // the exact mode to 0.5 %.  Kept behind a knob for A/B.
+    // the exact mode to 0.5 % (those runs had ONE exchange per batch, which alone costs that much: DESIGN 5) -- and with 4 exchanges
+    // per batch a 600 k-node graph of 64 tight components in 2 shards still came out 13-18 % short at lambda = 1 where lambda = 1/2
+    // sits at +4 ... +9 % (the 11 M-node graph: no difference).  How much a thick slice shows depends on the graph.  Kept behind a knob.
     if (sharded && o->sl_classes && !debug_knob("AE_SL_LAMBDA") && debug_knob("AE_SL_THICK")) {   // (A/B only: see above)
         const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
         const double resident = sl_resident_events(o);   // (a step up to what the device holds at once: 125 k events cost what 190 k do)
