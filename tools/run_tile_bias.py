@@ -13,8 +13,13 @@ import bench  # noqa: E402
 import annembed_amd as A  # noqa: E402
 
 n, k, d, nb = int(os.environ.get("N", "1000000")), 6, int(os.environ.get("D", "8")), int(os.environ.get("NB", "20"))
-gr = bench.config_graphs(A, "c4", permute_seed=int(os.environ.get("PERMUTE", "9")) or None, n_override=n)
-indptr, nbr, dist = gr["indptr"], gr["nbr"], gr["dist"]
+if os.environ.get("GRAPH") == "comp":   # 64 well separated tight components (the sharded tests' graph) instead of the Higgs-shaped blobs
+    x_, bounds_ = bench.mixture_points_gpu(n, 28, 64, seed=5, mean_sigma=10.0)
+    indptr, nbr, dist = bench.component_knn_graph(A, x_, bounds_, k, permute_seed=int(os.environ.get("PERMUTE", "9")) or None)
+    del x_
+else:
+    gr = bench.config_graphs(A, "c4", permute_seed=int(os.environ.get("PERMUTE", "9")) or None, n_override=n)
+    indptr, nbr, dist = gr["indptr"], gr["nbr"], gr["dist"]
 g = A.KGraph(indptr, nbr, dist, k)
 hub = g.hubness() if os.environ.get("HUBW", "1") == "1" else None
 if os.environ.get("HUBSYN") == "1":   # a heavy-tailed synthetic weighting (1 % of the nodes 500x as likely): a wrong negative law shows
