@@ -227,7 +227,7 @@ void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchang
     if (expect != o->dev.n) fail(AE_ERR_INVALID_ARG, "the ranks' node ranges must tile [0, n) in rank order");
     o->comm_equal = equal;
     o->comm = c;
-    o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
+    o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 4u;   // (0: the library's choice)
     // the time-sliced mode now knows every rank's range: its internal numbering (a random relabelling inside every rank's range, the
     // same on every rank) and everything built on it are made afresh
     if (o->params.ce_mode == AE_CE_SLICED && c->world > 1) ce_slice_prepare(o);

@@ -259,7 +259,7 @@ int32_t ae_embedder_set_comm(ae_embedder* e, ae_comm* comm, uint32_t exchanges_p
     return guard([&] {
         if (!e) fail(AE_ERR_INVALID_ARG, "null argument");
         e->comm = comm;
-        e->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 1u;
+        e->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 4u;   // (0: the library's choice)
     });
 }
 

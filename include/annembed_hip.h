@@ -373,7 +373,8 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * host channel; every rank calls ae_comm_init on its own device (ae_set_device first).  A communicator attached to an
  * EntropyOptim created on this rank's node range [node_lo, node_hi) -- the ranges of the ranks must tile [0, n) in rank
  * order -- makes ae_entropy_optim_gradient_iteration exchange the owned coordinate rows itself: in place, on the library's
- * stream, `exchanges_per_batch` times per batch at equal runs of rounds / time slices (1 = once per batch, at its end).  Two modes
+ * stream, `exchanges_per_batch` times per batch at equal runs of rounds / time slices (1 = once per batch, at its end; 0 = the library's
+ * choice: 4).  Two modes
  * shard: the time-sliced mode (AE_CE_SLICED; what AE_CE_AUTO resolves to on a sharded range) runs a shard's own events on current rows
  * and reads the other shards' rows -- negatives, the far ends of cross-shard edges, which fire as two half events -- as of the last
  * exchange: faithful for node orders with few cross-shard edges (connected components / locality; more than 10 % of a shard's edge mass
