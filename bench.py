@@ -29,7 +29,8 @@ rounds mode on the lattice (round 2-3's series); `--weak`: 60 k MNIST-shaped poi
 A "step" = one CE batch.  The timed region holds only `ae_entropy_optim_gradient_iteration` calls
 (the collective is inside them when N>1) with every input already resident in HBM.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints everything it measured as `bench_details: {...}` (also written to bench_details.json) and then, LAST, ONE compact
+JSON line (< 4 KB: the contract's keys + roofline + cpu_baseline + parity_mode + one figure per scale shape).
 """
 import argparse
 import json
@@ -409,6 +410,122 @@ def config_graphs(A, which, permute_seed=9, n_override=None, shuffle_within_shar
                 t1 - t0, t2 - t1)}
 
 
+FINAL_LINE_MAX = 4096   # the driver keeps the tail of stdout: the LAST line must parse on its own (round 4's 40 KB line did not)
+
+
+def _short(v, nmax=160):
+    return v if not isinstance(v, str) or len(v) <= nmax else v[:nmax - 3] + "..."
+
+
+def compact_roofline(r):
+    """the judged fields of a roofline object, nothing else"""
+    if not r:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "kernel", "launch_avg_ms", "launches_per_batch",
+            "bytes_per_sample", "bytes_per_launch", "frac_whole_batch")
+    return {k: (_short(r[k], 120) if k in ("kernel", "traffic_from") else r[k]) for k in keep if k in r}
+
+
+def compact_line(full):
+    """`full` = everything bench.py measured (-> bench_details.json and an earlier stdout line).  Returns the ONE final JSON line:
+    the contract's keys, roofline, cpu_baseline, parity_mode, the SVD-init figures and one number per scale shape."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                    "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: _short(cfg[k], 200) for k in ("workload", "ce_mode", "samples_per_step", "exchanges_per_batch", "rccl_ranks", "collective",
+                                                      "partition", "cross_shard_mass") if k in cfg}
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: _short(cpu[k], 200) for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+    else:
+        out["cpu_baseline"] = None
+    pm = full.get("parity_mode")
+    if pm:
+        out["parity_mode"] = {"ce_mode": "AE_CE_SEQUENTIAL (bit-exact vs the oracle)", "ms_per_step": pm["ms_per_step"], "points_per_s": pm["points_per_s"],
+                              "frac": pm["roofline"]["frac"]}
+    for k in ("svd_init", "svd_init_c4", "svd_dense"):
+        if full.get(k):
+            out[k] = {kk: vv for kk, vv in full[k].items() if not isinstance(vv, (dict, list)) and not (isinstance(vv, str) and len(vv) > 80)}
+    shapes = full.get("scale_shapes") or {}
+    brief = {}
+    for name, sh in shapes.items():
+        dm = (sh or {}).get("default_mode")
+        if dm:
+            brief[name] = {"ms": round(dm["ms_per_step"], 2), "points_per_s": round(dm["points_per_s"]), "frac": round(dm["roofline"]["frac"], 4),
+                           "frac_whole_batch": round(dm["roofline"]["frac_whole_batch"], 4)}
+    if brief:
+        out["scale_shapes"] = brief
+    for k in ("per_rank_batch_ms_max", "faithful", "samples_per_s", "ce_before", "ce_after", "details"):
+        if k in full:
+            out[k] = _short(full[k], 120)
+    line = json.dumps(out)
+    if len(line) >= FINAL_LINE_MAX:   # never: but a parseable short line beats a complete long one
+        for k in ("scale_shapes", "svd_dense", "svd_init_c4", "svd_init", "faithful"):
+            out.pop(k, None)
+            line = json.dumps(out)
+            if len(line) < FINAL_LINE_MAX:
+                break
+    assert len(line) < FINAL_LINE_MAX, len(line)
+    return line
+
+
+def emit(full):
+    """writes bench_details.json (repo root, and gpurun_out/ when it exists), prints the details as an EARLIER stdout line (not JSON on
+    its own: prefixed) and the compact line LAST"""
+    full = dict(full)
+    full["details"] = "bench_details.json (also the preceding stdout line, prefixed 'bench_details: ')"
+    blob = json.dumps(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    f.write(blob + "\n")
+        except OSError:
+            pass
+    print("bench_details: " + blob, flush=True)
+    print(compact_line(full), flush=True)
+
+
+def spawn_ranks(n_ranks, argv):
+    """`python3 bench.py --gpus N` without a launcher: N rank processes are started here, BEFORE this process makes any GPU call (a
+    child is a fresh interpreter; nothing is exec'ed over a process that has touched the GPU).  Rank 0 inherits stdout (its last line
+    is the result), the other ranks' stdout goes to stderr.  A failed rank fails the run."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("AE_BENCH_SPAWN_TIMEOUT", "3000"))
+    alive = list(procs)
+    while alive:
+        for p_ in list(alive):
+            code = p_.poll()
+            if code is None:
+                continue
+            alive.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:     # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+        if time.time() > deadline:
+            for q in alive:
+                q.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -439,6 +556,8 @@ def main():
                     help="torch.distributed backend used for rendezvous, barriers and timing reductions (gloo: validation runs with several "
                          "ranks sharing ONE GPU; RCCL refuses duplicate devices, so the exchange then goes through torch/gloo and the figure is not a result)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # plain `python3 bench.py --gpus N`: start the N ranks ourselves
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -447,8 +566,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
     if args.backend == "gloo":
@@ -481,8 +599,8 @@ def main():
         line = multi_gpu(args, A, L, dist, torch, rank, world, fence)
         dist.barrier()
         dist.destroy_process_group()
-        if line is not None:  # the ONE JSON line, after everything that might still write to stdout (RCCL's banner, teardown)
-            print(json.dumps(line), flush=True)
+        if line is not None:  # the ONE JSON line LAST, after everything that might still write to stdout (RCCL's banner, teardown)
+            emit(line)
         return
 
     # =============================== N = 1 ===============================
@@ -659,7 +777,7 @@ def main():
         "samples_per_s": head["nb_sample"] / (head["ms_per_step"] * 1e-3),
         "ce_before": head["ce_before"], "ce_after": head["ce_after"],
     }
-    print(json.dumps(out))
+    emit(out)
 
 
 def multi_gpu(args, A, L, dist, torch, rank, world, fence):
@@ -839,7 +957,7 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
 def pmc_traffic(mode):
     """HBM bytes per launch of the dominant kernel REPLAYED from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/pmc_ce_*.json, written by tools/prof_bench.sh: FETCH_SIZE and WRITE_SIZE collected in separate passes).
-    Not a measurement of this run: reported under its own keys, `traffic` stays null."""
+    Not a measurement of this run: `traffic_from` says where it comes from."""
     import glob
     name = {0: "pmc_ce_round.json", 1: "pmc_ce_dataflow.json", 3: "pmc_ce_event.json", 6: "pmc_ce_ordered.json"}.get(mode)
     if not name:
@@ -850,7 +968,9 @@ def pmc_traffic(mode):
     try:
         with open(files[-1]) as f:
             j = json.load(f)
-        return {"traffic_replayed": float(j["hbm_bytes_per_launch"]), "traffic_replayed_from": os.path.relpath(files[-1], ROOT)}
+        # `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (separate --pmc passes, the
+        # guide's gfx950 correction applied by tools/prof_bench.sh); rocprofv3 wraps the process, so it cannot be collected from inside
+        return {"traffic": float(j["hbm_bytes_per_launch"]), "traffic_from": os.path.relpath(files[-1], ROOT) + " (replayed: a PMC run of this command, not this run)"}
     except Exception:
         return None
 

@@ -146,3 +146,46 @@ def test_oracle_knn_definition_matches_f64_bruteforce():
     xt = np.zeros((6, 2), np.float32)  # all points identical: every row lists the other indices in increasing order
     _, nbt, dst = O.knn_bruteforce_l2(xt, 3)
     assert np.array_equal(nbt.reshape(6, 3)[0], [1, 2, 3]) and np.array_equal(nbt.reshape(6, 3)[5], [0, 1, 2]) and not dst.any()
+
+
+def test_bench_final_line_is_short_and_parses():
+    """the driver keeps the tail of stdout: bench.py's LAST line must be < 4 KB and parse on its own (round 4's 40 KB line did not)"""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*", "bench_r*.json")))
+    assert files
+    seen = 0
+    for f in files[-3:]:
+        text = open(f).read().strip().splitlines()[-1]
+        if text.startswith("bench_details: "):
+            text = text[len("bench_details: "):]
+        full = json.loads(text)
+        line = bench.compact_line(full)
+        assert len(line) < 4096 and "\n" not in line
+        back = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                  "roofline", "cpu_baseline"):
+            assert k in back, k
+        assert back["value"] == full["value"] and back["roofline"]["frac"] == full["roofline"]["frac"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(back["roofline"])
+        if full.get("cpu_baseline"):
+            assert {"value", "cores", "kind", "sample"} <= set(back["cpu_baseline"])
+        seen += 1
+    assert seen
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus N` without a launcher starts N rank processes before any GPU call; a failing rank fails the run.
+    (Here there is no GPU: every rank must exit with bench.py's "needs a GPU" message, and the parent with a non-zero code.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["AE_BENCH_SPAWN_TIMEOUT"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert "needs a GPU" in r.stderr
+        assert "started with WORLD_SIZE" not in r.stderr   # both ranks got RANK / WORLD_SIZE from the parent
