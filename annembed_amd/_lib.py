@@ -58,6 +58,11 @@ class CQualityReport(C.Structure):
     ]
 
 
+class CPartitionReport(C.Structure):
+    _fields_ = [("components", C.c_uint64), ("splits", C.c_uint64), ("cross_mass", C.c_double), ("cross_mass_worst_rank", C.c_double),
+                ("imbalance", C.c_double)]
+
+
 class CDiffusionParams(C.Structure):
     _fields_ = [
         ("asked_dim", C.c_uint64), ("alfa", C.c_float), ("beta", C.c_float), ("epsil", C.c_float), ("t", C.c_float),
@@ -148,6 +153,9 @@ SIGNATURES = {
     "ae_embedder_destroy": [_vp],
     "ae_embedder_set_comm": [_vp, _vp, C.c_uint32],
     "ae_embedder_embed": [_vp],
+    "ae_kgraph_partition": [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _P(CPartitionReport)],
+    "ae_kgraph_permuted": [_vp, _vp, _P(_vp)],
+    "ae_embedder_get_partition_report": [_vp, _P(CPartitionReport)],
     "ae_embedder_get_nb_nodes": [_vp, _P(_u64)],
     "ae_embedder_get_embedded": [_vp, _vp],
     "ae_embedder_get_embedded_reindexed": [_vp, _vp, _vp],

@@ -132,6 +132,11 @@ class _Handle:
             pass
 
 
+def _partition_report(rep):
+    return {"components": int(rep.components), "splits": int(rep.splits), "cross_mass": float(rep.cross_mass),
+            "cross_mass_worst_rank": float(rep.cross_mass_worst_rank), "imbalance": float(rep.imbalance)}
+
+
 class KGraph(_Handle):
     """KGraph<f32>, src/fromhnsw/kgraph.rs:109-120, resident on the GPU as a CSR."""
 
@@ -186,6 +191,30 @@ class KGraph(_Handle):
         h = C.c_void_p()
         check(L.load().ae_kgraph_bruteforce_l2(ptr(x), x.shape[0], x.shape[1], nbng, C.byref(h)))
         return cls._wrap(h)
+
+    def partition(self, world, y=None, node_params=None):
+        """Locality partition into `world` contiguous ranges (ae_kgraph_partition; no reference counterpart: SURVEY 8e "after locality
+        reordering"): connected components packed whole, a component that must be cut is cut by coordinate bisection of y (n x dim;
+        None: id order).  -> order (order[pos] = this graph's node at position pos), ranges [(lo, hi)] per rank, report dict"""
+        n = self.get_nb_nodes()
+        order = np.zeros(n, np.uint32)
+        ranges = np.zeros(2 * world, np.uint64)
+        rep = L.CPartitionReport()
+        dim = 0
+        if y is not None:
+            y = _f32(y)
+            if y.ndim != 2 or y.shape[0] != n:
+                raise ValueError("y must have one row per node")
+            dim = y.shape[1]
+        check(L.load().ae_kgraph_partition(self._h, node_params._h if node_params is not None else None, ptr(y), dim, world, ptr(order), ptr(ranges), C.byref(rep)))
+        return order, [(int(ranges[2 * r]), int(ranges[2 * r + 1])) for r in range(world)], _partition_report(rep)
+
+    def permuted(self, order):
+        """the same graph with the node at position p = node order[p] (ae_kgraph_permuted); coordinates come back as y_here[order] = y_there"""
+        order = _u32(order)
+        h = C.c_void_p()
+        check(L.load().ae_kgraph_permuted(self._h, ptr(order), C.byref(h)))
+        return KGraph._wrap(h)
 
     def get_nb_nodes(self):
         v = C.c_uint64()
@@ -596,9 +625,17 @@ class Embedder(_Handle):
 
     def set_comm(self, comm, exchanges_per_batch=4):
         """multi-GPU embedding: this process is one rank of `comm` (annembed_amd.dist.LibraryComm / HostMemComm); embed() then
-        shards the CE loop over the ranks (ae_embedder_set_comm).  parameters.ce_mode must be AE_CE_HOGWILD."""
+        shards the CE loop over the ranks (ae_embedder_set_comm): the graph may be in any node order -- embed() partitions it by
+        locality (get_partition_report) and returns the embedding in the caller's order.  parameters.ce_mode: AE_CE_AUTO / AE_CE_SLICED
+        (the faithful time-sliced mode) or AE_CE_HOGWILD (the approximate rounds mode, by name)."""
         self._comm = comm  # keep the communicator alive
         check(L.load().ae_embedder_set_comm(self._h, comm._h if comm is not None else None, exchanges_per_batch))
+
+    def get_partition_report(self):
+        """the locality partition the last multi-GPU embed() applied (ae_embedder_get_partition_report)"""
+        rep = L.CPartitionReport()
+        check(L.load().ae_embedder_get_partition_report(self._h, C.byref(rep)))
+        return _partition_report(rep)
 
     @classmethod
     def from_hkgraph(cls, graph_projection, parameters):

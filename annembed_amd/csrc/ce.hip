@@ -980,6 +980,7 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         if (np->g != g) fail(AE_ERR_INVALID_ARG, "node params were not computed from this graph");
         if (params->asked_dim == 0 || params->asked_dim > 64) fail(AE_ERR_INVALID_ARG, "asked_dim must be in [1,64]");
         if (node_lo >= node_hi || node_hi > g->n) fail(AE_ERR_INVALID_ARG, "bad node range");
+        if (params->ce_precision != AE_PRECISION_F64 && params->ce_precision != AE_PRECISION_F32) fail(AE_ERR_INVALID_ARG, "unknown ce_precision %u", params->ce_precision);
         if (g->n < (uint64_t)g->max_nbng + 8) fail(AE_ERR_INVALID_ARG, "graph too small for negative sampling");
         std::unique_ptr<ae_entropy_optim> o(new ae_entropy_optim);
         o->g = g;
@@ -1074,7 +1075,9 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         if (mode_final == AE_CE_EVENT || mode_final == AE_CE_HOGWILD) ce_node_build_transpose(o.get());
         if (mode_final == AE_CE_EVENT) ce_event_prepare(o.get());
         o->params.ce_mode = mode_final;  // (ce_slice_prepare reads it: the cost model of the matching cut belongs to this mode only)
-        if (mode_final == AE_CE_SLICED) ce_slice_prepare(o.get());
+        // (a sharded range prepares once its communicator is attached and every rank's range known -- the internal numbering depends
+        // on them --, or with its first batch: not twice)
+        if (mode_final == AE_CE_SLICED && !sharded) ce_slice_prepare(o.get());
         return o.release();
     }
 }
@@ -1111,6 +1114,7 @@ int32_t ae_entropy_optim_slice_info(const ae_entropy_optim* o, uint32_t* classes
     return guard([&] {
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
         if (o->params.ce_mode != AE_CE_SLICED) fail(AE_ERR_STATE, "the handle does not run AE_CE_SLICED");
+        if (!o->sl_prepared && !ce_slice_unsupported(o)) ce_slice_prepare(const_cast<ae_entropy_optim*>(o));
         if (classes) *classes = o->sl_classes;
         if (overflow_fraction) *overflow_fraction = o->sl_ov_frac;
         if (colouring_rounds) *colouring_rounds = o->sl_color_rounds;
@@ -1122,6 +1126,7 @@ int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim* o, uint32_t* max
     return guard([&] {
         if (!o) fail(AE_ERR_INVALID_ARG, "null argument");
         if (o->params.ce_mode != AE_CE_SLICED) fail(AE_ERR_STATE, "the handle does not run AE_CE_SLICED");
+        if (!o->sl_prepared && !ce_slice_unsupported(o)) ce_slice_prepare(const_cast<ae_entropy_optim*>(o));
         if (max_in_degree) *max_in_degree = o->sl_max_in_degree;
         // (half an event per node and slice on average: a row of degree D sees 0.5 D / mean degree of them, spread over the classes)
         if (busiest_row_events_per_step)

@@ -123,6 +123,7 @@ struct ae_entropy_optim {
     DevBuf<uint32_t> sl_chain_head, sl_chain_next;  // chain rounds: per node the head of its pending in-events' list (kept all-NIL between rounds), per list position the next link
     DevBuf<char> sl_sort_tmp;                   // rocPRIM's temporary storage of the event sort (histograms), kept with the handle
     float sl_pmax = 0.f;
+    bool sl_prepared = false;                   // ce_slice_prepare has run (a sharded handle defers it to the communicator's attach or its first batch)
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
     DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
@@ -149,7 +150,7 @@ struct ae_entropy_optim {
     float* comm_y = nullptr;                    // the array the in-batch exchanges act on, if not y (the time-sliced mode's internal copy)
     bool comm_equal = false;
     uint32_t comm_exchanges = 1;
-    uint64_t comm_bytes = 0;                    // bytes of coordinate rows received through exchanges since the handle was created (per rank: n x stride x 4 each)
+    uint64_t comm_bytes = 0;                    // bytes of coordinate rows received through exchanges since the handle was created (the other ranks' rows x stride x 4 per exchange; every mode)
     ~ae_entropy_optim() {
         if (df_ahead.prep) { (void)hipStreamSynchronize(df_ahead.prep); (void)hipStreamDestroy(df_ahead.prep); }
         if (df_ahead.run) { (void)hipStreamSynchronize(df_ahead.run); (void)hipStreamDestroy(df_ahead.run); }

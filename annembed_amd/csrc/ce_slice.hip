@@ -515,6 +515,7 @@ bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event*
 namespace ae {
 
 constexpr double kMaxCrossShardMass = 0.10;
+double ce_slice_max_cross_mass() { return kMaxCrossShardMass; }
 
 const char* ce_slice_unsupported(const ae_entropy_optim* o) {
     if (o->dev.nnz >= 0xFFFFFFFFull) return "more than 2^32 edges";
@@ -753,12 +754,9 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     for (float v : hp) pmax = std::max(pmax, v);
     o->sl_pmax = pmax;
     slice_color_edges(o);
-    // A sharded range runs a cross-shard edge as two half events, each against a replica of the far end that is as old as the last
-    // exchange: fine for a few per cent of the edges (a partition by connected components has none), not for a graph in arbitrary order.
-    if ((o->dev.node_lo != 0 || o->dev.node_hi != g->n) && o->sl_cross_frac > kMaxCrossShardMass && !debug_knob("AE_SL_ANY_PARTITION"))
-        fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED on nodes [%llu, %llu): %.1f %% of the shard's edge probability mass lies on cross-shard edges (limit %.0f %%): "
-                                 "order the nodes by locality / connected component before sharding, or ask for the approximate rounds mode (AE_CE_HOGWILD)",
-             (unsigned long long)o->dev.node_lo, (unsigned long long)o->dev.node_hi, 100. * o->sl_cross_frac, 100. * kMaxCrossShardMass);
+    // (A sharded range runs a cross-shard edge as two half events, each against a replica of the far end that is as old as the last
+    // exchange: fine for a few per cent of the edges, not for a graph in arbitrary order.  The limit is enforced where every rank takes
+    // the same decision: entropy_optim_attach_comm, comm.hip; a range without a communicator: the first batch, below.)
     o->sl_owner.alloc(2 * g->n);
     AE_HIP(hipMemsetAsync(o->sl_owner.p, 0xFF, sizeof(uint32_t) * 2 * g->n, stream()));
     o->sl_counts.alloc(3 * kSub);
@@ -767,6 +765,7 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     o->sl_done.zero();
     o->sl_chunk_flag.release();
     if (!o->sample_counter.n) { o->sample_counter.alloc(1024); o->sample_counter.zero(); }
+    o->sl_prepared = true;
 }
 
 // events a step can hold with ALL its workgroups resident at once (the step kernel's occupancy x CUs x 256, less 3 %: the classes'
@@ -785,7 +784,12 @@ static double sl_resident_events(ae_entropy_optim* o) {
 
 void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double grad_step, uint32_t iter) {
     if (const char* why = ce_slice_unsupported(o)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: %s", why);
+    if (!o->sl_prepared) ce_slice_prepare(o);   // (a sharded range nobody attached a communicator to)
     const uint64_t n = o->dev.n, nnz = o->dev.nnz;
+    if ((o->dev.node_lo != 0 || o->dev.node_hi != n) && !o->comm && o->sl_cross_frac > kMaxCrossShardMass && !debug_knob("AE_SL_ANY_PARTITION"))
+        fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED on nodes [%llu, %llu): %.1f %% of the shard's edge probability mass lies on cross-shard edges (limit %.0f %%): "
+                                 "order the nodes by locality / connected component before sharding (ae_kgraph_partition), or ask for the approximate rounds mode (AE_CE_HOGWILD)",
+             (unsigned long long)o->dev.node_lo, (unsigned long long)o->dev.node_hi, 100. * o->sl_cross_frac, 100. * kMaxCrossShardMass);
     // A sharded node range (multi-GPU): nb_sample counts this shard's samples (nb_sampling_by_edge x its edges); everything that shapes
     // the batch -- segments, slices, exchange points -- follows the WHOLE graph's total so that every rank cuts the batch alike, and the
     // per-edge Poisson means are the whole graph's law (edges are drawn in proportion to p_e over the whole graph, embedder.rs:987).
@@ -981,11 +985,22 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // segment's drain): between two exchanges a shard reads the other shards' rows -- negatives, the far ends of its cross-shard
     // edges -- as of the last one.  Every rank has the same slices (they follow the whole graph's totals), hence the same exchange points.
     const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
+    uint64_t exchanges_done = 0;
+    auto exchange_now = [&] { ce_comm_exchange(o); exchanges_done++; };
     auto exchange_after = [&](uint32_t s) {
         if (exchanges < 2u) return;
         const uint32_t q = (uint32_t)(((uint64_t)(s + 1u) * exchanges) / n_slices), q0 = (uint32_t)(((uint64_t)s * exchanges) / n_slices);
-        if (q != q0 && q < exchanges) { ce_comm_exchange(o); o->comm_bytes += o->dev.n * o->dev.dim * sizeof(float); }
+        if (q != q0 && q < exchanges) exchange_now();
     };
+    // A batch that fails on THIS rank (event capacity, a pending list, a poll budget) still owes the other ranks its part in the batch's
+    // remaining exchanges: they are collectives the others are about to enter.  The error is reported after them.
+    struct OweExchanges {
+        ae_entropy_optim* o; const uint64_t& done; uint64_t owed; bool armed = true;
+        ~OweExchanges() {
+            if (!armed || !o->comm) return;
+            try { for (uint64_t x = done; x < owed; x++) ce_comm_exchange(o); } catch (...) {}
+        }
+    } owe{o, exchanges_done, (uint64_t)segments * exchanges};
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
@@ -1166,9 +1181,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 cur = (cur + 1) % 3;
             }
         }
-        if (exchanges) { ce_comm_exchange(o); o->comm_bytes += o->dev.n * o->dev.dim * sizeof(float); }   // (after the drain: the segment's last exchange)
+        if (exchanges) exchange_now();   // (after the drain: the segment's last exchange)
         t_drain += wall() - t_enq;
     }
+    owe.armed = false;
     if (relabelled)   // back to the caller's labels
         hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap(n * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
                            (const uint32_t*)o->sl_perm.p, (const float*)o->sl_y.p, o->dev.y, 0);

@@ -137,6 +137,9 @@ void comm_broadcast_f32(ae_comm* c, float* p, uint64_t count, int root) {
     sync();
 }
 
+// (bytes are bytes: both transports move a float32 buffer verbatim)
+void comm_broadcast_u32(ae_comm* c, uint32_t* p, uint64_t count, int root) { comm_broadcast_f32(c, reinterpret_cast<float*>(p), count, root); }
+
 // every rank's two words, in rank order
 static std::vector<uint64_t> comm_all_gather_u64x2(ae_comm* c, const uint64_t (&mine)[2]) {
     std::vector<uint64_t> all(2 * (size_t)c->world);
@@ -178,6 +181,7 @@ void ce_comm_exchange(ae_entropy_optim* o) {
     ae_comm* c = o->comm;
     if (!comm_active(c)) return;
     const uint64_t dim = o->dev.dim;
+    o->comm_bytes += (o->dev.n - (o->dev.node_hi - o->dev.node_lo)) * dim * sizeof(float);   // received: the other ranks' rows
     float* const yb = o->comm_y ? o->comm_y : o->y.p;   // (rows in the caller's labels, or the time-sliced mode's internal copy: the same ranges)
     if (c->host) {
         HostMem& h = *c->host;
@@ -228,9 +232,39 @@ void entropy_optim_attach_comm(ae_entropy_optim* o, ae_comm* c, uint32_t exchang
     o->comm_equal = equal;
     o->comm = c;
     o->comm_exchanges = exchanges_per_batch ? exchanges_per_batch : 4u;   // (0: the library's choice)
-    // the time-sliced mode now knows every rank's range: its internal numbering (a random relabelling inside every rank's range, the
-    // same on every rank) and everything built on it are made afresh
-    if (o->params.ce_mode == AE_CE_SLICED && c->world > 1) ce_slice_prepare(o);
+    // The time-sliced mode now knows every rank's range: its internal numbering (a random relabelling inside every rank's range, the
+    // same on every rank) and everything built on it are made now (a sharded handle defers its preparation to this point or to its
+    // first batch: ce.hip).  A preparation that fails on ONE rank (or a range whose cross-shard mass is over the limit on one rank
+    // and under it on another) must not leave the others waiting in the first collective: the ranks agree on the outcome first.
+    if (o->params.ce_mode == AE_CE_SLICED && c->world > 1) {
+        int32_t code = AE_OK;
+        std::string msg;
+        try {
+            ce_slice_prepare(o);
+        } catch (const Error& e) {
+            code = e.code;
+            msg = e.msg;
+        }
+        uint64_t mine[2] = {0, (uint64_t)(uint32_t)code};
+        memcpy(&mine[0], &o->sl_cross_frac, 8);
+        const std::vector<uint64_t> all = comm_all_gather_u64x2(c, mine);
+        double worst = 0.;
+        int worst_rank = 0, failed_rank = -1;
+        for (int q = 0; q < c->world; q++) {
+            double f;
+            memcpy(&f, &all[2 * q], 8);
+            if (f > worst) { worst = f; worst_rank = q; }
+            if (all[2 * q + 1] != 0 && failed_rank < 0) failed_rank = q;
+        }
+        if (code != AE_OK) { o->comm = nullptr; fail(code, "%s", msg.c_str()); }
+        if (failed_rank >= 0) { o->comm = nullptr; fail((int32_t)all[2 * failed_rank + 1], "rank %d could not prepare its shard of the time-sliced mode (its own message says why)", failed_rank); }
+        if (worst > ce_slice_max_cross_mass() && !debug_knob("AE_SL_ANY_PARTITION")) {
+            o->comm = nullptr;
+            fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED over %d ranks: %.1f %% of rank %d's edge probability mass lies on cross-shard edges (limit %.0f %%): order the nodes by "
+                                     "locality first (ae_kgraph_partition + ae_kgraph_permuted; Embedder::embed does it itself), or ask for the approximate rounds mode (AE_CE_HOGWILD)",
+                 c->world, 100. * worst, worst_rank, 100. * ce_slice_max_cross_mass());
+        }
+    }
 }
 
 }  // namespace ae

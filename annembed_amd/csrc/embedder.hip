@@ -77,6 +77,8 @@ struct ae_embedder {
     double ce_before = 0., ce_after = 0.;
     ae_comm* comm = nullptr;       // multi-GPU: this process is one rank of the embedding (ae_embedder_set_comm)
     uint32_t comm_exchanges = 1;
+    bool has_partition = false;    // the last embed() ran sharded: the report of its (last stage's) locality partition
+    ae_partition_report partition;
 };
 
 namespace {
@@ -85,6 +87,9 @@ namespace {
 struct Dist {
     ae_comm* comm = nullptr;
     uint32_t exchanges = 1;
+    ae_partition_report* report = nullptr;   // where the stage's partition report goes
+    const float* part_y = nullptr;           // coordinates the partition bisects along, if not the stage's initial embedding
+    uint32_t part_dim = 0;
     bool active() const { return comm_world(comm) > 1; }
 };
 
@@ -110,18 +115,104 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
         rc_check(ae_kgraph_hubness(g, hub.data()));
     }
     uint64_t lo = 0, hi = g->n;
+    // Multi-GPU: the graph arrives in the caller's node order -- the reference's is IndexSet insertion order of the HNSW points, file
+    // order (kgraph.rs:489,500): no locality -- and the sharded loop wants contiguous ranges with few cross-range edges.  Rank 0
+    // partitions (connected components packed whole, a component that must be cut is cut by coordinate bisection of the initial
+    // embedding: partition.hip), the order is broadcast, every rank relabels its copy of the graph, the node parameters, the initial
+    // embedding and the hubness counts, runs on the relabelled problem and hands the rows back in the caller's order.
+    Partition part;
+    std::unique_ptr<ae_kgraph> g_part;
+    ae_node_params np_part;
+    DevBuf<float> y0_part;
+    const ae_kgraph* gr = g;
+    const ae_node_params* npr = np;
+    float* y0r = d_y0;
+    const uint64_t dim = params.asked_dim;
     if (dist.active()) {
         if (params.ce_mode != AE_CE_HOGWILD && params.ce_mode != AE_CE_AUTO && params.ce_mode != AE_CE_SLICED)
-            fail(AE_ERR_INVALID_ARG, "a multi-GPU embedding runs the time-sliced mode (ce_mode = AE_CE_AUTO / AE_CE_SLICED: faithful, for node orders with few cross-shard "
-                                     "edges) or the approximate rounds mode (AE_CE_HOGWILD, by name); the other modes need the whole graph on one device");
-        const uint64_t world = (uint64_t)comm_world(dist.comm), rank = (uint64_t)comm_rank(dist.comm);
-        if (g->n < world * ((uint64_t)g->max_nbng + 8)) fail(AE_ERR_INVALID_ARG, "graph too small for %llu ranks", (unsigned long long)world);
-        const uint64_t base = g->n / world, rem = g->n % world;  // contiguous ranges, the remainder spread over the first ranks
-        lo = rank * base + std::min(rank, rem);
-        hi = lo + base + (rank < rem ? 1 : 0);
-        comm_broadcast_f32(dist.comm, d_y0, g->n * params.asked_dim, 0);
+            fail(AE_ERR_INVALID_ARG, "a multi-GPU embedding runs the time-sliced mode (ce_mode = AE_CE_AUTO / AE_CE_SLICED: faithful) or the approximate rounds mode "
+                                     "(AE_CE_HOGWILD, by name); the other modes need the whole graph on one device");
+        const uint32_t world = (uint32_t)comm_world(dist.comm), rank = (uint32_t)comm_rank(dist.comm);
+        if (g->n < (uint64_t)world * ((uint64_t)g->max_nbng + 8)) fail(AE_ERR_INVALID_ARG, "graph too small for %u ranks", world);
+        comm_broadcast_f32(dist.comm, d_y0, g->n * dim, 0);
+        // rank 0's partition on every rank: order + ranges + report
+        int32_t code = AE_OK;
+        std::string msg;
+        DevBuf<uint32_t> head(2 * (size_t)world * 2 + 16);   // ranges (as u32 pairs lo/hi words), status, report
+        std::vector<uint32_t> hhead(head.n, 0u);
+        if (rank == 0) {
+            try {
+                if (dist.part_y) partition_nodes_device(g, np->proba.p, dist.part_y, dist.part_dim, dist.part_dim, world, part);
+                else partition_nodes_device(g, np->proba.p, d_y0, (uint32_t)dim, (uint32_t)dim, world, part);
+            } catch (const Error& e) {
+                code = e.code;
+                msg = e.msg;
+            }
+            if (code == AE_OK) {
+                for (uint32_t x = 0; x < 2 * world; x++) { hhead[2 * x] = (uint32_t)part.ranges[x]; hhead[2 * x + 1] = (uint32_t)(part.ranges[x] >> 32); }
+                double rep[3] = {part.cross_mass, part.cross_mass_worst_rank, part.imbalance};
+                memcpy(&hhead[4 * world + 2], rep, sizeof(rep));
+                hhead[4 * world + 8] = (uint32_t)part.components; hhead[4 * world + 9] = (uint32_t)(part.components >> 32);
+                hhead[4 * world + 10] = (uint32_t)part.splits;
+            }
+            hhead[4 * world] = (uint32_t)code;
+        }
+        head.upload(hhead.data(), hhead.size());
+        sync();
+        comm_broadcast_u32(dist.comm, head.p, head.n, 0);
+        hhead = head.to_host();
+        if (hhead[4 * world] != AE_OK) {
+            if (rank == 0) fail(code, "%s", msg.c_str());
+            fail((int32_t)hhead[4 * world], "rank 0 could not partition the graph (its own message says why)");
+        }
+        if (rank != 0) {
+            part.ranges.resize(2 * (size_t)world);
+            for (uint32_t x = 0; x < 2 * world; x++) part.ranges[x] = (uint64_t)hhead[2 * x] | ((uint64_t)hhead[2 * x + 1] << 32);
+            double rep[3];
+            memcpy(rep, &hhead[4 * world + 2], sizeof(rep));
+            part.cross_mass = rep[0]; part.cross_mass_worst_rank = rep[1]; part.imbalance = rep[2];
+            part.components = (uint64_t)hhead[4 * world + 8] | ((uint64_t)hhead[4 * world + 9] << 32);
+            part.splits = hhead[4 * world + 10];
+            part.order.alloc(g->n);
+            part.perm.alloc(g->n);
+        }
+        comm_broadcast_u32(dist.comm, part.order.p, g->n, 0);
+        comm_broadcast_u32(dist.comm, part.perm.p, g->n, 0);
+        if (dist.report) {
+            dist.report->components = part.components;
+            dist.report->splits = part.splits;
+            dist.report->cross_mass = part.cross_mass;
+            dist.report->cross_mass_worst_rank = part.cross_mass_worst_rank;
+            dist.report->imbalance = part.imbalance;
+        }
+        // every rank takes the same decision from the same numbers (the time-sliced mode; the rounds mode is approximate anyway)
+        if (params.ce_mode != AE_CE_HOGWILD && part.cross_mass_worst_rank > ce_slice_max_cross_mass() && !debug_knob("AE_SL_ANY_PARTITION"))
+            fail(AE_ERR_INVALID_ARG, "multi-GPU embedding over %u ranks: after the locality partition %.1f %% of a rank's edge probability mass still lies on cross-rank edges "
+                                     "(limit %.0f %%; %.1f %% over all edges): this graph does not shard in the faithful mode -- run it on one device, or ask for the approximate "
+                                     "rounds mode (AE_CE_HOGWILD)", world, 100. * part.cross_mass_worst_rank, 100. * ce_slice_max_cross_mass(), 100. * part.cross_mass);
+        // the relabelled problem
+        np_part.proba.release();
+        g_part.reset(kgraph_permuted_device(g, part.order.p, part.perm.p, np->proba.p, &np_part.proba));
+        np_part.g = g_part.get();
+        np_part.scale.alloc(g->n);
+        permute_rows_device(np->scale.p, np_part.scale.p, g->n, 1, part.order.p, false);
+        y0_part.alloc(g->n * dim);
+        permute_rows_device(d_y0, y0_part.p, g->n, (uint32_t)dim, part.order.p, false);
+        if (!hub.empty()) {
+            const std::vector<uint32_t> ho = part.order.to_host();
+            std::vector<uint32_t> h2(g->n);
+            for (uint64_t p = 0; p < g->n; p++) h2[p] = hub[ho[p]];
+            out.hubness = hub;   // (reported in the caller's order)
+            hub.swap(h2);
+        }
+        sync();
+        gr = g_part.get();
+        npr = &np_part;
+        y0r = y0_part.p;
+        lo = part.ranges[2 * rank];
+        hi = part.ranges[2 * rank + 1];
     }
-    ae_entropy_optim* o = entropy_optim_create_impl(g, np, &params, d_y0, true, hub.empty() ? nullptr : hub.data(), lo, hi);
+    ae_entropy_optim* o = entropy_optim_create_impl(gr, npr, &params, y0r, true, hub.empty() ? nullptr : hub.data(), lo, hi);
     try {
         if (dist.active()) entropy_optim_attach_comm(o, dist.comm, dist.exchanges);
         double ce = 0.;
@@ -132,7 +223,11 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
         const uint64_t nb_sample = params.nb_sampling_by_edge * nnz;  // :858
         for (uint64_t iter = 1; iter <= params.nb_grad_batch; iter++) {  // :873
             const double step = params.grad_step * (1. - (double)iter / (double)params.nb_grad_batch);  // :875
-            rc_check(ae_entropy_optim_gradient_iteration(o, nb_sample, step, iter));
+            const int32_t rc = ae_entropy_optim_gradient_iteration(o, nb_sample, step, iter);
+            // a batch that failed on one rank (it still joined the batch's exchanges: ce_slice.hip) ends the loop on every rank
+            if (dist.active() && comm_all_reduce_sum(dist.comm, rc == AE_OK ? 0. : 1.) > 0. && rc == AE_OK)
+                fail(AE_ERR_STATE, "a CE batch failed on another rank (its own message says why)");
+            rc_check(rc);
         }
         double ms;
         uint64_t cnt;
@@ -145,8 +240,14 @@ void entropy_optimize_device(const ae_kgraph* g, const ae_node_params* np, const
         out.y.alloc(g->n * params.asked_dim);
         AE_HIP(hipMemcpy2DAsync(out.y.p, sizeof(float) * params.asked_dim, dy, sizeof(float) * stride, sizeof(float) * params.asked_dim, g->n,
                                 hipMemcpyDeviceToDevice, stream()));
+        if (dist.active()) {   // back to the caller's node order
+            DevBuf<float> back(g->n * dim);
+            permute_rows_device(out.y.p, back.p, g->n, (uint32_t)dim, part.order.p, true);
+            sync();
+            out.y = std::move(back);
+        }
         sync();
-        out.hubness = std::move(hub);
+        if (!dist.active()) out.hubness = std::move(hub);
     } catch (...) {
         ae_entropy_optim_destroy(o);
         throw;
@@ -185,7 +286,25 @@ void one_step_embed_device(const ae_kgraph* g, const ae_embedder_params& params,
     to_proba_edges_device(g, (float)params.scale_rho, (float)params.beta, &np);  // :351-355
     if (dist.active()) comm_broadcast_f32(dist.comm, y0.p, n * dim, 0);  // (before it is reported: get_initial_embedding is rank 0's everywhere)
     if (initial_out) { initial_out->resize(n * dim); y0.download(initial_out->data(), n * dim); }
-    entropy_optimize_device(g, &np, params, y0.p, out, dist);  // :356
+    // A random start says nothing about the graph: a multi-GPU run then bisects along diffusion-map coordinates computed for the
+    // partition alone (rank 0 is the one that partitions; a graph the diffusion map refuses -- e.g. disconnected: a degenerate
+    // spectrum -- is packed by its components and, where one must be cut, cut along the random start: refused if that crosses too much)
+    DevBuf<float> part_y;
+    Dist stage = dist;
+    if (dist.active() && !params.dmap_init && comm_rank(dist.comm) == 0) {
+        try {
+            ae_diffusion_params dp;
+            memset(&dp, 0, sizeof(dp));
+            const uint64_t pd = std::min<uint64_t>(std::max<uint64_t>(dim, 2), 8);
+            dp.asked_dim = pd; dp.alfa = 0.5f; dp.beta = -0.1f; dp.epsil = 2.0f; dp.t = 5.0f; dp.has_t = 1; dp.gnbn = 12; dp.has_gnbn = 1;
+            ae_laplacian lap;
+            dmap_laplacian_device(g, &dp, 0, &lap);
+            if (embed_from_laplacian_device(&lap, pd, dp.t, true, part_y, nullptr) == pd) { stage.part_y = part_y.p; stage.part_dim = (uint32_t)pd; }
+        } catch (const Error&) {
+            stage.part_y = nullptr;
+        }
+    }
+    entropy_optimize_device(g, &np, params, y0.p, out, stage);  // :356
 }
 
 // h_embed, embedder.rs:194-295
@@ -272,6 +391,8 @@ int32_t ae_embedder_embed(ae_embedder* e) {
         Dist dist;
         dist.comm = e->comm;
         dist.exchanges = e->comm_exchanges;
+        dist.report = &e->partition;
+        e->has_partition = dist.active();
         if (e->g) one_step_embed_device(e->g, e->params, res, &e->initial_embedding, dist);  // :184-186
         else h_embed_device(e->proj, e->params, res, &e->initial_embedding, dist);           // :187-190
         e->embedding.resize(e->n * e->params.asked_dim);
@@ -333,6 +454,13 @@ int32_t ae_embedder_get_quality_estimate_from_edge_length(const ae_embedder* e, 
     const ae_kgraph* g = e->g ? e->g : e->proj->large_graph;  // :481-487
     return ae_quality_estimate_from_edge_length(g, e->embedding.data(), (uint32_t)(e->embedding.size() / e->n), nbng, rep, ratio_by_node,
                                                 first_dist);
+}
+int32_t ae_embedder_get_partition_report(const ae_embedder* e, ae_partition_report* report) {
+    return guard([&] {
+        if (!e || !report) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (!e->done || !e->has_partition) fail(AE_ERR_STATE, "no partition: get_partition_report is for a multi-GPU embed()");
+        *report = e->partition;
+    });
 }
 int32_t ae_embedder_get_cross_entropy(const ae_embedder* e, double* before, double* after) {
     return guard([&] {

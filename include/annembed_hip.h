@@ -101,7 +101,7 @@ enum {
        cross entropy 0.6-1.07x the sequential loop's).  The five negatives of a sample are read from an LDS
        tile of rows the wave loads once per round: T consecutive rows from a uniform random start (uniform sampler; every
        node equally likely, as embedder.rs:1121), T alias-table draws (hubness-weighted sampler, from 2^20 nodes on).
-       The only mode that shards over devices.  asked_dim <= 32 and rows of <= 32 neighbours
+       Shards over devices (so does the faithful AE_CE_SLICED).  asked_dim <= 32 and rows of <= 32 neighbours
        (longer rows: asked_dim in {2,3,4,8,16}); anything else fails with AE_ERR_INVALID_ARG. */
     AE_CE_HOGWILD = 0,
     /* Deterministic: the result of executing samples 0,1,2,... of the reference's `gradient_iteration`
@@ -396,8 +396,8 @@ int32_t ae_comm_init_hostmem(int32_t rank, int32_t world, const char *name, uint
 int32_t ae_comm_destroy(ae_comm *c);
 int32_t ae_comm_all_reduce_sum(ae_comm *c, double *value);
 int32_t ae_entropy_optim_set_comm(ae_entropy_optim *o, ae_comm *c, uint32_t exchanges_per_batch);
-/* bytes of coordinate rows this rank has RECEIVED through the exchanges of its batches since the handle was created (n x row stride x 4
-   per exchange) -- the volume a scaling estimate needs */
+/* bytes of coordinate rows this rank has RECEIVED through the exchanges of its batches since the handle was created (the other
+   ranks' rows x row stride x 4 per exchange, in both sharding modes) -- the volume a scaling estimate needs */
 int32_t ae_entropy_optim_comm_bytes(const ae_entropy_optim *o, uint64_t *bytes);
 /* The sharded protocol on ONE device (validation; no reference counterpart): one batch of `world` rounds-mode handles of
  * the same graph whose node ranges tile [0, n) in order, run in lockstep -- round r of every shard, then, at the exchange
@@ -468,9 +468,33 @@ int32_t ae_embedder_destroy(ae_embedder *e);
    embedding is broadcast (the replicas start bit-identical), rank r optimises the r-th contiguous share of the source nodes
    (both stages of a hierarchical embedding), the coordinate rows are all-gathered `exchanges_per_batch` times per CE batch
    inside the library, the reported cross entropies are sums over the ranks, and after embed() every rank holds the whole
-   embedding.  Only the rounds mode shards: params.ce_mode must be AE_CE_HOGWILD (approximate -- DESIGN 5 -- so it is never
-   chosen silently); embed() fails with AE_ERR_INVALID_ARG otherwise.  A NULL or one-rank communicator changes nothing. */
+   embedding IN THE CALLER'S NODE ORDER.  The graph may come in any node order (the reference's is file order): embed() partitions
+   it by locality first (ae_kgraph_partition below, on rank 0, broadcast), runs on the relabelled graph and hands the rows back in
+   the caller's order; a partition that still leaves more than 10 % of a rank's edge mass on cross-rank edges is refused on every
+   rank alike (AE_ERR_INVALID_ARG).  ce_mode: AE_CE_AUTO / AE_CE_SLICED (the faithful time-sliced mode) or AE_CE_HOGWILD (the
+   approximate rounds mode, by name).  A NULL or one-rank communicator changes nothing. */
 int32_t ae_embedder_set_comm(ae_embedder *e, ae_comm *comm, uint32_t exchanges_per_batch);
+/* The locality partition a multi-GPU embed() applies internally (partition.hip; SURVEY 8e "contiguous node ranges ... after
+   locality reordering").  The reference numbers its nodes in IndexSet insertion order of the HNSW points -- file order,
+   src/fromhnsw/kgraph.rs:489,500 -- so contiguous id ranges of the caller's graph would cut (world - 1) / world of the edges.
+   ae_kgraph_partition: connected components (packed whole into the ranks: a graph of separated clusters is cut nowhere), a
+   component that must be split is split by recursive coordinate bisection of `y` (n x dim, host; e.g. the diffusion-map
+   initialisation; NULL: id order -- a partition, not a good one).  np (may be NULL) weighs the report's edges with their
+   probabilities.  order[pos] = the caller's id of the node at position pos; ranges[2 r], ranges[2 r + 1] = rank r's positions.
+   ae_kgraph_permuted: the same graph with the node at position p = node order[p] (rows keep their distance order): what the
+   ranks create their sharded ae_entropy_optim on; coordinates come back through order (y_caller[order[p]] = y[p]). */
+typedef struct ae_partition_report {
+    uint64_t components;          /* connected components of the undirected graph */
+    uint64_t splits;              /* components (or pieces) cut by coordinate bisection */
+    double cross_mass;            /* share of the edge (probability) mass on edges whose ends lie in different ranges */
+    double cross_mass_worst_rank; /* the largest share any one rank sees among the edges with an end in its range */
+    double imbalance;             /* largest range / (n / world) - 1 */
+} ae_partition_report;
+int32_t ae_kgraph_partition(const ae_kgraph *g, const ae_node_params *np, const float *y, uint64_t dim, uint32_t world,
+                            uint32_t *order, uint64_t *ranges, ae_partition_report *report);
+int32_t ae_kgraph_permuted(const ae_kgraph *g, const uint32_t *order, ae_kgraph **out);
+/* the report of the partition the last multi-GPU embed() applied (AE_ERR_STATE before it, or after a one-rank embed) */
+int32_t ae_embedder_get_partition_report(const ae_embedder *e, ae_partition_report *report);
 /* Embedder::embed (embedder.rs:183): one_step_embed (:298) or h_embed (:194). Ok(1) -> AE_OK */
 int32_t ae_embedder_embed(ae_embedder *e);
 int32_t ae_embedder_get_nb_nodes(const ae_embedder *e, uint64_t *n);          /* :785 */

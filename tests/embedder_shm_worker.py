@@ -1,7 +1,7 @@
 """worker of tests/test_gpu_parity.py::test_embedder_multi_gpu_entry_two_ranks_one_gpu: one rank of a two-rank embedding through
 the library's Embedder-level entry (ae_embedder_set_comm) over the shared-memory communicator; both ranks share this box's GPU.
-usage: embedder_shm_worker.py <dir> <rank> <world> <segment name> <flat|hier|faithful>
-(faithful: the default mode -- AE_CE_AUTO on the ranks' node ranges = the time-sliced mode -- on a graph whose node ids are in locality order)"""
+usage: embedder_shm_worker.py <dir> <rank> <world> <segment name> <flat|hier|faithful|faithful_dmap>
+(faithful: the default mode -- AE_CE_AUTO on the ranks' node ranges = the time-sliced mode -- on a graph in ANY node order: embed() partitions it)"""
 import os
 import sys
 
@@ -20,11 +20,15 @@ def main():
     n = len(g0["indptr"]) - 1
     comm = HostMemComm(rank, world, name, n * 64 * 4)
     par = A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD, grad_step=1.0)
-    if kind == "faithful":
-        par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=False)   # ce_mode = AE_CE_AUTO
+    if kind in ("faithful", "faithful_dmap"):
+        # ce_mode = AE_CE_AUTO; the graph comes in ANY node order: embed() partitions it by locality itself
+        par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=kind == "faithful_dmap")
         e = A.Embedder(g, par)
         e.set_comm(comm, 2)
         assert e.embed() == 1
+        import json
+        with open(os.path.join(out_dir, "part_%s_rank%d.json" % (kind, rank)), "w") as f:
+            json.dump(e.get_partition_report(), f)
         np.save(os.path.join(out_dir, "y_%s_rank%d.npy" % (kind, rank)), e.get_embedded())
         np.save(os.path.join(out_dir, "y0_%s_rank%d.npy" % (kind, rank)), e.get_initial_embedding())
         np.save(os.path.join(out_dir, "ce_%s_rank%d.npy" % (kind, rank)), np.array(e.get_cross_entropy()))
@@ -36,7 +40,7 @@ def main():
     else:
         e = A.Embedder(g, par)
     e.set_comm(comm, 2)
-    bad = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2))  # AE_CE_AUTO shards through the time-sliced mode, which refuses this node order (random: half of the edge mass crosses the two shards)
+    bad = A.Embedder(g, A.EmbedderParams(nb_grad_batch=2, ce_mode=A.AE_CE_SEQUENTIAL))  # the bit-exact mode needs the whole graph on one device: refused on every rank
     bad.set_comm(comm, 1)
     try:
         bad.embed()

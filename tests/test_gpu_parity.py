@@ -1116,12 +1116,16 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(kind):
         assert j["faithful"] is False
 
 
-def test_embedder_multi_gpu_entry_faithful_two_ranks_one_gpu(A, tmp_path):
+@pytest.mark.parametrize("kind", ["faithful", "faithful_dmap"])
+def test_embedder_multi_gpu_entry_faithful_two_ranks_one_gpu(A, tmp_path, kind):
     """Embedder::embed (embedder.rs:183-371) on two ranks in the DEFAULT mode: with a communicator attached AE_CE_AUTO resolves to the
-    time-sliced mode on each rank's node range (verdict r3, item 3).  Graph: 20 000 points in 8 well separated components, node ids in
-    component order (the two ranges cut no component), random initialisation broadcast from rank 0.  Both ranks end with the same
-    embedding; it is the reference's: final CE within 3 %, edge-length quartiles within 6 % of the one-device run in the sequential mode
-    from the same initial embedding."""
+    time-sliced mode on each rank's node range.  The graphs come in the REFERENCE's kind of node order -- ids shuffled globally (file
+    order carries no locality, kgraph.rs:489,500): embed() partitions them itself (partition.hip) and returns the rows in the caller's
+    order.  faithful: 20 000 points in 8 well separated components, random start broadcast from rank 0 -- the components are packed whole,
+    no edge crosses.  faithful_dmap: ONE component (20 000 points uniform in a square), diffusion-map start -- the component is bisected
+    along the initialisation, ~1 % of the edge mass crosses.  Both ranks end with the same embedding; it is the reference's: final CE within
+    3 %, edge-length quartiles within 6 % of the one-device run in the sequential mode from the same initial embedding."""
+    import json
     import subprocess
     import sys
     sys_argv = sys.argv
@@ -1129,29 +1133,41 @@ def test_embedder_multi_gpu_entry_faithful_two_ranks_one_gpu(A, tmp_path):
     import bench
     sys.argv = sys_argv
     n, k = 20000, 6
-    x, bounds = bench.mixture_points_gpu(n, 16, 8, seed=6, mean_sigma=10.0)
-    indptr, nbr, dist = bench.component_knn_graph(A, x, bounds, k, permute_seed=None)
+    if kind == "faithful":
+        x, bounds = bench.mixture_points_gpu(n, 16, 8, seed=6, mean_sigma=10.0)
+        indptr, nbr, dist = bench.component_knn_graph(A, x, bounds, k, permute_seed=11)   # ids shuffled globally
+    else:
+        x = np.random.default_rng(8).random((n, 2)).astype(np.float32)   # (rows in random order already: ids carry no locality)
+        indptr, nbr, dist = A.KGraph.bruteforce_l2(x, k).get_neighbours()
     np.savez(tmp_path / "graph.npz", indptr=indptr, nbr=nbr, dist=dist)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name = "annembed_test_%d_faithful" % os.getpid()
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "embedder_shm_worker.py"), str(tmp_path), str(r), "2", name, "faithful"],
+    name = "annembed_test_%d_%s" % (os.getpid(), kind)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "embedder_shm_worker.py"), str(tmp_path), str(r), "2", name, kind],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so[-1500:], se[-3000:])
-    ya, yb = np.load(tmp_path / "y_faithful_rank0.npy"), np.load(tmp_path / "y_faithful_rank1.npy")
-    ia, ib = np.load(tmp_path / "y0_faithful_rank0.npy"), np.load(tmp_path / "y0_faithful_rank1.npy")
-    ca, cb = np.load(tmp_path / "ce_faithful_rank0.npy"), np.load(tmp_path / "ce_faithful_rank1.npy")
+    ya, yb = np.load(tmp_path / ("y_%s_rank0.npy" % kind)), np.load(tmp_path / ("y_%s_rank1.npy" % kind))
+    ia, ib = np.load(tmp_path / ("y0_%s_rank0.npy" % kind)), np.load(tmp_path / ("y0_%s_rank1.npy" % kind))
+    ca, cb = np.load(tmp_path / ("ce_%s_rank0.npy" % kind)), np.load(tmp_path / ("ce_%s_rank1.npy" % kind))
     assert np.array_equal(ia, ib) and np.array_equal(ya, yb) and np.isfinite(ya).all() and np.array_equal(ca, cb)
-    # the same schedule on one device in the sequential mode, from the same initial embedding
+    reps = [json.load(open(tmp_path / ("part_%s_rank%d.json" % (kind, r)))) for r in range(2)]
+    assert reps[0] == reps[1]   # rank 0's partition, broadcast
+    print("two-rank embed() partition:", reps[0])
+    if kind == "faithful":
+        assert reps[0]["components"] == 8 and reps[0]["cross_mass"] == 0.0 and reps[0]["splits"] == 0
+    else:
+        assert reps[0]["splits"] >= 1 and 0.0 < reps[0]["cross_mass"] < 0.04, reps[0]
+    # the same schedule on one device in the sequential mode, from the same initial embedding (the caller's node order on both sides)
     g = A.KGraph(indptr, nbr, dist)
     npar = A.to_proba_edges(g, 1.0, 1.0)
     par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, ce_mode=A.AE_CE_SEQUENTIAL)
-    yr, _, cer = A.entropy_optimize(g, npar, par, ia)
+    yr, ce0, cer = A.entropy_optimize(g, npar, par, ia)
+    assert abs(ca[0] - ce0) < 1e-5 * ce0   # the initial cross entropy: the relabelled problem is the same problem
     src = np.repeat(np.arange(n), k)
     q = np.quantile(np.linalg.norm(ya[src] - ya[nbr], axis=1), [0.25, 0.5, 0.75])
     qr = np.quantile(np.linalg.norm(yr[src] - yr[nbr], axis=1), [0.25, 0.5, 0.75])
-    print("faithful two-rank embed(): CE ratio %.4f, quartile ratios %s" % (ca[1] / cer, np.round(q / qr, 3)))
+    print("faithful two-rank embed() [%s]: CE ratio %.4f, quartile ratios %s" % (kind, ca[1] / cer, np.round(q / qr, 3)))
     assert abs(ca[1] - cer) < 0.03 * cer, (ca, cer)
     assert np.all(np.abs(q - qr) < 0.06 * qr), (q, qr)
 
