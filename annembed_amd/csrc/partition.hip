@@ -18,7 +18,10 @@
 //      (the diffusion-map initialisation, or the projection initialisation of the hierarchical embedding: embedder.rs:231-269 --
 //      both place graph neighbours near each other): its nodes are sorted along the axis of largest variance of the piece and cut
 //      at the count the packing asks for; pieces are split again along THEIR widest axis further down the recursion (recursive
-//      coordinate bisection).  Without coordinates a piece is cut in id order (a partition, not a good one).
+//      coordinate bisection).  The coordinates are first SMOOTHED ON THE GRAPH (a few dozen lazy random-walk steps inside the piece:
+//      what is left are its slow modes, the directions a short cut is perpendicular to -- the reference's rank-20 / 5-iteration
+//      initialisation resolves clusters, not the slow modes of a sheet), and the cut is then polished by a balanced majority vote of
+//      the nodes along it.  Without coordinates the walk starts from noise (a partition; a worse one).
 //
 // Output: order[pos] = caller's id of the node at position pos, the ranks' position ranges, and a report (components, splits,
 // cross-range edge mass as the sharded time-sliced mode will see it, imbalance).
@@ -139,6 +142,11 @@ __global__ void __launch_bounds__(256) piece_stats_kernel(const uint32_t* __rest
     if (threadIdx.x < 2 * dim)
         out[(uint64_t)blockIdx.x * 2 * dim + threadIdx.x] = s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x];
 }
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
 // floats in an order-preserving u32 encoding
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -151,6 +159,141 @@ __global__ void __launch_bounds__(256) piece_keys_kernel(const uint32_t* __restr
     const uint32_t v = order[b + p];
     const float f = y[(uint64_t)v * stride + axis];
     keys[p] = ordered_bits(f == f ? f : 0.f);
+    vals[p] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the coordinates a piece is cut along: the caller's, smoothed on the graph
+// ---------------------------------------------------------------------------------------------
+// z (kZ columns per node) starts as the first columns of the caller's coordinates (or hashed noise when there are none) and takes
+// lazy random-walk steps restricted to the piece: z_u <- (z_u + mean of z over u's out-neighbours inside the piece) / 2.  A step
+// damps a mode of wavelength L hops by ~(1 - c / L^2): a few dozen steps remove everything shorter than ~10 hops and leave the slow
+// modes -- the directions a short cut is perpendicular to (power iteration towards the Fiedler vectors, started from an embedding
+// that already knows the clusters).  Pure gathers: deterministic.
+constexpr uint32_t kZ = 4;
+__global__ void __launch_bounds__(256) smooth_init_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, const float* __restrict__ y, uint32_t ydim,
+                                                          uint32_t ystride, float* __restrict__ z, uint8_t* __restrict__ side) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t v = order[b + p];
+    side[v] = 1;
+    for (uint32_t a = 0; a < kZ; a++) {
+        float f;
+        if (y && a < ydim) { f = y[(uint64_t)v * ystride + a]; f = f == f ? f : 0.f; }
+        else f = (float)(pcg_hash(v * kZ + a + 0x51ED270Bu) >> 8) * (1.0f / 16777216.0f) - 0.5f;
+        z[(uint64_t)v * kZ + a] = f;
+    }
+}
+__global__ void __launch_bounds__(256) smooth_step_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint32_t uniform_k, const uint64_t* __restrict__ indptr,
+                                                          const uint32_t* __restrict__ nbr, const uint8_t* __restrict__ side, const float* __restrict__ z, float* __restrict__ z2) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t u = order[b + p];
+    uint64_t rb, re;
+    if (uniform_k) { rb = (uint64_t)u * uniform_k; re = rb + uniform_k; } else { rb = indptr[u]; re = indptr[u + 1]; }
+    float acc[kZ] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t cnt = 0;
+    for (uint64_t x = rb; x < re; x++) {
+        const uint32_t v = nbr[x];
+        if (!side[v]) continue;
+        const float4 zv = *reinterpret_cast<const float4*>(z + (uint64_t)v * kZ);
+        acc[0] += zv.x; acc[1] += zv.y; acc[2] += zv.z; acc[3] += zv.w;
+        cnt++;
+    }
+    const float4 zu = *reinterpret_cast<const float4*>(z + (uint64_t)u * kZ);
+    float4 out = zu;
+    if (cnt) {
+        const float inv = 0.5f / (float)cnt;
+        out.x = 0.5f * zu.x + inv * acc[0]; out.y = 0.5f * zu.y + inv * acc[1]; out.z = 0.5f * zu.z + inv * acc[2]; out.w = 0.5f * zu.w + inv * acc[3];
+    }
+    *reinterpret_cast<float4*>(z2 + (uint64_t)u * kZ) = out;
+}
+// z <- (z - mean) / std per column (the constant is the walk's dominant mode: it goes; f32 range is kept)
+struct ZNorm { float mean[kZ], inv_std[kZ]; };
+__global__ void __launch_bounds__(256) smooth_norm_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, ZNorm nm, float* __restrict__ z) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t v = order[b + p];
+    for (uint32_t a = 0; a < kZ; a++) z[(uint64_t)v * kZ + a] = (z[(uint64_t)v * kZ + a] - nm.mean[a]) * nm.inv_std[a];
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement of a bisection: balanced majority vote along the cut
+// ---------------------------------------------------------------------------------------------
+// The coordinates a piece is cut along are as good as the embedding they come from, and the reference's diffusion-map initialisation
+// (rank 20, 5 subspace iterations: graphlaplace.rs:97-125) resolves clusters, not the slow modes of a sheet: on a graph without
+// clusters its level sets are wiggly curves and the coordinate cut is several times longer than it has to be.  So the cut is smoothed
+// on the GRAPH: every node of the piece adds up the (quantised) probability mass of its edges -- both directions -- to its own side and to
+// the other; nodes that would cut less mass on the other side are candidates, half of them (a coin per node and round: neighbours do not
+// swap places for ever) move, the same number from either side (the larger candidate set is thinned by a hash threshold; the sides'
+// sizes are steered back to the target every round).  Integer atomics only: the result does not depend on the order of execution.
+constexpr uint8_t kSideNone = 0, kSideLeft = 1, kSideRight = 2;
+__global__ void __launch_bounds__(256) refine_set_side_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint64_t left_count, uint8_t* __restrict__ side,
+                                                              int32_t* __restrict__ gain, int clear) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t v = order[b + p];
+    if (clear) { side[v] = kSideNone; return; }
+    side[v] = p < left_count ? kSideLeft : kSideRight;
+    gain[v] = 0;
+}
+__global__ void __launch_bounds__(256) refine_gain_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint32_t uniform_k, const uint64_t* __restrict__ indptr,
+                                                          const uint32_t* __restrict__ nbr, const float* __restrict__ proba, const uint8_t* __restrict__ side,
+                                                          int32_t* __restrict__ gain) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t u = order[b + p];
+    uint64_t rb, re;
+    if (uniform_k) { rb = (uint64_t)u * uniform_k; re = rb + uniform_k; } else { rb = indptr[u]; re = indptr[u + 1]; }
+    const uint8_t su = side[u];
+    int32_t mine = 0;
+    for (uint64_t x = rb; x < re; x++) {
+        const uint32_t v = nbr[x];
+        const uint8_t sv = side[v];
+        if (sv == kSideNone) continue;   // an edge out of the piece: it is cut (or not) whatever side u takes... by another bisection
+        const int32_t w = proba ? max(1, (int32_t)(proba[x] * 4096.f)) : 1;
+        const int32_t s = su == sv ? -w : w;
+        mine += s;
+        atomicAdd(gain + v, s);
+    }
+    if (mine) atomicAdd(gain + u, mine);
+}
+// counts[0 / 1]: candidates on the left / right (gain > 0 and this round's coin)
+__global__ void __launch_bounds__(256) refine_count_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, const uint8_t* __restrict__ side,
+                                                           const int32_t* __restrict__ gain, uint32_t round_key, unsigned long long* __restrict__ counts) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    unsigned long long cl = 0, cr = 0;
+    if (p < count) {
+        const uint32_t v = order[b + p];
+        if (gain[v] > 0 && (pcg_hash(v ^ round_key) & 1u)) { if (side[v] == kSideLeft) cl = 1; else cr = 1; }
+    }
+    for (int off = 32; off > 0; off >>= 1) { cl += __shfl_xor(cl, off); cr += __shfl_xor(cr, off); }
+    if ((threadIdx.x & 63) == 0) { if (cl) atomicAdd(counts, cl); if (cr) atomicAdd(counts + 1, cr); }
+}
+// candidates move with probability thr / 2^32 of their side; gains are cleared for the next round; counts[2]: moved left -> right, [3]: right -> left
+__global__ void __launch_bounds__(256) refine_move_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint8_t* __restrict__ side, int32_t* __restrict__ gain,
+                                                          uint32_t round_key, uint32_t thr_left, uint32_t thr_right, unsigned long long* __restrict__ counts) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    unsigned long long ml = 0, mr = 0;
+    if (p < count) {
+        const uint32_t v = order[b + p];
+        const uint8_t sv = side[v];
+        if (gain[v] > 0 && (pcg_hash(v ^ round_key) & 1u)) {
+            const uint32_t h = pcg_hash(v * 0x9E3779B9u + round_key);
+            if (sv == kSideLeft && h <= thr_left) { side[v] = kSideRight; ml = 1; }
+            else if (sv == kSideRight && h <= thr_right) { side[v] = kSideLeft; mr = 1; }
+        }
+        gain[v] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { ml += __shfl_xor(ml, off); mr += __shfl_xor(mr, off); }
+    if ((threadIdx.x & 63) == 0) { if (ml) atomicAdd(counts + 2, ml); if (mr) atomicAdd(counts + 3, mr); }
+}
+__global__ void __launch_bounds__(256) refine_keys_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, const uint8_t* __restrict__ side,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t v = order[b + p];
+    keys[p] = side[v] == kSideLeft ? 0u : 1u;
     vals[p] = v;
 }
 
@@ -319,28 +462,104 @@ void partition_nodes_device(const ae_kgraph* g, const float* d_proba, const floa
     uint64_t splits = 0;
     DevBuf<double> d_stats;
     DevBuf<uint32_t> skeys, skeys2, svals, svals2;
+    DevBuf<uint8_t> d_side;
+    DevBuf<float> d_z, d_z2;
+    DevBuf<int32_t> d_gain;
+    DevBuf<unsigned long long> d_counts;
     auto split_piece = [&](const Piece& pc, uint64_t left_count, Piece& left, Piece& right) {
         // sort order[begin, begin + size) along the piece's widest axis; the first left_count nodes are the left piece
-        if (d_y && pc.size > 1) {
+        if (pc.size > 1 && (d_y || !debug_knob("AE_PART_NO_SMOOTH"))) {
             if (!d_stats.n) d_stats.alloc_pooled((size_t)kStatBlocks * 2 * 64);
-            const unsigned sg = (unsigned)std::min<uint64_t>(kStatBlocks, (pc.size + 255) / 256);
-            hipLaunchKernelGGL(piece_stats_kernel, dim3(sg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.begin + pc.size, d_y, ydim, ystride, d_stats.p);
-            std::vector<double> hs((size_t)sg * 2 * ydim);
-            d_stats.download(hs.data(), hs.size());
-            uint32_t axis = 0;
-            double best = -1.;
-            for (uint32_t a = 0; a < ydim; a++) {
-                double s = 0., q = 0.;
-                for (unsigned bk = 0; bk < sg; bk++) { s += hs[(size_t)bk * 2 * ydim + 2 * a]; q += hs[(size_t)bk * 2 * ydim + 2 * a + 1]; }
-                const double mean = s / (double)pc.size, var = q / (double)pc.size - mean * mean;
-                if (var > best) { best = var; axis = a; }
-            }
+            if (!d_side.n) { d_side.alloc_pooled(n); d_side.zero(); d_gain.alloc_pooled(n); d_counts.alloc_pooled(4); }
             if (skeys.n < pc.size) { skeys.alloc_pooled(pc.size); skeys2.alloc_pooled(pc.size); svals.alloc_pooled(pc.size); svals2.alloc_pooled(pc.size); }
-            hipLaunchKernelGGL(piece_keys_kernel, dim3(blocks_for(pc.size, 256)), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, d_y, axis, ystride,
-                               skeys.p, svals.p);
-            sort_pairs_u32_u32(skeys.p, skeys2.p, svals.p, svals2.p, pc.size, 32);
-            AE_HIP(hipMemcpyAsync(order.p + pc.begin, svals2.p, sizeof(uint32_t) * pc.size, hipMemcpyDeviceToDevice, stream()));
+            const unsigned sg = (unsigned)std::min<uint64_t>(kStatBlocks, (pc.size + 255) / 256), pg = blocks_for(pc.size, 256);
+            // per-column mean / standard deviation of `arr` (stride `st`, `nc` columns) over the piece, blocks added in order
+            auto column_stats = [&](const float* arr, uint32_t nc, uint32_t st, std::vector<double>& mean, std::vector<double>& sd) {
+                hipLaunchKernelGGL(piece_stats_kernel, dim3(sg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.begin + pc.size, arr, nc, st, d_stats.p);
+                std::vector<double> hs((size_t)sg * 2 * nc);
+                d_stats.download(hs.data(), hs.size());
+                mean.assign(nc, 0.); sd.assign(nc, 0.);
+                for (uint32_t a = 0; a < nc; a++) {
+                    double sum = 0., q = 0.;
+                    for (unsigned bk = 0; bk < sg; bk++) { sum += hs[(size_t)bk * 2 * nc + 2 * a]; q += hs[(size_t)bk * 2 * nc + 2 * a + 1]; }
+                    mean[a] = sum / (double)pc.size;
+                    sd[a] = std::sqrt(std::max(0., q / (double)pc.size - mean[a] * mean[a]));
+                }
+            };
+            const float* key_src = d_y;
+            uint32_t key_stride = ystride, axis = 0;
+            std::vector<double> mean, sd;
+            const int blocks = debug_knob("AE_PART_NO_SMOOTH") ? 0 : (debug_knob("AE_PART_SMOOTH") ? atoi(debug_knob("AE_PART_SMOOTH")) : (d_y ? 12 : 32));
+            if (blocks > 0 && pc.size >= 64) {
+                // blocks of 8 walk steps, normalised in between; the column that decays least over the last block is the smoothest
+                if (!d_z.n) { d_z.alloc_pooled(n * kZ); d_z2.alloc_pooled(n * kZ); }
+                hipLaunchKernelGGL(smooth_init_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, d_y, ydim, ystride, d_z.p, d_side.p);
+                std::vector<double> keep(kZ, 0.);
+                for (int blk = 0; blk < blocks; blk++) {
+                    column_stats(d_z.p, kZ, kZ, mean, sd);
+                    ZNorm nm;
+                    for (uint32_t a = 0; a < kZ; a++) { nm.mean[a] = (float)mean[a]; nm.inv_std[a] = sd[a] > 1e-30 ? (float)(1.0 / sd[a]) : 0.f; }
+                    hipLaunchKernelGGL(smooth_norm_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, nm, d_z.p);
+                    for (int st = 0; st < 8; st++) {
+                        hipLaunchKernelGGL(smooth_step_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, g->uniform_k,
+                                           (const uint64_t*)g->indptr.p, (const uint32_t*)g->nbr.p, (const uint8_t*)d_side.p, (const float*)d_z.p, d_z2.p);
+                        std::swap(d_z.p, d_z2.p);
+                    }
+                }
+                column_stats(d_z.p, kZ, kZ, mean, sd);   // (every column entered the last block with deviation 1)
+                double best = -1.;
+                for (uint32_t a = 0; a < kZ; a++) if (sd[a] > best) { best = sd[a]; axis = a; }
+                hipLaunchKernelGGL(refine_set_side_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, 0ull, d_side.p, d_gain.p, 1);
+                key_src = d_z.p;
+                key_stride = kZ;
+            } else if (d_y) {   // the caller's coordinates as they are: the widest axis
+                column_stats(d_y, ydim, ystride, mean, sd);
+                double best = -1.;
+                for (uint32_t a = 0; a < ydim; a++) if (sd[a] > best) { best = sd[a]; axis = a; }
+            }
+            if (key_src) {
+                hipLaunchKernelGGL(piece_keys_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, key_src, axis, key_stride, skeys.p, svals.p);
+                sort_pairs_u32_u32(skeys.p, skeys2.p, svals.p, svals2.p, pc.size, 32);
+                AE_HIP(hipMemcpyAsync(order.p + pc.begin, svals2.p, sizeof(uint32_t) * pc.size, hipMemcpyDeviceToDevice, stream()));
+            }
             check_launch("partition: bisection");
+        }
+        // the cut, smoothed on the graph (see the refine_* kernels); the sides keep their sizes to within a fraction of a per cent
+        if (pc.size >= 64 && left_count >= 16 && pc.size - left_count >= 16 && !debug_knob("AE_PART_NO_REFINE")) {
+            if (!d_side.n) { d_side.alloc_pooled(n); d_side.zero(); d_gain.alloc_pooled(n); d_counts.alloc_pooled(4); }
+            if (skeys.n < pc.size) { skeys.alloc_pooled(pc.size); skeys2.alloc_pooled(pc.size); svals.alloc_pooled(pc.size); svals2.alloc_pooled(pc.size); }
+            const unsigned pg = blocks_for(pc.size, 256);
+            hipLaunchKernelGGL(refine_set_side_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, left_count, d_side.p, d_gain.p, 0);
+            int64_t left_now = (int64_t)left_count;
+            const int rounds_max = debug_knob("AE_PART_ROUNDS") ? atoi(debug_knob("AE_PART_ROUNDS")) : 96;
+            for (int round = 0; round < rounds_max; round++) {
+                const uint32_t round_key = 0x9E3779B9u * (uint32_t)(round + 1) + (uint32_t)splits * 0x85EBCA6Bu;
+                d_counts.zero();
+                hipLaunchKernelGGL(refine_gain_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, g->uniform_k, (const uint64_t*)g->indptr.p,
+                                   (const uint32_t*)g->nbr.p, d_proba, (const uint8_t*)d_side.p, d_gain.p);
+                hipLaunchKernelGGL(refine_count_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, (const uint8_t*)d_side.p,
+                                   (const int32_t*)d_gain.p, round_key, d_counts.p);
+                unsigned long long hc[4];
+                d_counts.download(hc, 4);
+                // how many may move each way: the same number, corrected by what the sides are off their target
+                const int64_t off = left_now - (int64_t)left_count;   // > 0: the left side is too big
+                double want_l = (double)std::min(hc[0], hc[1]), want_r = want_l;
+                if (off > 0) want_l = std::min((double)hc[0], want_l + (double)off); else want_r = std::min((double)hc[1], want_r - (double)off);
+                if (want_l + want_r < 1.0) break;
+                auto thr = [](double want, unsigned long long have) { return have ? (uint32_t)std::min(4294967295.0, want / (double)have * 4294967296.0) : 0u; };
+                hipLaunchKernelGGL(refine_move_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, d_side.p, d_gain.p, round_key,
+                                   thr(want_l, hc[0]), thr(want_r, hc[1]), d_counts.p);
+                d_counts.download(hc, 4);
+                left_now += (int64_t)hc[3] - (int64_t)hc[2];
+                if (hc[2] + hc[3] < std::max<uint64_t>(2, pc.size / 20000)) break;
+            }
+            hipLaunchKernelGGL(refine_keys_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, (const uint8_t*)d_side.p, skeys.p, svals.p);
+            sort_pairs_u32_u32(skeys.p, skeys2.p, svals.p, svals2.p, pc.size, 1);
+            AE_HIP(hipMemcpyAsync(order.p + pc.begin, svals2.p, sizeof(uint32_t) * pc.size, hipMemcpyDeviceToDevice, stream()));
+            hipLaunchKernelGGL(refine_set_side_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, 0ull, d_side.p, d_gain.p, 1);
+            check_launch("partition: refinement");
+            sync();
+            if (left_now > 0 && left_now < (int64_t)pc.size) left_count = (uint64_t)left_now;
         }
         left = Piece{pc.begin, left_count};
         right = Piece{pc.begin + left_count, pc.size - left_count};

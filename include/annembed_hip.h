@@ -471,7 +471,9 @@ int32_t ae_embedder_destroy(ae_embedder *e);
    embedding IN THE CALLER'S NODE ORDER.  The graph may come in any node order (the reference's is file order): embed() partitions
    it by locality first (ae_kgraph_partition below, on rank 0, broadcast), runs on the relabelled graph and hands the rows back in
    the caller's order; a partition that still leaves more than 10 % of a rank's edge mass on cross-rank edges is refused on every
-   rank alike (AE_ERR_INVALID_ARG).  ce_mode: AE_CE_AUTO / AE_CE_SLICED (the faithful time-sliced mode) or AE_CE_HOGWILD (the
+   rank alike (AE_ERR_INVALID_ARG).  exchanges_per_batch = 0 leaves the number to the library: 4 where (next to) nothing crosses the
+   ranks, 8 below 3 % of a rank's edge mass, 16 above (cross-rank edges fire against replicas as old as the last exchange; measured
+   in tools/run_part_fidelity.py).  ce_mode: AE_CE_AUTO / AE_CE_SLICED (the faithful time-sliced mode) or AE_CE_HOGWILD (the
    approximate rounds mode, by name).  A NULL or one-rank communicator changes nothing. */
 int32_t ae_embedder_set_comm(ae_embedder *e, ae_comm *comm, uint32_t exchanges_per_batch);
 /* The locality partition a multi-GPU embed() applies internally (partition.hip; SURVEY 8e "contiguous node ranges ... after

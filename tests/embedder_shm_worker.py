@@ -24,7 +24,7 @@ def main():
         # ce_mode = AE_CE_AUTO; the graph comes in ANY node order: embed() partitions it by locality itself
         par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=kind == "faithful_dmap")
         e = A.Embedder(g, par)
-        e.set_comm(comm, 2)
+        e.set_comm(comm, int(os.environ.get("AE_TEST_EXCHANGES", "0")))   # 0: the library's choice (4 per batch)
         assert e.embed() == 1
         import json
         with open(os.path.join(out_dir, "part_%s_rank%d.json" % (kind, rank)), "w") as f:

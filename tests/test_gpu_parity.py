@@ -548,9 +548,12 @@ def test_unsupported_shape_fails_loudly(A, oracle):
     with pytest.raises(A.AnnembedError) as e:  # the rounds mode has no kernel for 64 columns: no silent fall-back to the racy per-sample kernel
         eo.gradient_iteration_threaded(1000, 1.0, 1)
     assert e.value.code == 1
-    with pytest.raises(A.AnnembedError) as e:  # AE_CE_AUTO shards through the time-sliced mode -- which refuses a partition with most of its edge mass across shards (random order)
-        A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=40), y0, node_lo=0, node_hi=300)
-    assert e.value.code == 1
+    # AE_CE_AUTO shards through the time-sliced mode -- which refuses a partition with most of its edge mass across shards (random order):
+    # with the range's first batch (a range with a communicator: on every rank alike when it is attached)
+    sh = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=40), y0, node_lo=0, node_hi=300)
+    with pytest.raises(A.AnnembedError) as e:
+        sh.gradient_iteration_threaded(10 * sh.get_nb_edges(), 1.0, 1)
+    assert e.value.code == 1 and "cross-shard" in str(e.value)
     y0 = y0[:, :2].copy()
     ev = A.EntropyOptim(g, A.NodeParams.from_host(g, p0, s0), A.EmbedderParams(asked_dim=2, ce_mode=A.AE_CE_EVENT), y0, node_lo=0, node_hi=300)
     with pytest.raises(A.AnnembedError) as e:  # the event-ordered kernel does not shard: says so instead of running something else
@@ -916,8 +919,10 @@ def test_device_coords_alias_and_sharded_hogwild(A, oracle, graph):
     shards = []
     for r in range(2):
         lo, hi = shard_range(2500, 2, r)
+        auto = A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0, node_lo=lo, node_hi=hi)
         with pytest.raises(A.AnnembedError):  # AE_CE_AUTO on a shard = the time-sliced mode, which refuses a node order with > 10 % of the edge mass across shards
-            A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5), y0, node_lo=lo, node_hi=hi)
+            auto.gradient_iteration_threaded(10 * auto.get_nb_edges(), 1.0, 1)
+        del auto
         shards.append((lo, hi, A.EntropyOptim(g, npar, A.EmbedderParams(nb_grad_batch=5, ce_mode=A.AE_CE_HOGWILD), y0, node_lo=lo, node_hi=hi)))
     views = [device_tensor(eo) for _, _, eo in shards]
     assert views[0].shape == (2500, 2) and views[0].is_cuda
