@@ -9,12 +9,12 @@ from ._lib import (AE_CE_AUTO, AE_CE_EVENT, AE_CE_HOGWILD, AE_CE_ORDERED, AE_CE_
                    load)
 from .api import (DiffusionMaps, DiffusionParams, Embedder, EmbedderParams, EntropyOptim, GraphLaplacian, KGraph,  # noqa: F401
                   KGraphProjection, MatRepr, NodeParams, QualityReport, RangeApprox, RangePrecision, RangeRank, SvdApprox, SvdResult, entropy_optimize,
-                  adaptative_range_finder_matrep, quality_estimate_from_edge_length, set_data_box, subspace_iteration, to_proba_edges, transpose_dense_mult_csr)
+                  adaptative_range_finder_matrep, quality_estimate_from_edge_length, set_data_box, subspace_iteration, to_proba_edges, transpose_dense_mult_csr, set_summation_order)
 
 __all__ = [
     "KGraph", "KGraphProjection", "NodeParams", "EmbedderParams", "DiffusionParams", "Embedder", "EntropyOptim",
     "DiffusionMaps", "GraphLaplacian", "MatRepr", "RangeRank", "SvdApprox", "SvdResult", "to_proba_edges", "set_data_box",
     "entropy_optimize", "subspace_iteration", "transpose_dense_mult_csr", "QualityReport", "quality_estimate_from_edge_length", "RangePrecision", "RangeApprox",
     "adaptative_range_finder_matrep",
-    "AnnembedError", "load",
+    "set_summation_order", "AnnembedError", "load",
 ]

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ae_set_device": [_i32],
     "ae_synchronize": [],
     "ae_get_stream": [_P(_vp)],
+    "ae_set_summation_order": [_u32],
     "ae_embedder_params_default": [_P(CEmbedderParams)],
     "ae_diffusion_params_new": [_P(CDiffusionParams), _u64, _f32, _u8, _u64, _u8],
     "ae_diffusion_params_set_alfa": [_P(CDiffusionParams), _f32],
@@ -99,6 +100,7 @@ SIGNATURES = {
     "ae_kgraph_get_neighbours": [_vp, _vp, _vp, _vp],
     "ae_kgraph_fill_l2_distances": [_vp, _vp, _u64],
     "ae_kgraph_bruteforce_l2": [_vp, _u64, _u64, _u32, _P(_vp)],
+    "ae_kgraph_bruteforce_l2_grouped": [_vp, _u64, _u64, _u32, _vp, _u32, _P(_vp), _vp],
     "ae_kgraph_hubness": [_vp, _vp],
     "ae_kgraph_projection_create": [_vp, _vp, _vp, _vp, _P(_vp)],
     "ae_kgraph_projection_destroy": [_vp],

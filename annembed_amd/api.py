@@ -137,6 +137,11 @@ def _partition_report(rep):
             "cross_mass_worst_rank": float(rep.cross_mass_worst_rank), "imbalance": float(rep.imbalance)}
 
 
+def set_summation_order(tree):
+    """ae_set_summation_order: True = f64 tree reductions in the stage-level entry points, False = the reference's sequential f32 order"""
+    check(L.load().ae_set_summation_order(1 if tree else 0))
+
+
 class KGraph(_Handle):
     """KGraph<f32>, src/fromhnsw/kgraph.rs:109-120, resident on the GPU as a CSR."""
 
@@ -191,6 +196,18 @@ class KGraph(_Handle):
         h = C.c_void_p()
         check(L.load().ae_kgraph_bruteforce_l2(ptr(x), x.shape[0], x.shape[1], nbng, C.byref(h)))
         return cls._wrap(h)
+
+    @classmethod
+    def bruteforce_l2_grouped(cls, x, nbng, bounds):
+        """the exact global kNN graph of points sorted into groups (ae_kgraph_bruteforce_l2_grouped); `.knn_stats` = (fallback rows,
+        pairs of the pruned phase, pairs inside the groups)"""
+        x, bounds = _f32(x), _u64(bounds)
+        h = C.c_void_p()
+        st = np.zeros(3, np.uint64)
+        check(L.load().ae_kgraph_bruteforce_l2_grouped(ptr(x), x.shape[0], x.shape[1], nbng, ptr(bounds), len(bounds) - 1, C.byref(h), ptr(st)))
+        g = cls._wrap(h)
+        g.knn_stats = tuple(int(v) for v in st)
+        return g
 
     def partition(self, world, y=None, node_params=None):
         """Locality partition into `world` contiguous ranges (ae_kgraph_partition; no reference counterpart: SURVEY 8e "after locality

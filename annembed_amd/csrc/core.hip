@@ -170,16 +170,20 @@ __global__ void row_sort_kernel(uint64_t n, const uint64_t* __restrict__ indptr,
 // kNN producer (knn.hip reaches the same rows on the matrix cores and uses this kernel for the rows it cannot certify).
 // `rows` (optional) lists the queries; blockIdx.y selects a chunk of the points, the per-chunk lists are merged by
 // knn_merge_chunks_kernel (chunks ascending + strict comparisons: among equal distances the smaller index wins).
+// Rectangular form (knn.hip's grouped producer): query t is place p = rows[t] (or t) of a list whose entry p is point qrows[p] (or
+// q_begin + p); the points are the range [p_begin, n).
 template <int TILE>
-__global__ void __launch_bounds__(256) bruteforce_knn_kernel(const float* __restrict__ x, uint64_t n, uint64_t dim, uint32_t k,
-                                                             const uint32_t* __restrict__ rows, uint64_t nrows, uint64_t chunk_len,
-                                                             uint32_t* __restrict__ out_nbr, float* __restrict__ out_d2) {
+__global__ void __launch_bounds__(256) bruteforce_knn_kernel(const float* __restrict__ x, uint64_t p_begin, uint64_t n, uint64_t dim, uint32_t k,
+                                                             const uint32_t* __restrict__ rows, const uint32_t* __restrict__ qrows, uint64_t q_begin,
+                                                             uint64_t nrows, uint64_t chunk_len,
+                                                             uint32_t* __restrict__ out_nbr, float* __restrict__ out_d2, const uint32_t* __restrict__ orig) {
     extern __shared__ float tile[];  // TILE x dimchunk
     constexpr int DC = 32;           // coordinates per chunk
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const bool active = t < nrows;
-    const uint64_t q = active ? (rows ? rows[t] : t) : 0;
-    const uint64_t c_begin = blockIdx.y * chunk_len, c_end = c_begin + chunk_len < n ? c_begin + chunk_len : n;
+    const uint64_t place = active ? (rows ? rows[t] : t) : 0;
+    const uint64_t q = active ? (qrows ? (uint64_t)qrows[place] : q_begin + place) : p_begin;
+    const uint64_t c_begin = p_begin + blockIdx.y * chunk_len, c_end = c_begin + chunk_len < n ? c_begin + chunk_len : n;
     float* best_d = out_d2 + (t * gridDim.y + blockIdx.y) * k;  // kept sorted ascending in global (L2 resident), k small
     uint32_t* best_i = out_nbr + (t * gridDim.y + blockIdx.y) * k;
     if (active)
@@ -218,42 +222,63 @@ __global__ void __launch_bounds__(256) bruteforce_knn_kernel(const float* __rest
                 uint64_t c = c0 + s;
                 if (c >= c_end || c == q) continue;
                 float d = acc[s];
-                if (!(d < best_d[k - 1])) continue;
-                uint32_t pos = k - 1;
-                while (pos > 0 && d < best_d[pos - 1]) {
-                    best_d[pos] = best_d[pos - 1];
-                    best_i[pos] = best_i[pos - 1];
-                    pos--;
+                if (!orig) {   // points in the caller's order: scanning ascending, a strict comparison keeps the smaller index among equals
+                    if (!(d < best_d[k - 1])) continue;
+                    uint32_t pos = k - 1;
+                    while (pos > 0 && d < best_d[pos - 1]) {
+                        best_d[pos] = best_d[pos - 1];
+                        best_i[pos] = best_i[pos - 1];
+                        pos--;
+                    }
+                    best_d[pos] = d;
+                    best_i[pos] = (uint32_t)c;
+                } else {       // points reordered internally (knn.hip's grouped producer): ties by the caller's ids
+                    const uint32_t oc = orig[c];
+                    auto before = [&](uint32_t slot) { return d < best_d[slot] || (d == best_d[slot] && best_i[slot] != 0xFFFFFFFFu && oc < orig[best_i[slot]]); };
+                    if (!before(k - 1)) continue;
+                    uint32_t pos = k - 1;
+                    while (pos > 0 && before(pos - 1)) {
+                        best_d[pos] = best_d[pos - 1];
+                        best_i[pos] = best_i[pos - 1];
+                        pos--;
+                    }
+                    best_d[pos] = d;
+                    best_i[pos] = (uint32_t)c;
                 }
-                best_d[pos] = d;
-                best_i[pos] = (uint32_t)c;
             }
         }
     }
 }
 // thread per query: the k smallest (d2, index) of its per-chunk lists, written as row `q` of the graph (sqrt applied)
-__global__ void knn_merge_chunks_kernel(const uint32_t* __restrict__ rows, uint64_t nrows, uint32_t chunks, uint32_t k,
-                                        const uint32_t* __restrict__ part_i, const float* __restrict__ part_d,
-                                        uint32_t* __restrict__ nbr, float* __restrict__ dist) {
+__global__ void knn_merge_chunks_kernel(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ qrows, uint64_t q_begin, uint64_t nrows, uint32_t chunks,
+                                        uint32_t k, const uint32_t* __restrict__ part_i, const float* __restrict__ part_d,
+                                        uint32_t* __restrict__ nbr, float* __restrict__ dist, int out_by_list, int raw, const uint32_t* __restrict__ orig) {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= nrows) return;
-    const uint64_t q = rows ? rows[t] : t;
+    const uint64_t place = rows ? rows[t] : t;
+    const uint64_t q = out_by_list ? place : (qrows ? (uint64_t)qrows[place] : q_begin + place);
     float* bd = dist + q * k;
     uint32_t* bi = nbr + q * k;
     for (uint32_t s = 0; s < k; s++) { bd[s] = INFINITY; bi[s] = 0xFFFFFFFFu; }
     for (uint64_t e = t * chunks * k; e < (t + 1) * chunks * k; e++) {
         const float d = part_d[e];
-        if (!(d < bd[k - 1])) continue;
+        const uint32_t pi = part_i[e];
+        if (pi == 0xFFFFFFFFu) continue;
+        auto before = [&](uint32_t slot) {
+            return d < bd[slot] || (orig && d == bd[slot] && bi[slot] != 0xFFFFFFFFu && orig[pi] < orig[bi[slot]]);
+        };
+        if (!before(k - 1)) continue;
         uint32_t pos = k - 1;
-        while (pos > 0 && d < bd[pos - 1]) {
+        while (pos > 0 && before(pos - 1)) {
             bd[pos] = bd[pos - 1];
             bi[pos] = bi[pos - 1];
             pos--;
         }
         bd[pos] = d;
-        bi[pos] = part_i[e];
+        bi[pos] = pi;
     }
-    for (uint32_t s = 0; s < k; s++) bd[s] = sqrtf(bd[s]);
+    if (!raw)
+        for (uint32_t s = 0; s < k; s++) bd[s] = sqrtf(bd[s]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -287,25 +312,32 @@ static void finish_kgraph(ae_kgraph* g) {
 }
 
 namespace ae {
-// exact brute force for the listed rows (nullptr: rows 0..nrows-1); few rows are spread over many point chunks
-void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint32_t* d_rows, uint64_t nrows,
-                         uint32_t* d_nbr, float* d_dist) {
+// exact brute force for the listed places of a query list against the points [p_begin, p_end) (see bruteforce_knn_kernel); few rows
+// are spread over many point chunks
+void bruteforce_knn_rect(const float* d_x, uint64_t dim, uint32_t k, const uint32_t* d_qrows, uint64_t q_begin, const uint32_t* d_places, uint64_t nrows,
+                         uint64_t p_begin, uint64_t p_end, uint32_t* d_nbr, float* d_dist, bool out_by_list, bool raw, const uint32_t* d_orig) {
     if (nrows == 0) return;
     constexpr int TILE = 32;
+    const uint64_t np = p_end - p_begin;
     const uint64_t row_blocks = blocks_for(nrows, 256);
-    uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / row_blocks), std::max<uint64_t>(1, n / 128));
+    uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, 2048 / row_blocks), std::max<uint64_t>(1, np / 128));
     chunks = std::min<uint32_t>(chunks, 1024);
-    const uint64_t chunk_len = (n + chunks - 1) / chunks;
+    const uint64_t chunk_len = (np + chunks - 1) / chunks;
     DevBuf<uint32_t> part_i;
     DevBuf<float> part_d;
     part_i.alloc_pooled(nrows * chunks * k);
     part_d.alloc_pooled(nrows * chunks * k);
-    hipLaunchKernelGGL((bruteforce_knn_kernel<TILE>), dim3((unsigned)row_blocks, chunks), dim3(256), TILE * 32 * sizeof(float), stream(), d_x,
-                       n, dim, k, d_rows, nrows, chunk_len, part_i.p, part_d.p);
+    hipLaunchKernelGGL((bruteforce_knn_kernel<TILE>), dim3((unsigned)row_blocks, chunks), dim3(256), TILE * 32 * sizeof(float), stream(), d_x, p_begin, p_end,
+                       dim, k, d_places, d_qrows, q_begin, nrows, chunk_len, part_i.p, part_d.p, d_orig);
     check_launch("bruteforce_knn");
-    hipLaunchKernelGGL(knn_merge_chunks_kernel, dim3((unsigned)row_blocks), dim3(256), 0, stream(), d_rows, nrows, chunks, k,
-                       (const uint32_t*)part_i.p, (const float*)part_d.p, d_nbr, d_dist);
+    hipLaunchKernelGGL(knn_merge_chunks_kernel, dim3((unsigned)row_blocks), dim3(256), 0, stream(), d_places, d_qrows, q_begin, nrows, chunks, k,
+                       (const uint32_t*)part_i.p, (const float*)part_d.p, d_nbr, d_dist, out_by_list ? 1 : 0, raw ? 1 : 0, d_orig);
     check_launch("knn_merge_chunks");
+}
+// exact brute force for the listed rows (nullptr: rows 0..nrows-1) against all n points
+void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint32_t* d_rows, uint64_t nrows,
+                         uint32_t* d_nbr, float* d_dist) {
+    bruteforce_knn_rect(d_x, dim, k, nullptr, 0, d_rows, nrows, 0, n, d_nbr, d_dist, false, false, nullptr);
 }
 }  // namespace ae
 
@@ -332,6 +364,12 @@ int32_t ae_synchronize(void) {
     return guard([&] {
         require_device();
         sync();
+    });
+}
+int32_t ae_set_summation_order(uint32_t order) {
+    return guard([&] {
+        if (order != AE_SUM_REFERENCE_ORDER && order != AE_SUM_TREE) fail(AE_ERR_INVALID_ARG, "unknown summation order %u", order);
+        set_tree_sums_default(order == AE_SUM_TREE);
     });
 }
 int32_t ae_get_stream(void** s) {
@@ -570,6 +608,32 @@ int32_t ae_kgraph_bruteforce_l2(const float* x, uint64_t n, uint64_t dim, uint32
         } else {
             bruteforce_knn_rows(dx.p, n, dim, nbng, nullptr, n, g->nbr.p, g->dist.p);
         }
+        finish_kgraph(g.get());
+        *out = g.release();
+    });
+}
+
+int32_t ae_kgraph_bruteforce_l2_grouped(const float* x, uint64_t n, uint64_t dim, uint32_t nbng, const uint64_t* bounds, uint32_t groups, ae_kgraph** out,
+                                        uint64_t* stats3) {
+    return guard([&] {
+        require_device();
+        if (!x || !out || !bounds || n < 2 || dim == 0 || nbng == 0 || nbng >= n || nbng + 8 > 64) fail(AE_ERR_INVALID_ARG, "bad arguments (nbng <= 56)");
+        DevBuf<float> dx;
+        dx.alloc(n * dim);
+        dx.upload(x, n * dim);
+        std::unique_ptr<ae_kgraph> g(new ae_kgraph);
+        g->n = n;
+        g->max_nbng = nbng;
+        g->nnz = n * nbng;
+        std::vector<uint64_t> indptr(n + 1);
+        for (uint64_t i = 0; i <= n; i++) indptr[i] = i * nbng;
+        g->indptr.alloc(n + 1);
+        g->indptr.upload(indptr.data(), n + 1);
+        g->nbr.alloc(g->nnz);
+        g->dist.alloc(g->nnz);
+        uint64_t st[3] = {0, 0, 0};
+        knn_grouped(dx.p, n, dim, nbng, bounds, groups, g->nbr.p, g->dist.p, st);
+        if (stats3) { stats3[0] = st[0]; stats3[1] = st[1]; stats3[2] = st[2]; }
         finish_kgraph(g.get());
         *out = g.release();
     });

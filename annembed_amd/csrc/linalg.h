@@ -47,6 +47,7 @@ struct TreeSums {
     bool prev;
 };
 bool tree_sums();
+void set_tree_sums_default(bool on);
 
 // exact sequential f32 sum (the reference's iter().sum::<f32>() order) of d_x[0..n) with stride
 float seq_sum_f32(const float* d_x, uint64_t n, uint64_t stride = 1);
@@ -59,4 +60,8 @@ float ndarray_sum_f32(const float* d_x, uint64_t n);
 uint64_t knn_mfma(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, uint32_t* d_nbr, float* d_dist);
 void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint32_t* d_rows, uint64_t nrows,
                          uint32_t* d_nbr, float* d_dist);
+void bruteforce_knn_rect(const float* d_x, uint64_t dim, uint32_t k, const uint32_t* d_qrows, uint64_t q_begin, const uint32_t* d_places, uint64_t nrows,
+                         uint64_t p_begin, uint64_t p_end, uint32_t* d_nbr, float* d_dist, bool out_by_list, bool raw, const uint32_t* d_orig);
+// exact GLOBAL kNN of points sorted into groups (clusters): own group first, then only the groups a triangle-inequality bound cannot exclude
+void knn_grouped(const float* d_x, uint64_t n, uint64_t dim, uint32_t k, const uint64_t* bounds, uint32_t groups, uint32_t* d_nbr, float* d_dist, uint64_t* stats);
 }  // namespace ae

@@ -912,9 +912,11 @@ __global__ void __launch_bounds__(128) tree_sum_cols_final_kernel(const double* 
     out[threadIdx.x] = (float)s;
 }
 static thread_local bool g_tree_sums = false;
+static bool g_tree_sums_default = false;   // ae_set_summation_order: what the stage-level entry points do outside an Embedder
 TreeSums::TreeSums(bool on) : prev(g_tree_sums) { g_tree_sums = on; }
 TreeSums::~TreeSums() { g_tree_sums = prev; }
-bool tree_sums() { return g_tree_sums; }
+bool tree_sums() { return g_tree_sums || g_tree_sums_default; }
+void set_tree_sums_default(bool on) { g_tree_sums_default = on; }
 // x: n rows of `dim` consecutive values, `stride` floats apart
 static void tree_sum_cols(const float* d_x, uint64_t n, uint32_t dim, uint64_t stride, float* host_out) {
     const uint32_t per = 256u / dim * dim;

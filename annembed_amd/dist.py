@@ -39,14 +39,15 @@ def shard_sizes(n, world):
 class ShardedCE:
     """Per-batch protocol: local gradient iteration, then all-gather of the owned rows."""
 
-    def __init__(self, backend, y_tensor, n, dim, rank, world, group=None, pre_gather=None):
+    def __init__(self, backend, y_tensor, n, dim, rank, world, group=None, pre_gather=None, ranges=None):
+        """ranges: [(lo, hi)] per rank (a locality partition's, KGraph.partition); None: equal shares"""
         import torch.distributed as dist
         self.dist = dist
         self.backend, self.y, self.n, self.dim = backend, y_tensor, n, dim
         self.rank, self.world, self.group = rank, world, group
-        self.lo, self.hi = shard_range(n, world, rank)
+        self.lo, self.hi = ranges[rank] if ranges is not None else shard_range(n, world, rank)
         self.pre_gather = pre_gather
-        sizes = shard_sizes(n, world)
+        sizes = [hi - lo for lo, hi in ranges] if ranges is not None else shard_sizes(n, world)
         self.equal = len(set(sizes)) == 1
         self.sizes = sizes
 

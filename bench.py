@@ -88,6 +88,34 @@ def svd_flops(n, nnz_a, l=20, nbiter=5):
             + 2 * n * l * l)
 
 
+def svd_bytes(n, nnz_a, l=20, nbiter=5):
+    """algorithmic HBM bytes of the same (each SpMM >= 8 nnz_A + 2 * 4 N l, each QR >= 2 * 4 N l per pass, two passes): 2 nbiter
+    products (the range iteration's 2 nbiter - 1 and B = Q^T A), 2 nbiter - 1 orthonormalisations, U = Q U_b"""
+    return 2 * nbiter * (8 * nnz_a + 8 * n * l) + (2 * nbiter - 1) * 2 * 8 * n * l + 8 * n * l
+
+
+def svd_init_of(A, L, kg, d, reps=3):
+    """the diffusion-map initialisation's randomized SVD (graphlaplace.rs:97-125: rank 20, 5 iterations) of a graph's laplacian, timed alone
+    (U stays in HBM as in the embedder's own call): ms, GFLOP/s and HBM fraction by the SURVEY 8d formulas"""
+    dp = A.DiffusionParams(d, 5.0, 12)
+    A.set_summation_order(True)   # (no bit-exact CE mode follows this call: f64 tree sums, as Embedder::embed chooses by itself)
+    t0 = time.perf_counter()
+    lap = A.DiffusionMaps(dp).laplacian_from_kgraph(kg)
+    L.check(L.load().ae_synchronize())
+    lap_s = time.perf_counter() - t0
+    A.set_summation_order(False)
+    _, n, nnz_a = lap.info()
+    lap.do_svd(want_u=False)  # warm
+    L.check(L.load().ae_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sv = lap.do_svd(want_u=False)
+    dt = (time.perf_counter() - t0) / reps
+    return {"ms": dt * 1e3, "gflops": svd_flops(n, nnz_a) / dt / 1e9, "hbm_gbps": svd_bytes(n, nnz_a) / dt / 1e9, "hbm_frac": svd_bytes(n, nnz_a) / dt / 8e12,
+            "nnz_laplacian": int(nnz_a), "nodes": int(n), "rank": 20, "nbiter": 5, "laplacian_build_ms": lap_s * 1e3,
+            "sigma_1_2_3": [float(v) for v in sv.get_sigma()[:3]] if hasattr(sv, "get_sigma") else None}
+
+
 def lattice_graph(n, k, seed, permute):
     """ring lattice (neighbours at Fibonacci offsets, gamma-distributed distances): a kNN-shaped graph at sizes where an
     exact kNN is out of reach of brute force.  permute: node ids are a random permutation of the ring positions, so that
@@ -301,7 +329,7 @@ def full_size_shape(A, L, which, d, steps):
     return out
 
 
-def scale_shape(A, L, name, n, k, d, steps, with_sequential, graph=None, hub_weighting=False, dmap_start=None):
+def scale_shape(A, L, name, n, k, d, steps, with_sequential, graph=None, hub_weighting=False, dmap_start=None, svd_init=False):
     """configs[2] / [3] / [4]-shard shapes on one GPU.  graph None: the node-permuted ring lattice (uniform in-degree: the best case of
     every faithful mode), started from its diffusion-map initialisation.  graph = dict(indptr, nbr, dist, desc, build_s): a kNN graph of
     the config's own data (real in-degree skew: hubs), started from a random layout in the 10-box (a component-wise kNN graph is
@@ -324,17 +352,27 @@ def scale_shape(A, L, name, n, k, d, steps, with_sequential, graph=None, hub_wei
     if hub_weighting:
         hub = hubv
         out["negative_sampling"] = "hubness-weighted (NodeSampler, embedder.rs:915-930)"
+    y0 = None
     if dmap_start if dmap_start is not None else graph is None:
-        t0 = time.perf_counter()
-        y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
-        L.check(L.load().ae_synchronize())
-        out["dmap_init_s"] = time.perf_counter() - t0
-        out["start"] = "diffusion-map initialisation"
-    else:
+        try:
+            t0 = time.perf_counter()
+            y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)
+            L.check(L.load().ae_synchronize())
+            out["dmap_init_s"] = time.perf_counter() - t0
+            out["start"] = "diffusion-map initialisation"
+            if svd_init:
+                out["svd_init"] = svd_init_of(A, L, kg, d)
+        except A.AnnembedError as e:   # e.g. a degenerate spectrum on a graph of many components
+            out["dmap_init_error"] = str(e)[:300]
+            y0 = None
+    if y0 is None:
         y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)
         out["start"] = "random normal layout in the 10-box"
     if graph is not None:
         out["graph_build_s"] = graph.get("build_s")
+        for key in ("edges_leaving_their_cluster", "knn_pairs"):
+            if key in graph:
+                out[key] = graph[key]
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
 
     def entry(r, faithful):
@@ -400,9 +438,33 @@ def config_graphs(A, which, permute_seed=9, n_override=None, shuffle_within_shar
     if shuffle_within_shards:
         from annembed_amd.dist import shard_range
         within = [shard_range(n, shuffle_within_shards, r) for r in range(shuffle_within_shards)]
-    indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed, shuffle_within=within)
+    if which == "c4":
+        # configs[3]'s graph as HNSW would give it (kgraph.rs:440-579: neighbours are GLOBAL): the exact global kNN graph through the
+        # grouped producer (own cluster first, then only the shells of the other clusters a triangle-inequality bound cannot exclude)
+        gk = A.KGraph.bruteforce_l2_grouped(x, k, bounds.astype(np.uint64))
+        knn_stats = gk.knn_stats
+        indptr, nbr, dist = gk.get_neighbours()
+        del gk
+        lab = np.searchsorted(bounds, np.arange(n), side="right") - 1
+        leaving = float((np.repeat(lab, k) != lab[nbr]).mean())
+        del lab
+        if permute_seed is not None:
+            perm = np.random.default_rng(permute_seed).permutation(n).astype(np.uint32)  # old id -> new id
+            inv = np.empty(n, np.int64)
+            inv[perm] = np.arange(n)
+            nbr = np.ascontiguousarray(perm[nbr.reshape(n, k)][inv].reshape(-1))
+            dist = np.ascontiguousarray(dist.reshape(n, k)[inv].reshape(-1))
+            del perm, inv
+    else:
+        indptr, nbr, dist = component_knn_graph(A, x, bounds, k, permute_seed=permute_seed, shuffle_within=within)
     del x
     t2 = time.perf_counter()
+    if which == "c4":
+        return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0, "k": k, "n": n, "edges_leaving_their_cluster": leaving,
+                "knn_pairs": {"fallback_rows": knn_stats[0], "pruned_phase": knn_stats[1], "inside_clusters": knn_stats[2], "all": float(n) * n},
+                "desc": "GLOBAL exact kNN graph (k = %d) of %d %s, node ids %s; points %.1f s, graph %.1f s (%.2f %% of the n^2 pairs computed; %.4f %% of the edges "
+                        "leave their cluster)" % (k, n, what, "randomly permuted" if permute_seed is not None else "in cluster order", t1 - t0, t2 - t1,
+                                                  100.0 * (knn_stats[1] + knn_stats[2]) / (float(n) * n), 100.0 * leaving)}
     return {"indptr": indptr, "nbr": nbr, "dist": dist, "build_s": t2 - t0, "k": k, "n": n,
             "desc": "kNN graph (k = %d) of %d %s, exact inside every component, node ids %s; points %.1f s, graph %.1f s" % (
                 k, n, what, "randomly permuted" if permute_seed is not None else
@@ -723,8 +785,11 @@ def main():
             "c3_knn_shape": scale_shape(A, L, "c3knn", 1_650_000, 6, 2, 6, with_sequential=True, hub_weighting=True, dmap_start=True,
                                         graph=exact_knn_graph(A, higgs_shaped_points(1_650_000), 6, "Higgs-shaped points (28-D, 64 components)")),
             # configs[3] on its own kind of graph: 11 M Higgs-shaped points, hubness weighting on as examples/higgs.rs:204-242
-            "c4_knn_shape": scale_shape(A, L, "c4knn", 11_000_000, 6, 8, 5, with_sequential=False, hub_weighting=True, graph=config_graphs(A, "c4")),
-            "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 5, with_sequential=True),
+            # (the global graph of these points falls into ~40 components -- 0.000x % of its edges leave their cluster --: the
+            # diffusion-map start is tried as the reference would, and timed: svd_init)
+            "c4_knn_shape": scale_shape(A, L, "c4knn", 11_000_000, 6, 8, 5, with_sequential=False, hub_weighting=True, graph=config_graphs(A, "c4"), dmap_start=True,
+                                        svd_init=True),
+            "c4_shape": scale_shape(A, L, "c4", 11_000_000, 6, 8, 5, with_sequential=True, svd_init=True),
             # configs[4]: one GPU's eighth of the 50 M nodes as a graph of its own (k = 10, 16-D) -- the mixture's kNN graph, then the lattice
             "c5_shard_knn_shape": scale_shape(A, L, "c5knn", 6_250_000, 10, 16, 5, with_sequential=False, graph=config_graphs(A, "c5")),
             "c5_shard_shape": scale_shape(A, L, "c5", 6_250_000, 10, 16, 5, with_sequential=False),
@@ -772,6 +837,7 @@ def main():
                            "the time-sliced mode, faithful where few edges cross shards (DESIGN 5); scale_shapes.c4_knn_shape is the same graph (node ids permuted) on one "
                            "GPU, c5_shard_knn_shape one eighth of configs[4]'s"),
         "svd_init": {"gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5},
+        "svd_init_c4": ((scale_shapes or {}).get("c4_knn_shape") or {}).get("svd_init") or ((scale_shapes or {}).get("c4_shape") or {}).get("svd_init"),
         "svd_dense": svd_dense,
         "knn_producer": knn_producer,
         "samples_per_s": head["nb_sample"] / (head["ms_per_step"] * 1e-3),
@@ -812,25 +878,42 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
         workload = "Higgs-11M-shaped ring lattice (node ids permuted) %d nodes -> %dD, k=%d, source nodes sharded over %d GPUs (configs[3], strong scaling, rounds mode)" % (n, d, k, world)
         scaling = "strong"
     else:
-        # configs[3] on its own kind of graph, FAITHFUL: the kNN graph of the Higgs-shaped points in COMPONENT order (a locality order: the
-        # contiguous node ranges of the ranks cut a few of the 64 components, nothing else crosses shards), hubness-weighted negatives
+        # configs[3] on its own kind of graph, FAITHFUL, in the REFERENCE's kind of node order: the kNN graph of the Higgs-shaped points with
+        # the node ids SHUFFLED GLOBALLY (file order carries no locality, kgraph.rs:489,500).  The library's partitioner
+        # (ae_kgraph_partition: connected components packed whole, what must be cut is bisected and smoothed on the graph) gives the
+        # ranks their contiguous ranges; every rank computes the same partition from the same graph (checked below).
         d = 8
-        # (inside a rank's range the ids are shuffled: the time-sliced mode on a sharded range works in the caller's labels, and a tile
-        # window of consecutive ids should not be one component -- DESIGN 4.3, "internal numbering")
-        gr = config_graphs(A, "c4", permute_seed=None, n_override=args.scale_nodes, shuffle_within_shards=world)
-        n, k, indptr, nbr, dst = gr["n"], gr["k"], gr["indptr"], gr["nbr"], gr["dist"]
-        lo, hi = shard_range(n, world, rank)
-        chk = torch.tensor([float(nbr[::1009].astype(np.float64).sum())], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        if world > 1:  # every rank built the graph itself: it must be the same graph
+        gr = config_graphs(A, "c4", permute_seed=9, n_override=args.scale_nodes)
+        n, k = gr["n"], gr["k"]
+        g0 = A.KGraph(gr["indptr"], gr["nbr"], gr["dist"], k)
+        t0 = time.perf_counter()
+        order, ranges, part = g0.partition(world)
+        part["seconds"] = time.perf_counter() - t0
+        naive_cross = 1.0 - 1.0 / world   # shuffled ids: contiguous id ranges would cut (world - 1) / world of the edges
+        kg_ready = g0.permuted(order)   # (the relabelled graph stays on the device)
+        nnz = len(gr["nbr"])
+        chk = torch.tensor([float(gr["nbr"][::1009].astype(np.float64).sum()), float(order[::997].astype(np.float64).sum())], dtype=torch.float64,
+                           device="cuda" if args.backend == "nccl" else "cpu")
+        del g0, gr
+        lo, hi = ranges[rank]
+        if world > 1:  # every rank built and partitioned the graph itself: it must be the same graph in the same order
             lo_hi = [chk.clone() for _ in range(world)]
             dist.all_gather(lo_hi, chk)
-            if any(float(v) != float(chk) for v in lo_hi):
-                raise SystemExit("the ranks built different graphs")
-        workload = "%s -> %dD, source nodes sharded over %d GPUs in contiguous ranges (configs[3], strong scaling, faithful time-sliced mode)" % (gr["desc"], d, world)
+            if any(bool((v != chk).any()) for v in lo_hi):
+                raise SystemExit("the ranks built different graphs / partitions")
+        workload = ("kNN graph (k = %d) of %d Higgs-shaped points (28-D, 64 components), node ids shuffled globally -> %dD, partitioned by the library into %d contiguous "
+                    "ranges (configs[3], strong scaling, faithful time-sliced mode)" % (k, n, d, world))
         scaling = "strong"
     faithful = not args.weak and not args.rounds
+    if not faithful:
+        ranges = [shard_range(n, world, r) for r in range(world)]
+    part_info = dict(part, naive_cross_mass_of_id_ranges=naive_cross) if faithful else None
     torch.cuda.empty_cache()
-    kg = A.KGraph(indptr, nbr, dst, k)
+    if faithful:
+        kg = kg_ready
+    else:
+        kg = A.KGraph(indptr, nbr, dst, k)
+        nnz = len(nbr)
     hub = kg.hubness() if faithful else None
     if faithful:
         y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)   # (a component-wise kNN graph is disconnected: no diffusion-map start)
@@ -861,9 +944,9 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
                 comm.close()
                 comm = None
             library_comm = False
-            torch_gather = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world)
+            torch_gather = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world, ranges=ranges)
     else:  # validation over gloo: ranks share a GPU, the exchange goes through torch (once per batch)
-        sharded = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world)
+        sharded = ShardedCE(HipBackend(eo), device_tensor(eo), n, d, rank, world, ranges=ranges)
     ce_before = eo.ce_compute_threaded()
 
     def one_step(it):
@@ -873,7 +956,7 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
         if sharded is not None:
             L.check(L.load().ae_synchronize())
             y_host = device_tensor(eo).cpu()
-            sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
+            sizes = [r_hi - r_lo for r_lo, r_hi in ranges]
             own = torch.zeros((max(sizes), d))
             own[:hi - lo] = y_host[lo:hi]
             parts = [torch.empty((max(sizes), d)) for _ in range(world)]  # gloo wants equal shapes: padded
@@ -929,8 +1012,9 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             "vs_baseline": None,
             "dtype": mode_dtype(resolved),
             "data": "synthetic" if args.backend == "nccl" else "synthetic (VALIDATION RUN over gloo, ranks sharing a GPU: not a result)",
-            "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * len(nbr)), "ce_mode": MODE_NAMES.get(resolved),
-                       "exchanges_per_batch": exch,
+            "config": {"workload": workload, "nb_sampling_by_edge": 10, "samples_per_step": int(10 * nnz), "ce_mode": MODE_NAMES.get(resolved),
+                       "exchanges_per_batch": exch, "rccl_ranks": world if library_comm else 0,
+                       "partition": part_info, "cross_shard_mass": (part_info or {}).get("cross_mass"),
                        "bytes_received_per_rank_and_batch": int(exch * n * d * 4),
                        "collective": "in-place RCCL all-gather of the owned rows inside ae_entropy_optim_gradient_iteration (library communicator)" if library_comm
                        else ("in-place RCCL all-gather through torch.distributed on the library stream (the library communicator failed: %s)" % comm_error if torch_gather is not None
@@ -945,7 +1029,7 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             "n1_like_for_like": ("the --gpus 1 line measures configs[1] in the default mode (its `value` is NOT the one-GPU point of this series); the same mode on ONE GPU on "
                                  "the node-permuted graph of the same points is its key scale_shapes.c4_knn_shape.default_mode (points_per_s, ms_per_step)" if resolved == 5 else
                                  "the --gpus 1 line's key scale_shapes.c4_shape.rounds_mode / rounds_mode (same shape and mode on one GPU)"),
-            "samples_per_s": 10 * len(nbr) * args.steps / elapsed,
+            "samples_per_s": 10 * nnz * args.steps / elapsed,
             "ce_before": ce0, "ce_after": ce_after,
         }
     if comm is not None:

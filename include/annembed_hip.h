@@ -58,6 +58,13 @@ int32_t ae_device_count(int32_t *count);
 int32_t ae_set_device(int32_t device);
 /* synchronise the library's stream on the current device */
 int32_t ae_synchronize(void);
+/* Summation order of the global f32 sums of the STAGE-LEVEL entry points (mean of the scales, column means of set_data_box, the
+   laplacian's normalisers ...).  AE_SUM_REFERENCE_ORDER (default): the reference's sequential f32 order, as single-lane chains -- what
+   bit parity with the oracle needs, 40-100 ms each at 11 M nodes.  AE_SUM_TREE: two-level f64 tree reductions (deterministic,
+   microseconds; the results differ from the reference order in the last bits).  ae_embedder_embed and ae_entropy_optim_create choose
+   by themselves: reference order exactly when the CE mode that follows is the bit-exact AE_CE_SEQUENTIAL. */
+enum { AE_SUM_REFERENCE_ORDER = 0, AE_SUM_TREE = 1 };
+int32_t ae_set_summation_order(uint32_t order);
 /* raw hipStream_t the library launches on (for hipEvent timing by the caller) */
 int32_t ae_get_stream(void **stream);
 
@@ -238,6 +245,14 @@ int32_t ae_kgraph_fill_l2_distances(ae_kgraph *g, const float *x, uint64_t dim);
    rows are exact for any input (knn.hip).  AE_KNN_LEGACY=1 forces the plain kernel. */
 int32_t ae_kgraph_bruteforce_l2(const float *x, uint64_t n, uint64_t dim, uint32_t nbng,
                                 ae_kgraph **out);
+/* The same graph -- the exact GLOBAL kNN rows, bit for bit -- of points that come SORTED INTO GROUPS (clusters; group g = rows
+   bounds[g] .. bounds[g + 1]): the k nearest inside the own group first, then, group by group, only the points a triangle-inequality
+   bound cannot exclude (|x - m_g| - max_y |y - m_g| against the point's current k-th distance) are run against the group.  What
+   brute force costs n^2 costs sum of squares of the groups plus the pairs the bound lets through (configs[3]'s 11 M Higgs-shaped
+   points in 64 overlapping clusters: DESIGN 7).  stats3 (may be NULL): rows recomputed by the brute-force fallback, query-point
+   pairs of the second phase, of the first.  nbng <= 56. */
+int32_t ae_kgraph_bruteforce_l2_grouped(const float *x, uint64_t n, uint64_t dim, uint32_t nbng, const uint64_t *bounds,
+                                        uint32_t groups, ae_kgraph **out, uint64_t *stats3);
 
 /* Hubness::new (src/fromhnsw/hubness.rs:39-76): in-degree count of every node. counts[n] */
 int32_t ae_kgraph_hubness(const ae_kgraph *g, uint32_t *counts);

@@ -154,6 +154,50 @@ def test_knn_producer_duplicates_and_ties(A, oracle, monkeypatch):
     assert np.array_equal(nb2, nb) and np.array_equal(ds2, ds)
 
 
+@pytest.mark.parametrize("n,dim,k,ncomp,spread", [(3000, 12, 6, 5, 2.0), (40000, 28, 6, 16, 2.0), (9000, 7, 10, 9, 30.0), (5000, 128, 10, 4, 10.0)])
+def test_grouped_knn_producer_is_the_global_exact_graph(A, oracle, n, dim, k, ncomp, spread):
+    """ae_kgraph_bruteforce_l2_grouped: the exact GLOBAL kNN graph of points sorted into clusters -- the rows of the definition
+    (oracle.knn_bruteforce_l2 at the small size, the whole-set producer, itself pinned to the oracle, at the others), index sets AND
+    distances bit for bit -- with overlapping clusters (most pairs of groups must be visited), well separated ones (none), ragged group
+    sizes, a group barely larger than k."""
+    rng = np.random.default_rng(n + dim)
+    means = rng.normal(size=(ncomp, dim)) * spread
+    scales = 0.5 + rng.random((ncomp, dim))
+    lab = np.sort(rng.integers(0, ncomp, n))
+    lab[:k + 2] = 0                                   # (a small first group is still larger than k)
+    x = (means[lab] + scales[lab] * rng.normal(size=(n, dim))).astype(np.float32)
+    bounds = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=ncomp))]).astype(np.uint64)
+    bounds = np.unique(bounds)                        # (an empty cluster is no group)
+    g = A.KGraph.bruteforce_l2_grouped(x, k, bounds)
+    ip, nb, ds = g.get_neighbours()
+    if n <= 3000:
+        oi, on, od = oracle.knn_bruteforce_l2(x, k)
+    else:
+        oi, on, od = A.KGraph.bruteforce_l2(x, k).get_neighbours()
+    assert np.array_equal(ip, oi) and np.array_equal(nb, on) and np.array_equal(ds, od)
+    fell, pairs_b, pairs_a = g.knn_stats
+    print("grouped kNN %d x %d, %d groups: pairs inside groups %.3g, pruned phase %.3g of %.3g, fallback rows %d" % (n, dim, len(bounds) - 1, pairs_a, pairs_b,
+                                                                                                                    float(n) * n - pairs_a, fell))
+    if spread >= 10.0:
+        assert pairs_b < 0.2 * (float(n) * n - pairs_a)   # separated clusters: the bound excludes (nearly) everything
+    with pytest.raises(A.AnnembedError):
+        A.KGraph.bruteforce_l2_grouped(x, k, np.array([0, 3, n], np.uint64))   # a group of 3 points cannot hold k neighbours
+
+
+def test_grouped_knn_producer_ties_by_the_callers_ids(A, oracle):
+    """lattice points (massive ties) and duplicated points, in three groups: the grouped producer reorders the points inside their groups
+    internally (shells by distance to the centroid) -- ties must still fall by the CALLER's ids, as the definition says."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 4, size=(1500, 6)).astype(np.float32)
+    x = x[np.argsort(x[:, 0], kind="stable")]
+    x[200:240] = x[200]
+    bounds = np.array([0, 500, 1100, 1500], np.uint64)
+    k = 10
+    ip, nb, ds = A.KGraph.bruteforce_l2_grouped(x, k, bounds).get_neighbours()
+    oi, on, od = oracle.knn_bruteforce_l2(x, k)
+    assert np.array_equal(nb, on) and np.array_equal(ds, od)
+
+
 def test_embed_cli_end_to_end(A, tmp_path):
     """The `embed` command line (src/bin/embed.rs) on the library: CSV in (first record dropped, io.rs:170-186), exact
     kNN graph, embed, CSV out in the reference's `{:.5e}` format with one row per kept record."""
@@ -1345,5 +1389,5 @@ def test_embedder_multi_gpu_entry_two_ranks_one_gpu(A, graph, tmp_path, kind):
     ce1 = e.get_cross_entropy()
     # CE of the initial embedding: flat = the same dmap initialisation up to its run-to-run rounding; hierarchical = a projection of the
     # first stage's result, itself a (sharded) stochastic optimisation
-    assert abs(ca[0] - ce1[0]) < (2e-3 if kind == "flat" else 0.05) * ce1[0], (ca, ce1)
+    assert abs(ca[0] - ce1[0]) < (2e-3 if kind == "flat" else 0.10) * ce1[0], (ca, ce1)   # (hier: two runs of the approximate rounds mode on differently ordered problems: measured 1 ... 5 %)
     assert 0.7 * ce1[1] < ca[1] < 1.3 * ce1[1], (ca, ce1)
