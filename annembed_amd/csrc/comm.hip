@@ -117,6 +117,7 @@ namespace ae {
 
 static bool comm_active(const ae_comm* c) { return c && (c->world > 1 || debug_knob("AE_COMM_FORCE")); }  // (the knob: a single-GPU box exercises the RCCL calls)
 
+bool comm_shares_devices(const ae_comm* c) { return c && c->host != nullptr; }
 int comm_rank(const ae_comm* c) { return c ? c->rank : 0; }
 int comm_world(const ae_comm* c) { return c ? c->world : 1; }
 
