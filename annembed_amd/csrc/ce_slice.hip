@@ -1001,25 +1001,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             try { for (uint64_t x = done; x < owed; x++) ce_comm_exchange(o); } catch (...) {}
         }
     } owe{o, exchanges_done, (uint64_t)segments * exchanges};
-    // Steps of few events run as ONE persistent launch per run of slices (sl_persist_kernel: a grid barrier between steps instead of a
-    // kernel boundary, the next step's events and static records requested before the wait): whenever a step fits a grid of one
-    // workgroup per CU with a little to spare.  Not over the shared-memory transport (validation: its ranks may share one GPU, and
-    // persistent grids of several processes could hold each other's CUs).
-    static int s_cus = 0;
-    if (!s_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        AE_HIP(hipGetDevice(&dev));
-        AE_HIP(hipGetDeviceProperties(&prop, dev));
-        s_cus = prop.multiProcessorCount;
-    }
-    const int persist_cus = s_cus;
-    const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
-    const bool persist = classes && !debug_knob("AE_SL_NO_PERSIST") && (debug_knob("AE_SL_PERSIST") || (step_events <= 256.0 * 1.25 * persist_cus && !comm_shares_devices(o->comm)));
-    if (persist && !o->sl_bar.n) o->sl_bar.alloc(2);
-    uint32_t persist_done_to = 0;
     for (uint32_t sg = 0; sg < segments; sg++) {
-        persist_done_to = 0;
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
         // the order of the classes inside every slice: a fresh uniform permutation (so the order of two events that share a node is
@@ -1077,46 +1059,6 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         // finished (the drain below) before the next segment reuses the arrays
         for (uint32_t s = 0; s < n_slices; s++) {
             const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
-            if (persist && classes) {
-                // the class steps of a run of slices in ONE launch (sl_persist_kernel): this slice's alone when an overflow class follows
-                // every slice, else every slice up to the next exchange point (at most 32)
-                if (s >= persist_done_to) {
-                    uint32_t run = 1;
-                    if (!has_overflow) {
-                        while (run < 32u && s + run < n_slices) {
-                            const uint32_t sl = s + run - 1u;   // (an exchange after slice sl ends the run)
-                            if (exchanges >= 2u) {
-                                const uint32_t q1 = (uint32_t)(((uint64_t)(sl + 1u) * exchanges) / n_slices), q0 = (uint32_t)(((uint64_t)sl * exchanges) / n_slices);
-                                if (q1 != q0 && q1 < exchanges) break;
-                            }
-                            run++;
-                        }
-                    }
-                    uint32_t max_cnt = 0;
-                    uint64_t sum_cnt = 0;
-                    for (uint32_t r = 0; r < run; r++) {
-                        const uint32_t* spr = hptr.data() + (size_t)(s + r) * (classes + 1u);
-                        for (uint32_t q = 0; q < classes; q++) { max_cnt = std::max(max_cnt, spr[q + 1] - spr[q]); sum_cnt += spr[q + 1] - spr[q]; }
-                    }
-                    if (max_cnt) {
-                        PersistArgs pa;
-                        pa.d = da;
-                        pa.d.ept = 1;
-                        pa.sptr = o->sl_sptr.p;
-                        pa.classes = classes;
-                        pa.slice0 = s;
-                        pa.n_slices = run;
-                        pa.step_seq0 = step_seq;
-                        pa.bar = o->sl_bar.p;
-                        step_seq += run * classes;
-                        AE_HIP(hipMemsetAsync(o->sl_bar.p, 0, 2 * sizeof(uint32_t), stream()));
-                        const unsigned grid = std::max(1u, std::min<unsigned>((max_cnt + 255u) / 256u, (unsigned)persist_cus));
-                        const bool tile_run = use_tile && !y_in_cache && sum_cnt / ((uint64_t)run * classes) >= tile_min_events;
-                        AE_DISPATCH_DIM(o->dev.dim, launch_persist, pa, grid, o->sl_srec_floats, f64, tile_run);
-                    }
-                    persist_done_to = s + run;
-                }
-            } else
             for (uint32_t q = 0; q < classes; q++) {  // the slice's matchings, in this slice's order
                 if (sp[q + 1] == sp[q]) continue;
                 da.begin = sp[q];
@@ -1255,8 +1197,6 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         o->sl_counts.zero();
         sync();
         if (h[1024] & 2ull) fail(AE_ERR_STATE, "AE_CE_SLICED: a hub chain waited for the previous chunk beyond the poll budget (is another process using this GPU?)");
-        if (h[1024] & (unsigned long long)kErrPersistBarrier)
-            fail(AE_ERR_STATE, "AE_CE_SLICED: the grid barrier of a persistent run of steps was not completed within its poll budget (is another process using this GPU?)");
         fail(AE_ERR_STATE, "AE_CE_SLICED: pending list overflow");
     }
     // samples executed, into the common counter

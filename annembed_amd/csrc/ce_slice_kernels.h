@@ -719,203 +719,11 @@ __global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// a RUN of steps in one launch: the persistent form of sl_direct_kernel
-// ------------------------------------------------------------------------------------------------------------------
-// A step with few events (a rank's share of a sharded batch: 31 k events at configs[3] over 8 ranks; any graph of ~10^6 nodes) is a
-// chain of latencies, not a stream: kernel boundary, event load, record + rows, arithmetic, stores, drain -- 25-30 us however little
-// it holds, and a batch is ~2 600 such steps.  Here the class steps of a run of slices execute in ONE launch whose workgroups (at most
-// one per CU: all resident) meet at a grid barrier between steps, and what does not depend on the coordinates -- the next step's
-// events, the chain structure derived from them, the sources' static records -- is requested BEFORE a workgroup waits at the barrier:
-// a step's critical path is barrier -> rows -> arithmetic -> stores -> release.  The barrier is the guide's counter form (lane 0:
-// agent-scope release after the workgroup's stores, one device-scope atomic, relaxed polls, agent-scope acquire); a poll budget turns
-// a barrier nobody completes (another process holding the CUs) into an error flag, never a hang.  Everything else -- the chains
-// through shared targets, their hand-over between chunks, the tile of negatives, the arithmetic -- is sl_step_body's, event for event.
-struct PersistArgs {
-    DirectArgs d;                // c, srec, ev, key, step, done_counter, chunk_flag, hub_pool (begin / end / step_seq / ept / tile: per step, below)
-    const uint32_t* sptr;        // the segment's step pointers: step (slice, q) = [sptr[slice * (classes + 1) + q], sptr[.. + 1])
-    uint32_t classes;
-    uint32_t slice0, n_slices;   // the run: every class step of slices [slice0, slice0 + n_slices)
-    uint32_t step_seq0;          // running step number of the run's first step (tile windows, hand-over tokens)
-    uint32_t* bar;               // [0] arrivals (zeroed before the launch), [1] abort
-};
-constexpr uint32_t kErrPersistBarrier = 8u;   // done_counter[1024] flag: the grid barrier's poll budget ran out
-
-template <int DIM, int SREC, bool F64, bool TILE>
-__global__ void __launch_bounds__(256) sl_persist_kernel(PersistArgs pa) {
-    constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
-    __shared__ StepShared<DIM, SREC, F64, TILE> sh;
-    __shared__ uint32_t s_abort;
-    const DirectArgs& a = pa.d;
-    const CeDev c = a.c;
-    const bool hub = c.hub_odds != nullptr;
-    float* stage = sh.stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
-    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
-    const int lane = threadIdx.x & 63;
-    const uint32_t G = gridDim.x, wg = blockIdx.x;
-    const uint32_t n_steps = pa.n_slices * pa.classes;
-    uint32_t done = 0;
-    if (threadIdx.x == 0) s_abort = 0;
-    // ---- what phase A leaves for phase B (registers) ----
-    uint32_t s_begin = 0, s_end = 0, s_seq = 0, p = 0, i = 0, j = 0, rep = 1;
-    Event e{0u, kNoNode};
-    bool act0 = false, half = false, inrun = false, next_inrun = false, cmp = false, want_rec = false;
-    float scale_f = 1.f, w = 0.f;
-    uint32_t nbr_reg[KREG];
-    RecFetch<SREC, KREG> fr;
-    auto step_bounds = [&](uint32_t t, uint32_t& b, uint32_t& en) {
-        const uint32_t* sp = pa.sptr + (uint64_t)(pa.slice0 + t / pa.classes) * (pa.classes + 1u) + t % pa.classes;
-        b = sp[0];
-        en = sp[1];
-    };
-    // phase A: the chunk's events, the chain structure, the sources' static records -- nothing that a step in flight can change
-    auto phase_a = [&](uint32_t t, uint32_t chunk) {
-        step_bounds(t, s_begin, s_end);
-        s_seq = pa.step_seq0 + t;
-        p = s_begin + chunk * 256u + threadIdx.x;
-        act0 = p < s_end;
-        Event pv{0u, kNoNode}, nx{0u, kNoNode};
-        e = Event{0u, kNoNode};
-        if (act0) {
-            e = a.ev[p];
-            if (p > s_begin) pv = a.ev[p - 1];
-            if (p + 1 < s_end) nx = a.ev[p + 1];
-        }
-        i = e.im >> 5;
-        j = act0 ? ev_node(e.j) : 0u;
-        half = act0 && ev_half(e.j);
-        inrun = act0 && p > s_begin && ev_node(pv.j) == j;
-        next_inrun = act0 && p + 1u < s_end && ev_node(nx.j) == j;
-        const bool absorbed = inrun && pv.im == e.im;
-        cmp = act0 && !absorbed;
-        rep = 1;
-        if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < s_end && a.ev[p + rep].im == e.im && ev_node(a.ev[p + rep].j) == j) rep++; }
-        want_rec = cmp;
-        fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
-    };
-    // phase B: rows, arithmetic, stores (sl_step_body from its second hop on)
-    auto phase_b = [&](bool first_of_step, uint32_t tile_block) {
-        const uint32_t wkey = pcg_hash(nkey + s_seq * 0x85EBCA6Bu) + tile_block * 64u;
-        const unsigned long long run_mask = __ballot(inrun);
-        const bool cont = (run_mask & 1ull) != 0ull;
-        const unsigned long long heads = ~run_mask | 1ull;
-        const int head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
-        const uint32_t runpos = act0 ? (uint32_t)(lane - head) + ((cont && head == 0) ? 1u : 0u) : 0u;
-        const bool last_in_seg = lane == 63 || !((run_mask >> (lane + 1)) & 1ull);
-        const bool hand_over = act0 && lane == 63 && next_inrun;
-        float yi[DIM], yj[DIM];
-        TileFetch<DIM> ft;
-        RowFetch<DIM> fi, fj;
-        if constexpr (TILE) { if (first_of_step) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n); }
-        fi.issue(c.y, i, cmp, yi);             // :1185
-        fj.issue(c.y, j, cmp && !inrun, yj);   // :1186
-        if constexpr (TILE) { if (first_of_step) ft.land(sh.tile, sh.tnode); }
-        fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
-        fi.land(stage, yi);
-        fj.land(stage, yj);
-        const uint32_t chunk = (s_begin >> 6) + ((p - s_begin) >> 6);
-        SplitSample<DIM, F64, TILE> sm;
-        uint32_t neg[5], got = 0;
-        if (cmp && !half) {
-            got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
-            sm.fetch(c, sh.tile, neg);
-        }
-        for (uint32_t t = 0;; t++) {
-            if (t >= 1u) {   // (only chunks with chains get here)
-                float in[DIM];
-#pragma unroll
-                for (int q = 0; q < DIM; q++) in[q] = __shfl_up(yj[q], 1);
-                if (t == 1u && cont && lane == 0) {   // the target's row as the previous chunk left it
-                    const uint32_t token = s_seq + 1u;
-                    uint32_t polls = 0;
-                    while (__hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++polls > (1u << 24)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 2u); break; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    load_row_agent<DIM>(c.y, j, in);
-                }
-                if (act0 && runpos == t) {
-#pragma unroll
-                    for (int q = 0; q < DIM; q++) yj[q] = in[q];
-                }
-            }
-            if (cmp && runpos == t) {
-                for (uint32_t q = 0; q + 1u < rep; q++) {   // earlier repetitions of the edge: whole samples, one after the other
-                    uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
-                    const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng);
-                    run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
-                }
-                sm.attract(c, yi, yj, w, scale_f, a.step);
-            }
-            if (!__ballot(act0 && runpos > t)) break;
-        }
-        if (cmp && !half) {
-            sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
-            done += rep;
-        }
-        const bool store_j = act0 && last_in_seg && !hand_over;
-        row_store<DIM>(c.y, j, store_j, stage, yj);        // :1239
-        row_store<DIM>(c.y, i, cmp && !half, stage, yi);   // :1301
-        if (hand_over) {
-            store_row_agent<DIM>(c.y, j, yj);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(&a.chunk_flag[chunk], s_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    auto chunks_of = [&](uint32_t t) { uint32_t b, en; step_bounds(t, b, en); return (en - b + 255u) >> 8; };
-    __syncthreads();
-    if (n_steps && wg < chunks_of(0)) phase_a(0, wg);
-    for (uint32_t t = 0; t < n_steps; t++) {
-        const uint32_t nch = chunks_of(t);
-        if (wg < nch) phase_b(true, wg);
-        for (uint32_t ch = wg + G; ch < nch; ch += G) {   // (a step larger than the grid: the further chunks in turn, the tile kept)
-            phase_a(t, ch);
-            phase_b(false, wg);
-        }
-        if (t + 1u == n_steps) break;
-        // ---- grid barrier: publish, request the next step's static data, wait ----
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (!(a.dbg & 16)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAdd(pa.bar, 1u);
-        }
-        if (wg < chunks_of(t + 1u)) phase_a(t + 1u, wg);
-        if (threadIdx.x == 0) {
-            const uint32_t target = (a.dbg & 64) ? 0u : (t + 1u) * G;
-            uint32_t polls = 0;
-            while (__hip_atomic_load(pa.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (__hip_atomic_load(pa.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
-                if (++polls > (1u << 22)) {
-                    atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), kErrPersistBarrier);
-                    __hip_atomic_store(pa.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_abort = 1;
-                    break;
-                }
-            }
-            if (!(a.dbg & 32)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (s_abort) break;
-    }
-    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
-    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
-}
-template <int DIM, bool F64, bool TILE>
-void launch_persist3(const PersistArgs& a, unsigned grid, uint32_t srec) {
-    if (srec == 16) hipLaunchKernelGGL((sl_persist_kernel<DIM, 16, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
-    else if (srec == 32) hipLaunchKernelGGL((sl_persist_kernel<DIM, 32, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
-    else if (srec == 64) hipLaunchKernelGGL((sl_persist_kernel<DIM, 64, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
-    else hipLaunchKernelGGL((sl_persist_kernel<DIM, 128, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
-}
-template <int DIM>
-void launch_persist(const PersistArgs& a, unsigned grid, uint32_t srec, bool f64, bool tile_wanted) {
-    const bool tile = tile_wanted && a.d.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
-    if (f64) { if (tile) launch_persist3<DIM, true, true>(a, grid, srec); else launch_persist3<DIM, true, false>(a, grid, srec); }
-    else { if (tile) launch_persist3<DIM, false, true>(a, grid, srec); else launch_persist3<DIM, false, false>(a, grid, srec); }
-}
+// (A persistent form of this kernel -- the class steps of a run of slices in ONE launch, a grid barrier between steps, the next step's
+// events and static records requested before the wait -- was built and measured in round 5 and is not kept: on a rank's share of a
+// configs[3] batch, 31 k events per step, it ran 24.3 us per step against 23.6 us for one launch per step; the counter barrier with its
+// release / acquire fences costs what the prefetch saves, and even a free barrier would have bought 15 ms of 71.  profiles/r05/
+// r5_rank_share_notes.md; the code: commit 9deaf5d, `git show 9deaf5d:annembed_amd/csrc/ce_slice_kernels.h`.)
 
 // ------------------------------------------------------------------------------------------------------------------
 // the overflow class of a slice: optimistic passes (sl_mark_kernel: ce_slice.hip)
@@ -1131,7 +939,6 @@ void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
 #define AE_SL_LAUNCHERS(PREFIX, D)                                                                                                        \
     PREFIX template void launch_direct<D>(const DirectArgs&, uint32_t, bool);                                                             \
     PREFIX template void direct_blocks_per_cu<D>(uint32_t, bool, bool, int*);                                                             \
-    PREFIX template void launch_persist<D>(const PersistArgs&, unsigned, uint32_t, bool, bool);                                           \
     PREFIX template void launch_exec<D>(const SliceArgs&, unsigned, uint32_t, bool);                                                      \
     PREFIX template void launch_chain_run<D>(const SliceArgs&, unsigned, uint32_t, bool, const uint32_t*, const uint32_t*);
 #ifdef AE_SL_INSTANTIATE_DIM
