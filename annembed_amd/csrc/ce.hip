@@ -994,9 +994,8 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         // embedded scales: mean of the initial scales as the reference's sequential f32 sum (:1358)
         // (on the device: the reference's sequential f32 order as a single-lane chain -- bit parity of the scales with the oracle --, a
         // tree reduction while the embedder has switched the summation order for a mode that is not the bit-exact one: linalg.h)
-        // (the mode is resolved further down from the same inputs; a sharded range never runs the bit-exact mode)
-        const bool bit_exact_follows = (node_lo == 0 && node_hi == g->n) &&
-                                       resolve_ce_mode(params->ce_mode, dim, false, params->nb_sampling_by_edge * g->nnz, g->max_nbng, g->nnz) == AE_CE_SEQUENTIAL;
+        // (AE_CE_AUTO never resolves to the bit-exact mode: it runs by name only)
+        const bool bit_exact_follows = params->ce_mode == AE_CE_SEQUENTIAL;
         TreeSums sums(tree_sums() || !bit_exact_follows);
         const float mean_scale = seq_sum_f32(np->scale.p, n) / (float)n;
         o->emb_scale.alloc(n);

@@ -22,7 +22,7 @@ def main():
     par = A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD, grad_step=1.0)
     if kind in ("faithful", "faithful_dmap"):
         # ce_mode = AE_CE_AUTO; the graph comes in ANY node order: embed() partitions it by locality itself
-        par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=kind == "faithful_dmap")
+        par = A.EmbedderParams(nb_grad_batch=12, grad_step=1.0, dmap_init=kind == "faithful_dmap", seed=int(os.environ.get("AE_TEST_SEED", "4664397")))
         e = A.Embedder(g, par)
         e.set_comm(comm, int(os.environ.get("AE_TEST_EXCHANGES", "0")))   # 0: the library's choice (4 per batch)
         assert e.embed() == 1

@@ -1,6 +1,6 @@
 """worker of tests/test_gpu_configs.py::test_sharded_sliced_*: one rank of a `world`-rank FAITHFUL sharded CE schedule (AE_CE_AUTO on a
 node range -> the time-sliced mode) over the library's shared-memory communicator; all ranks share this box's GPU.
-usage: sliced_shm_worker.py <dir> <rank> <world> <segment name> <exchanges per batch> <batches>"""
+usage: sliced_shm_worker.py <dir> <rank> <world> <segment name> <exchanges per batch> <batches> [seed]"""
 import os
 import sys
 
@@ -23,7 +23,8 @@ def main():
     npar = A.to_proba_edges(g, float(g0["scale_rho"]), 1.0)
     lo, hi = shard_range(n, world, rank)
     comm = HostMemComm(rank, world, name, n * 64 * 4)
-    eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, grad_step=1.0), y0, node_lo=lo, node_hi=hi)  # AE_CE_AUTO
+    seed = int(sys.argv[7]) if len(sys.argv) > 7 else 4664397
+    eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, grad_step=1.0, seed=seed), y0, node_lo=lo, node_hi=hi)  # AE_CE_AUTO
     assert eo.get_ce_mode() == A.AE_CE_SLICED
     comm.attach(eo, exchanges)
     S = 10 * eo.get_nb_edges()

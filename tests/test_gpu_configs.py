@@ -17,6 +17,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.util import assert_means_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -70,33 +72,48 @@ def _assert_close(A, indptr, nbr, run, ref, tol_ce=0.03, tol_q=0.05):
     assert np.all(np.abs(q - qr) < tol_q * qr), (q, qr)
 
 
+def _metrics(indptr, nbr, y, ce):
+    q = _edge_q(indptr, nbr, y)
+    return [ce, q[0], q[1], q[2]]
+
+
+METRIC_NAMES = ("ce", "q25", "q50", "q75")
+SEEDS = (4664397, 12345, 777, 20261003)
+
+
 def test_k6_blobs_without_hubness_40_batches(A):
-    """The case the rounds mode misses by 28 % (final CE 0.72x, median edge 1.76x: 60 k points of 28-d blobs, k = 6,
-    scale_rho 0.75, no hubness weighting, 40 batches from a random initialisation).  Event-ordered vs sequential:
-    measured CE +0.8 %, quartiles -1 ... -2 %."""
+    """The case the rounds mode misses by 28 % (final CE 0.72x, median edge 1.76x: 60 k points of 28-d blobs, k = 6, scale_rho 0.75, no
+    hubness weighting, 40 batches from a random initialisation) -- and the stiff graph on which the time-sliced mode's repeat rule sits
+    worst.  FOUR seeds of every statistically faithful mode against four seeds of the exact mode: the MEAN of the final
+    cross entropy and of the median edge within 2 standard errors + 1 % of the exact mode's, the quartiles within 2 SE + 3 %
+    (tests/util.py: assert_means_close).  The time-sliced mode's optimistic path carries a known bias on THIS graph (six runs of round 4:
+    CE +2.1 %, quartiles -6 % in the mean: a kept repeat of an edge runs a pass later, not back to back, and the rule's rho does not
+    know): its floors are 3 % / 8 % and say so; the class path (forced: the cost model runs 60 k nodes optimistically) has the standard
+    ones."""
     n = 60000
     g = A.KGraph.bruteforce_l2(_blobs(n), 6)
     indptr, nbr, _ = g.get_neighbours()
     npar = A.to_proba_edges(g, 0.75, 1.0)
     y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
-    ref = _run_ce(A, g, npar, y0, 40, A.AE_CE_SEQUENTIAL)
     assert A.EntropyOptim(g, npar, A.EmbedderParams(), y0).get_ce_mode() == A.AE_CE_ORDERED  # the default at this size
-    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_ORDERED)  # measured over seeds: CE 1.000 +- 0.002, quartiles within 1 % (q05 4 %)
-    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.03, tol_q=0.06)
-    # measured over seeds: event-ordered CE +1 ... +2 %, quartiles -2 ... -4 % (single runs scatter by 1 % / 2 % around those): bars
-    # 4 % / 8 %; time-sliced (optimistic path at this size), six runs: CE +0.2 ... +3.3 % (mean +2.1), quartiles -2 ... -9 % (mean -6):
-    # this stiff graph is where the mode sits farthest from the exact one (every repeat moved to the next slice, rounds 3-4's rule:
-    # -0.5 % / -1 % here, but +2 % / -3 ... -8 % on the 1 M-node clustered graphs where the present rule matches; DESIGN 4.3): bars 5 % / 11 %
-    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_EVENT)
-    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.04, tol_q=0.08)
-    run = _run_ce(A, g, npar, y0, 40, A.AE_CE_SLICED)
-    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.05, tol_q=0.11)
+
+    def rows(mode):
+        out = []
+        for sd in SEEDS:
+            y, ce, _ = _run_ce(A, g, npar, y0, 40, mode, seed=sd)
+            assert np.isfinite(y).all()
+            out.append(_metrics(indptr, nbr, y, ce))
+        return out
+    exact = rows(A.AE_CE_SEQUENTIAL)
+    std = (0.01, 0.03, 0.01, 0.03)
+    assert_means_close(rows(A.AE_CE_ORDERED), exact, METRIC_NAMES, std, "k6 blobs, ordered (the default)")
+    assert_means_close(rows(A.AE_CE_EVENT), exact, METRIC_NAMES, (0.02, 0.04, 0.03, 0.04), "k6 blobs, event-ordered")   # (measured over seeds: CE +1 ... +2 %, quartiles -2 ... -4 %)
+    assert_means_close(rows(A.AE_CE_SLICED), exact, METRIC_NAMES, (0.03, 0.08, 0.08, 0.08), "k6 blobs, time-sliced, optimistic path (known bias: see above)")
     rounds = _run_ce(A, g, npar, y0, 40, A.AE_CE_HOGWILD)  # evidence: the rounds mode is outside the envelope here
-    assert rounds[1] < 0.85 * ref[1]
-    # the CLASS path on a graph with hubs (in-degrees up to ~105): the cost model runs a graph of this size optimistically, so the
-    # classes are forced through the debug knob.  Every class is a forest of in-stars (k + 5 = 11 classes whatever the in-degrees; ~2 %
-    # of the edge mass finds no colour and runs optimistically); the events of a step that share their target run as a chain through
-    # the target's row (ce_slice_kernels.h) -- on this graph the busiest row receives ~4 events per slice.
+    assert rounds[1] < 0.85 * np.mean([r[0] for r in exact])
+    # the CLASS path on a graph with hubs (in-degrees up to ~105): every class is a forest of in-stars (k + 5 = 11 classes whatever the
+    # in-degrees; ~2 % of the edge mass finds no colour and runs optimistically); the events of a step that share their target run as a
+    # chain through the target's row (ce_slice_kernels.h) -- on this graph the busiest row receives ~4 events per slice.
     knobs = {"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1"}
     saved = {k2: os.environ.get(k2) for k2 in knobs}
     os.environ.update(knobs)
@@ -105,14 +122,14 @@ def test_k6_blobs_without_hubness_40_batches(A):
         classes, ov_frac, _, _ = probe.slice_info()
         del probe
         assert classes == 11 and 0.0 < ov_frac <= 0.05, (classes, ov_frac)
-        run = _run_ce(A, g, npar, y0, 40, A.AE_CE_SLICED)
+        forced = rows(A.AE_CE_SLICED)
     finally:
         for k2, v2 in saved.items():
             if v2 is None:
                 os.environ.pop(k2, None)
             else:
                 os.environ[k2] = v2
-    _assert_close(A, indptr, nbr, run, ref, tol_ce=0.04, tol_q=0.10)
+    assert_means_close(forced, exact, METRIC_NAMES, (0.015, 0.04, 0.02, 0.04), "k6 blobs, time-sliced, class path forced")   # (round 4, single runs: CE 1.012, quartiles 0.96-1.00)
 
 
 @pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])
@@ -470,14 +487,14 @@ def test_high_dimensional_hubs_1m_nodes(A):
     assert t_s < 0.25, "time-sliced batch on the 128-D kNN graph took %.2f s (sequential %.2f s)" % (t_s, t_q)
 
 
-def _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, scale_rho, world, exchanges, nb_batch, tag):
+def _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, scale_rho, world, exchanges, nb_batch, tag, seed=4664397):
     """`world` processes on this box's one GPU, the library's communicator over shared memory: the faithful sharded schedule"""
     import subprocess
     np.savez(tmp_path / "graph.npz", indptr=indptr, nbr=nbr, dist=dist, k=k, y0=y0, scale_rho=scale_rho)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name = "annembed_sl_%d_%s" % (os.getpid(), tag)
+    name = "annembed_sl_%d_%s_%d" % (os.getpid(), tag, seed % 100000)
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "sliced_shm_worker.py"), str(tmp_path), str(r), str(world), name,
-                               str(exchanges), str(nb_batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for r in range(world)]
+                               str(exchanges), str(nb_batch), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root) for r in range(world)]
     outs = [p.communicate(timeout=1200) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so[-1500:], se[-3000:])
@@ -507,13 +524,21 @@ def test_sharded_sliced_component_partition(A, tmp_path, world):
     x, bounds = bench.mixture_points_gpu(n, 28, 16, seed=5, mean_sigma=10.0)
     indptr, nbr, dist = bench.component_knn_graph(A, x, bounds, k, permute_seed=None)
     y0 = A.set_data_box(np.random.default_rng(2).normal(size=(n, d)).astype(np.float32), 10.0)
-    y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 8, nb_batch, "comp%d" % world)
+    seeds = SEEDS if world == 2 else SEEDS[:3]
+    rows = []
+    for sd in seeds:
+        y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 8, nb_batch, "comp%d" % world, seed=sd)
+        assert nbytes == nb_batch * 8 * (n - n // world) * d * 4   # received: the other ranks' rows (equal shares here)
+        assert np.isfinite(y).all()
+        rows.append(_metrics(indptr, nbr, y, ce))
     g = A.KGraph(indptr, nbr, dist, k)
     npar = A.to_proba_edges(g, 1.0, 1.0)
-    ref = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL)
+    exact = []
+    for sd in SEEDS:
+        yr, cer, _ = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL, seed=sd)
+        exact.append(_metrics(indptr, nbr, yr, cer))
     print("sharded sliced, %d shards, component partition: %d bytes received per rank and batch" % (world, nbytes / nb_batch))
-    assert nbytes == nb_batch * 8 * (n - n // world) * d * 4   # received: the other ranks' rows (equal shares here)
-    _assert_close(A, indptr, nbr, (y, ce, None), ref, tol_ce=0.03, tol_q=0.05)
+    assert_means_close(rows, exact, METRIC_NAMES, (0.01, 0.03, 0.01, 0.03), "sharded time-sliced, %d shards, component partition" % world)
 
 
 def test_sharded_sliced_class_path_with_the_tile_on_component_ordered_labels(A, tmp_path):
@@ -521,8 +546,8 @@ def test_sharded_sliced_class_path_with_the_tile_on_component_ordered_labels(A, 
     columns, 2 shards, 4 exchanges per batch, the class path and the tile of negatives forced on (debug knobs, inherited by the rank
     processes; the thresholds use both from a few million nodes).  Attaching the communicator relabels the nodes at random inside every
     rank's range: without that a tile window is 16 nodes of one component, and an 11 M-node run in 2 shards came out at CE
-    0.969 / edges +18-23 % of the exact mode's.  Bars (see the assertions): CE within 5 %, quartiles within -20 ... +30 % of the un-sharded
-    sequential mode."""
+    0.969 / edges +18-23 % of the exact mode's.  Three seeds a side against the un-sharded sequential mode, mean against mean (see the
+    assertion for the floors and why)."""
     sys_argv = sys.argv
     sys.argv = ["bench.py"]
     import bench
@@ -534,38 +559,43 @@ def test_sharded_sliced_class_path_with_the_tile_on_component_ordered_labels(A, 
     knobs = {"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1"}
     saved = {q: os.environ.get(q) for q in knobs}
     os.environ.update(knobs)
+    rows = []
     try:
-        y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 4, nb_batch, "cls")
+        for sd in SEEDS[:3]:
+            y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 4, nb_batch, "cls", seed=sd)
+            assert nbytes == nb_batch * 4 * (n - n // world) * d * 4
+            rows.append(_metrics(indptr, nbr, y, ce))
     finally:
         for q, v in saved.items():
             if v is None:
                 os.environ.pop(q, None)
             else:
                 os.environ[q] = v
-    assert nbytes == nb_batch * 4 * (n - n // world) * d * 4
     g = A.KGraph(indptr, nbr, dist, k)
     npar = A.to_proba_edges(g, 1.0, 1.0)
-    par = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, ce_mode=A.AE_CE_SEQUENTIAL, grad_step=1.0)
-    eo = A.EntropyOptim(g, npar, par, y0)
-    S = 10 * eo.get_nb_edges()
-    for it in range(1, nb_batch + 1):
-        eo.gradient_iteration_threaded(S, 1.0 * (1 - it / nb_batch), it)
-    yr, cer = eo.get_embedded(), eo.ce_compute_threaded()
-    q, qr = _edge_q(indptr, nbr, y), _edge_q(indptr, nbr, yr)
-    print("sharded class path, tile, component order: ce ratio %.4f, quartile ratios %s" % (ce / cer, np.round(q / qr, 3)))
-    # Nine runs of this test: CE 0.978 ... 1.015, quartiles 0.87 ... 1.19 (two processes on one GPU interleave differently from run to
-    # run, and the exact mode's own seed-to-seed distance on this graph is 0.6 % / 3-6 %).  In the caller's labels: quartiles 0.75,
-    # 0.77, 0.84.
-    assert abs(ce - cer) < 0.05 * cer, (ce, cer)
-    assert np.all(q / qr > 0.80) and np.all(q / qr < 1.30), (q, qr)
+    exact = []
+    for sd in SEEDS[:3]:
+        par = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, ce_mode=A.AE_CE_SEQUENTIAL, grad_step=1.0, seed=sd)
+        eo = A.EntropyOptim(g, npar, par, y0)
+        S = 10 * eo.get_nb_edges()
+        for it in range(1, nb_batch + 1):
+            eo.gradient_iteration_threaded(S, 1.0 * (1 - it / nb_batch), it)
+        exact.append(_metrics(indptr, nbr, eo.get_embedded(), eo.ce_compute_threaded()))
+        del eo
+    # Round 4 held ONE run to -20 ... +30 % on the quartiles (nine single runs scattered 0.87 ... 1.19: two processes on one GPU interleave
+    # differently from run to run, and tight components amplify it).  Three seeds a side, mean against mean: the cross entropy within
+    # 2 SE + 2 %, the quartiles within 2 SE + 6 % -- the floors are what ce_slice.hip documents for this arrangement (edges +4 ... +9 % at
+    # 600 k nodes in 2 shards with 4 exchanges per batch: the other shard's rows are a quarter of a batch old); in the caller's labels,
+    # without the relabelling, the quartiles sat at 0.75 ... 0.84.
+    assert_means_close(rows, exact, METRIC_NAMES, (0.02, 0.09, 0.09, 0.09), "sharded class path + tile, 600 k nodes in component order, 2 shards, 4 exchanges")
 
 
 def test_sharded_sliced_locality_partition_with_cross_edges(A, tmp_path):
     """The same with edges that DO cross shards: Higgs-shaped blobs (64 overlapping components, exact GLOBAL kNN graph, k = 6,
     scale_rho 0.75 -- the stiff graph on which the sharded rounds mode ends at 1.3-1.7x the reference's CE), node ids in
     component order, 8 shards: a few per cent of the edge mass crosses; such an edge fires as two half events, each shard moving its own
-    end against its replica of the other.  16 exchanges per batch, 40 batches: CE within 4 %, quartiles within 8 % of the un-sharded
-    sequential mode (the un-sharded time-sliced mode's own bars on this graph)."""
+    end against its replica of the other.  16 exchanges per batch, 40 batches, three seeds against four of the un-sharded sequential mode:
+    mean against mean (tests/util.py: assert_means_close) with the un-sharded time-sliced mode's own floors on this graph."""
     n, k, d, nb_batch, world = 60000, 6, 2, 40, 8
     sys_argv = sys.argv
     sys.argv = ["bench.py"]
@@ -580,10 +610,17 @@ def test_sharded_sliced_locality_partition_with_cross_edges(A, tmp_path):
     print("locality partition: %.2f %% of the edges cross shards" % (100 * cross.mean()))
     assert 0.001 < cross.mean() < 0.10
     y0 = (np.random.default_rng(5).random(size=(n, d)).astype(np.float32) - 0.5)
-    y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 0.75, world, 16, nb_batch, "loc")
+    rows = []
+    for sd in SEEDS[:3]:
+        y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 0.75, world, 16, nb_batch, "loc", seed=sd)
+        rows.append(_metrics(indptr, nbr, y, ce))
     npar = A.to_proba_edges(g, 0.75, 1.0)
-    ref = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL)
-    _assert_close(A, indptr, nbr, (y, ce, None), ref, tol_ce=0.04, tol_q=0.08)
+    exact = []
+    for sd in SEEDS:
+        yr, cer, _ = _run_ce(A, g, npar, y0, nb_batch, A.AE_CE_SEQUENTIAL, seed=sd)
+        exact.append(_metrics(indptr, nbr, yr, cer))
+    # (the stiff graph: the un-sharded time-sliced mode's own floors here are 3 % / 8 %, test_k6_blobs_without_hubness_40_batches)
+    assert_means_close(rows, exact, METRIC_NAMES, (0.03, 0.08, 0.08, 0.08), "sharded time-sliced, 8 shards, 0.9 % cross edges, stiff k = 6 graph")
 
 
 def test_tile_of_negatives_is_unbiased_on_a_clustered_graph(A):
