@@ -167,7 +167,7 @@ SIGNATURES = {
     "ae_quality_estimate_from_edge_length": [_vp, _vp, _u32, _u32, _P(CQualityReport), _vp, _vp],
     "ae_embedder_get_quality_estimate_from_edge_length": [_vp, _u32, _P(CQualityReport), _vp, _vp],
 }
-STRING_GETTERS = ["ae_last_error_message", "ae_version"]
+STRING_GETTERS = ["ae_last_error_message", "ae_last_warning_message", "ae_version"]
 
 _lib = None
 
@@ -199,6 +199,10 @@ def load():
 def check(rc):
     if rc != AE_OK:
         raise AnnembedError(rc, load().ae_last_error_message().decode())
+    w = load().ae_last_warning_message()
+    if w:
+        import warnings
+        warnings.warn("annembed_hip: " + w.decode(), RuntimeWarning, stacklevel=3)
 
 
 def ptr(a):

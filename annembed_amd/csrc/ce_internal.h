@@ -144,6 +144,7 @@ struct ae_entropy_optim {
     uint32_t sl_srec_floats = 16;
     uint32_t sl_classes = 0, sl_color_rounds = 0;
     double sl_ov_frac = 1.;                     // share of the edge probability mass in the overflow class
+    double sl_ov_frac_sched = -1.;              // (a sharded run) the largest of the ranks' shares: what every rank cuts its slices by
     // multi-GPU (comm.hip): the communicator, every rank's node range, exchanges of the owned rows per batch
     ae_comm* comm = nullptr;
     std::vector<uint64_t> comm_ranges;

@@ -817,11 +817,14 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // memory round trips (~28 us at the configs[3] shape for 98 k or 196 k events alike); what does not fit starts when the first
     // workgroups end -- a second chain (measured: 250 k events on 768 resident workgroups of 256: 59 us).  So the slices are made as
     // thin as it takes for a step to fit the device (never thicker than lambda: thinner slices are the more faithful ones).
+    // (a sharded run: the overflow share the ranks agreed on when the communicator was attached -- the parallel colouring's own share
+    // depends on the scheduling, and every rank must cut its batch alike)
+    const double ov_sched = (o->comm && o->sl_ov_frac_sched >= 0.) ? o->sl_ov_frac_sched : o->sl_ov_frac;
     if (o->sl_classes && !debug_knob("AE_SL_NO_FIT")) {
         const double resident = sl_resident_events(o);
-        const double per_step = seg_rank * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)o->sl_classes);
+        const double per_step = seg_rank * (1.0 - ov_sched) / ((double)n_slices * (double)o->sl_classes);
         if (per_step > resident && per_step < 4.0 * resident)
-            n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - o->sl_ov_frac) / (resident * (double)o->sl_classes));
+            n_slices = (uint32_t)std::ceil(seg_rank * (1.0 - ov_sched) / (resident * (double)o->sl_classes));
     }
     // A rank of a sharded run holds a fraction of every step, and a step costs ~25-30 us however few events it has (one chain of memory
     // round trips): configs[3] over 8 ranks runs 2 640 steps of 31 k events -- 81 ms per batch and rank where one device takes 160 for

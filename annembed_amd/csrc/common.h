@@ -45,6 +45,8 @@ struct Error : std::exception {
 }
 
 void set_last_error(const std::string& s);
+void set_last_warning(const std::string& s);   // ae_last_warning_message: a call that succeeded but has something to say
+int& api_depth();                               // nesting of entry points on this thread (an outermost call clears the warning)
 
 #define AE_HIP(expr)                                                                              \
     do {                                                                                          \
@@ -65,6 +67,10 @@ inline std::recursive_mutex& api_mutex() {
 template <class F>
 inline int32_t guard(F&& f) {
     std::lock_guard<std::recursive_mutex> lock(api_mutex());
+    struct Depth {
+        Depth() { if (api_depth()++ == 0) set_last_warning(std::string()); }
+        ~Depth() { --api_depth(); }
+    } depth;
     try {
         f();
         return AE_OK;

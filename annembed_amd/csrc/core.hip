@@ -8,8 +8,12 @@
 
 namespace ae {
 
-static thread_local std::string g_last_error;
+static thread_local std::string g_last_error, g_last_warning;
+static thread_local int g_api_depth = 0;
 void set_last_error(const std::string& s) { g_last_error = s; }
+// (entry points nest -- ae_embedder_embed calls others --: only an OUTERMOST call clears what an earlier one said)
+void set_last_warning(const std::string& s) { g_last_warning = s; }
+int& api_depth() { return g_api_depth; }
 
 static std::mutex g_stream_mu;
 static hipStream_t g_streams[64] = {};
@@ -344,6 +348,7 @@ void bruteforce_knn_rows(const float* d_x, uint64_t n, uint64_t dim, uint32_t k,
 extern "C" {
 
 const char* ae_last_error_message(void) { return ae::g_last_error.c_str(); }
+const char* ae_last_warning_message(void) { return ae::g_last_warning.c_str(); }
 const char* ae_version(void) { return "annembed_hip 0.1.0 gfx950"; }
 
 int32_t ae_device_count(int32_t* count) {

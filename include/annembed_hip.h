@@ -52,6 +52,10 @@ enum {
 };
 
 const char *ae_last_error_message(void);
+/* A call that returned AE_OK may still have something to say (thread-local, cleared by the next outermost call): e.g.
+   ae_entropy_optim_set_comm / ae_embedder_embed with exchanges_per_batch = 1 on >= 4 ranks and >= 2^20 nodes -- outside the validated
+   envelope (one exchange per batch left the edges 10-21 % short at 11 M nodes in 8 shards).  Empty string: nothing. */
+const char *ae_last_warning_message(void);
 /* library / build identification: "annembed_hip <version> gfx950" */
 const char *ae_version(void);
 int32_t ae_device_count(int32_t *count);
@@ -388,8 +392,9 @@ int32_t ae_entropy_optim_get_nb_edges(const ae_entropy_optim *o, uint64_t *nnz);
  * host channel; every rank calls ae_comm_init on its own device (ae_set_device first).  A communicator attached to an
  * EntropyOptim created on this rank's node range [node_lo, node_hi) -- the ranges of the ranks must tile [0, n) in rank
  * order -- makes ae_entropy_optim_gradient_iteration exchange the owned coordinate rows itself: in place, on the library's
- * stream, `exchanges_per_batch` times per batch at equal runs of rounds / time slices (1 = once per batch, at its end; 0 = the library's
- * choice: 4).  Two modes
+ * stream, `exchanges_per_batch` times per batch at equal runs of rounds / time slices (1 = once per batch, at its end: the north star's
+ * figure, and OUTSIDE the validated envelope from 4 ranks and ~10^6 nodes on -- the call then succeeds with a warning,
+ * ae_last_warning_message; 0 = the library's choice: 4).  Two modes
  * shard: the time-sliced mode (AE_CE_SLICED; what AE_CE_AUTO resolves to on a sharded range) runs a shard's own events on current rows
  * and reads the other shards' rows -- negatives, the far ends of cross-shard edges, which fire as two half events -- as of the last
  * exchange: faithful for node orders with few cross-shard edges (connected components / locality; more than 10 % of a shard's edge mass

@@ -3,6 +3,8 @@
 # configs[3]'s own graph (tools/run_scale_shapes.py c4_knn); counters in their own passes (FETCH_SIZE, WRITE_SIZE), as the guide prescribes
 set -u
 TAG=$1; SHAPE=${2:-c4_knn}
+export NEEDLE="sl_direct_kernel<8, 16, true, true>"
+case $SHAPE in c5*) export NEEDLE="sl_direct_kernel<16, 32, true, true>";; esac
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -12,7 +14,7 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch 
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/tools/run_scale_shapes.py $SHAPE 1 > $OUT/run_write.log 2>&1
 cd $OUT
 python3 - <<'PY'
-import csv, glob, json
+import csv, glob, json, os
 out = {}
 for f in glob.glob('trace/**/*kernel_stats.csv', recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -21,7 +23,7 @@ for f in glob.glob('trace/**/*kernel_stats.csv', recursive=True):
             line = "%-120s calls %8s total %12s ns avg %12s ns  %6s %%" % (r['Name'][:120], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'])
             print(line); w.write(line + "\n")
     for r in rows:
-        if 'sl_direct_kernel<8, 16, true, true>' in r['Name']:
+        if os.environ['NEEDLE'] in r['Name']:
             out['step_kernel'] = r['Name']; out['calls'] = int(r['Calls']); out['avg_ns'] = float(r['AverageNs'])
 def avg(d, counter, needle):
     tot = 0.0; seen = set()
@@ -30,8 +32,8 @@ def avg(d, counter, needle):
             if needle in r['Kernel_Name'] and r['Counter_Name'] == counter:
                 tot += float(r['Counter_Value']); seen.add(r['Dispatch_Id'])
     return (tot / len(seen), len(seen)) if seen else (None, 0)
-fetch, nf = avg('pmc_fetch', 'FETCH_SIZE', 'sl_direct_kernel<8, 16, true, true>')
-write, nw = avg('pmc_write', 'WRITE_SIZE', 'sl_direct_kernel<8, 16, true, true>')
+fetch, nf = avg('pmc_fetch', 'FETCH_SIZE', os.environ['NEEDLE'])
+write, nw = avg('pmc_write', 'WRITE_SIZE', os.environ['NEEDLE'])
 out.update({"FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write, "dispatches_counted": [nf, nw], "fetch_correction": 2.0,
             "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024 if fetch and write else None,
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tools/run_scale_shapes.py; gfx950 FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"})
