@@ -1,5 +1,5 @@
 """SVD-init at the configs[3] size (BASELINE.json.metric: "SVD-init GFLOP/s, ... Higgs-11M"): the diffusion-map initialisation's randomized
-SVD (graphlaplace.rs:97-125) of the laplacian of an 11 M-node graph, timed alone.  usage: python tools/run_svd_init_c4.py [lattice|knn] [n]"""
+SVD (graphlaplace.rs:97-125) of the laplacian of an 11 M-node graph, timed alone.  usage: python tools/run_svd_init_c4.py [lattice|knn] [n] [ordered: node ids in cluster order instead of shuffled]"""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ n = int(argv[2]) if len(argv) > 2 else 11_000_000
 if which == "lattice":
     indptr, nbr, dst = bench.lattice_graph(n, 6, seed=7, permute=True)
 else:
-    gr = bench.config_graphs(A, "c4", n_override=n)
+    gr = bench.config_graphs(A, "c4", n_override=n, permute_seed=None if (len(argv) > 3 and argv[3] == "ordered") else 9)
     indptr, nbr, dst = gr["indptr"], gr["nbr"], gr["dist"]
     print(gr["desc"])
 kg = A.KGraph(indptr, nbr, dst, 6)
