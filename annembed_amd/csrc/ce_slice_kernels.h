@@ -710,8 +710,10 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
     for (uint32_t r = 1; r < a.ept && base + r * 256u < a.end; r++) pass(r, std::false_type{});
 }
 
+// (rows of <= 8 columns with f64 scalars and the LDS tile -- the big-graph path --: three waves per SIMD -- 168 VGPRs -- are worth a spill or two; the one-division arithmetic
+// sits at 171 without the bound, and a resident step of 190 k events instead of 127 k is what the slice count is sized by)
 template <int DIM, int SREC, bool F64, bool TILE>
-__global__ void __launch_bounds__(256) sl_direct_kernel(DirectArgs a) {
+__global__ void __launch_bounds__(256, (F64 && TILE && DIM <= 8) ? 3 : 1) sl_direct_kernel(DirectArgs a) {
     __shared__ StepShared<DIM, SREC, F64, TILE> sh;
     uint32_t done = 0;
     sl_step_body<DIM, SREC, F64, TILE>(a, blockIdx.x, sh, done);

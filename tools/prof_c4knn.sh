@@ -9,9 +9,9 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/tools/run_scale_shapes.py $SHAPE 3 > $OUT/run_trace.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/tools/run_scale_shapes.py $SHAPE 1 > $OUT/run_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/tools/run_scale_shapes.py $SHAPE 1 > $OUT/run_write.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o trace -- python3 $R/tools/run_step_shape.py $SHAPE 3 > $OUT/run_trace.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/tools/run_step_shape.py $SHAPE 1 > $OUT/run_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/tools/run_step_shape.py $SHAPE 1 > $OUT/run_write.log 2>&1
 cd $OUT
 python3 - <<'PY'
 import csv, glob, json, os
