@@ -296,6 +296,49 @@ def test_c4_shape_single_gpu_properties(A):
     assert abs(eh.ce_compute_threaded() - ce_uniform) < 0.01 * ce_uniform
 
 
+def test_c4_global_knn_graph_full_size(A):
+    """configs[3] on its OWN graph at full size: the exact GLOBAL kNN graph of 11 M Higgs-shaped points (k = 6; the grouped producer:
+    ~22 s) with the node ids shuffled globally -- what HNSW + the reference's IndexSet would hand over (kgraph.rs:440-579).  (1) The
+    partitioner at 8 ranks: the graph falls into a few dozen components (next to no edge leaves its cluster), they are packed into the
+    ranks with next to nothing crossing, balanced.  (2) One batch in the default mode (AE_CE_AUTO -> the time-sliced mode, hubness-weighted
+    negatives as examples/higgs.rs:204-242) against one batch of the sequential mode from the same start: samples drawn within 6 sigma,
+    finite rows, cross entropy within 1 %."""
+    sys_argv = sys.argv
+    sys.argv = ["bench.py"]
+    import bench
+    sys.argv = sys_argv
+    n, k, d = 11_000_000, 6, 8
+    gr = bench.config_graphs(A, "c4", permute_seed=9)
+    assert gr["edges_leaving_their_cluster"] < 1e-4 and gr["knn_pairs"]["fallback_rows"] < 0.001 * n
+    assert gr["knn_pairs"]["pruned_phase"] + gr["knn_pairs"]["inside_clusters"] < 0.05 * float(n) * n   # (brute force: all of n^2)
+    g = A.KGraph(gr["indptr"], gr["nbr"], gr["dist"], k)
+    hub = g.hubness()
+    assert hub.max() >= 100   # real in-degree skew (hubs)
+    order, ranges, rep = g.partition(8)
+    print("configs[3] graph, 8 ranks:", rep)
+    assert 8 <= rep["components"] <= 64 and rep["cross_mass"] < 0.01 and rep["cross_mass_worst_rank"] < 0.02 and rep["imbalance"] < 0.03, rep
+    del order
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(np.random.default_rng(3).normal(size=(n, d)).astype(np.float32), 10.0)
+    S = 10 * len(gr["nbr"])
+    ces = {}
+    for name, mode in (("auto", A.AE_CE_AUTO), ("sequential", A.AE_CE_SEQUENTIAL)):
+        h = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=d, ce_mode=mode, hubness_weighting=True), y0, hub_counts=hub)
+        assert h.get_ce_mode() == (A.AE_CE_SLICED if name == "auto" else A.AE_CE_SEQUENTIAL)
+        h.gradient_iteration_threaded(S, 0.5, 1)
+        ces[name] = h.ce_compute_threaded()
+        assert np.isfinite(h.get_embedded()).all()
+        if name == "auto":
+            drawn, _ = h.samples_drawn()
+            assert abs(drawn - S) < 6 * np.sqrt(S)
+            classes, overflow, _, slices = h.slice_info()
+            max_in, _ = h.slice_hub_info()
+            assert 11 <= classes <= 15 and overflow < 0.05 and slices >= 240 and max_in == hub.max(), (classes, overflow, slices, max_in)
+        del h
+    print("configs[3] graph, one batch: CE default / sequential = %.4f" % (ces["auto"] / ces["sequential"]))
+    assert abs(ces["auto"] - ces["sequential"]) < 0.01 * ces["sequential"], ces
+
+
 def test_c5_shape_one_shard_properties(A):
     """configs[4] shape, one GPU's share of it: the full 50 M-node graph (k = 10, ring lattice with randomly PERMUTED node ids)
     and the full 50 M x 16 coordinate replica on the device, this rank owning the first eighth of the nodes (6.25 M sources,
