@@ -468,7 +468,10 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                     for (int g = 0; g < 5; g++) load_row_coherent<DIM>(c.y, node[2 + g], negs[g]);
                 }
                 if (stage == 0 && (pending & 3u) == 0u) {
-                    sample_attract<DIM>(rows[0], rows[1], grad, w, scale, c.b, grad_step);
+                    // (the ordered form: f64 scalars with one division per interaction, ce_sample_math.h; the exact form: the reference's
+                    // operation order, bit for bit)
+                    if constexpr (RELAXED) attract_f64<DIM>(rows[0], rows[1], grad, w, rcp_f64(scale * scale), c.b, grad_step);
+                    else sample_attract<DIM>(rows[0], rows[1], grad, w, scale, c.b, grad_step);
                     if constexpr (RELAXED) df_store_version<DIM>(c.y, node[1], rows[1]);  // in place, for the negatives of others (:1239)
                     df_store_version<DIM>(ver, s * 2 + 1, rows[1]);
                     stage = 1;
@@ -494,8 +497,9 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
 #pragma unroll
                             for (int g = 0; g < 5; g++) sample_repulse_f32<DIM>(rows[0], negs[g], grad, inv_s2, (float)c.b, (float)grad_step);
                         } else {
+                            const double inv_s2 = rcp_f64(scale * scale);
 #pragma unroll
-                            for (int g = 0; g < 5; g++) sample_repulse<DIM>(rows[0], negs[g], grad, scale, c.b, grad_step);
+                            for (int g = 0; g < 5; g++) repulse_f64<DIM>(rows[0], negs[g], grad, inv_s2, c.b, grad_step);
                         }
                         stage = 6;
                     }
@@ -508,7 +512,8 @@ __global__ void __launch_bounds__(256) ce_dataflow_kernel(CeDev c, uint64_t S, c
                         if constexpr (RELAXED) load_row_coherent<DIM>(c.y, nk, yk);  // as the memory system has it now
                         else if (pk == kNoPred) load_row<DIM>(c.y, nk, yk);
                         else if (!df_try_load_version<DIM>(ver, pk, yk)) break;  // not published yet: next trip
-                        sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
+                        if constexpr (RELAXED) repulse_f64<DIM>(rows[0], yk, grad, rcp_f64(scale * scale), c.b, grad_step);
+                        else sample_repulse<DIM>(rows[0], yk, grad, scale, c.b, grad_step);
                         stage++;
                     }
                 }

@@ -402,67 +402,7 @@ __device__ __forceinline__ void repulse_f32(float* yi, const float* yk, float* g
     for (int t = 0; t < DIM; t++) yi[t] -= grad[t];
 }
 
-// The same in f64 (the mode's default: the reference's scalar type, embedder.rs:1207-1229), ONE division per interaction.  The
-// reference's formula spends four dependent f64 divisions on an attraction or a repulsion -- d / s^2, 1 / (1 + d), . / s^2,
-// 1 / max(d^2, .) -- and a sample is six interactions: 24 IEEE division sequences (a dozen dependent f64 instructions each) in a
-// row.  Measured on a rank's share of a configs[3] batch (31 k events per step: one wave per SIMD, nothing hides a dependent chain):
-// 9.4 of a step's 23.5 us.  Algebraically the coefficient is num / ((1 + d) max(d^2, .)) with 1 / s^2 taken once per sample:
-// one reciprocal per interaction, v_rcp_f64 refined by two Newton steps (what the division sequence itself does).  Still f64
-// throughout; it agrees with the four-division form to a few ulps of f64 (~1e-15 relative) before the coefficient is rounded to
-// the f32 it multiplies the coordinates with -- eight orders below that rounding.  The bit-exact modes (ce.hip) keep the
-// reference's operation order; this mode is validated statistically either way.
-__device__ __forceinline__ double rcp_f64(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-template <int DIM>
-__device__ __forceinline__ void attract_f64(float* yi, float* yj, float* grad, float w, double inv_s2, double b, double step) {
-    float acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < DIM; t++) { grad[t] = 0.f; const float df = yi[t] - yj[t]; acc += df * df; }
-    const double d = (double)acc * inv_s2;
-    if (d > 0.) {
-        const double weight = (double)w;
-        const double m = fmax(d * d, (double)(1.0f / kProbaMin));
-        double coeff_ij;
-        if (b == 1.) {   // 2 step / s^2 (-w + (1 - w) / m) / (1 + d)  =  2 step / s^2 ((1 - w) - w m) / ((1 + d) m)
-            coeff_ij = 2. * step * inv_s2 * ((1. - weight) - weight * m) * rcp_f64((1. + d) * m);
-        } else {
-            const double pb = pow(d, b);
-            coeff_ij = 2. * b * step * inv_s2 * (pb / d) * ((1. - weight) - weight * m) * rcp_f64((1. + pb) * m);
-        }
-        const float cf = (float)fmax(coeff_ij, -0.49);
-#pragma unroll
-        for (int t = 0; t < DIM; t++) grad[t] = (yj[t] - yi[t]) * cf;
-    }
-#pragma unroll
-    for (int t = 0; t < DIM; t++) { yi[t] -= grad[t]; yj[t] += grad[t]; }
-}
-template <int DIM>
-__device__ __forceinline__ void repulse_f64(float* yi, const float* yk, float* grad, double inv_s2, double b, double step) {
-    float ak = 0.f;
-#pragma unroll
-    for (int t = 0; t < DIM; t++) { const float df = yi[t] - yk[t]; ak += df * df; }
-    if (ak > 0.f) {
-        const double d = (double)ak * inv_s2;
-        const double m = fmax(d * d, 1. / 16.);
-        double coeff_ik;
-        if (b == 1.) {
-            coeff_ik = 2. * step * inv_s2 * rcp_f64((1. + d) * m);
-        } else {
-            const double pb = pow(d, b);
-            coeff_ik = 2. * b * step * inv_s2 * (pb / d) * rcp_f64((1. + pb) * m);
-        }
-        const float cf = (float)fmin(coeff_ik, 2.);
-#pragma unroll
-        for (int t = 0; t < DIM; t++) grad[t] = (yk[t] - yi[t]) * cf;
-    }  // else: `gradient` keeps its previous value, as in the reference
-#pragma unroll
-    for (int t = 0; t < DIM; t++) yi[t] -= grad[t];
-}
+// (attract_f64 / repulse_f64 -- f64 scalars with ONE division per interaction -- live in ce_sample_math.h: the ordered dataflow uses them too)
 
 // ce_optim_edge_shannon (embedder.rs:1167-1302) on yi / yj in registers, in its two phases: the attraction (one gradient, both ends
 // -- the part of a sample that a chain through the target's row serialises) and the repulsions from the `got` drawn negatives (tile
