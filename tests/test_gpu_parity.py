@@ -1159,9 +1159,13 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(kind):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo"]
+    env = dict(os.environ)
+    if kind == "faithful":   # plain `python3 bench.py --gpus 2`, as the driver calls it: bench.py starts its two ranks itself
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo"]
+        env = {k2: v2 for k2, v2 in os.environ.items() if k2 not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd += {"weak": ["--weak", "--points-per-gpu", "6000", "--dim", "64"], "rounds": ["--rounds", "--scale-nodes", "20001"],
             "faithful": ["--scale-nodes", "64000"]}[kind]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -1169,7 +1173,9 @@ def test_bench_sharded_path_two_ranks_on_one_gpu(kind):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == ("weak" if kind == "weak" else "strong")
     assert j["config"]["samples_per_step"] == {"weak": 2 * 6000 * 12 * 10, "rounds": 20001 * 6 * 10, "faithful": 64000 * 6 * 10}[kind]
     assert j["value"] > 0 and np.isfinite(j["ce_after"]) and j["roofline"]["launches_per_batch"] >= 1
+    assert len(lines[0]) < 4096 and r.stdout.strip().splitlines()[-1] == lines[0]   # the compact line, LAST
     if kind == "faithful":
+        assert j["config"]["partition"]["components"] >= 1 and j["config"]["cross_shard_mass"] < 0.05   # globally shuffled ids, the library's partition
         assert "AE_CE_SLICED" in j["config"]["ce_mode"] and str(j["faithful"]).startswith("statistically")
         assert j["dtype"].startswith("f32 coordinates, f64 scalars")
     else:

@@ -148,3 +148,24 @@ def test_partition_of_the_64_blob_global_knn_graph_at_8_ranks(A):
     order, ranges, rep = g.partition(8, y=y0, node_params=npar)
     print("64-blob global kNN graph, 8 ranks:", rep)
     assert rep["cross_mass"] < 0.05 and rep["cross_mass_worst_rank"] < 0.10 and rep["imbalance"] < 0.05, rep
+
+
+@pytest.mark.parametrize("world", [1, 3, 5])
+def test_partition_odd_worlds_and_small_graphs(A, world):
+    """world sizes that are no power of two, a single rank, a graph with fewer components than ranks and one barely larger than world"""
+    rng = np.random.default_rng(world)
+    x = np.concatenate([rng.normal(size=(700, 3)) + 20.0 * c for c in range(2)]).astype(np.float32)   # two separated clusters
+    g = A.KGraph.bruteforce_l2(x, 5)
+    indptr, nbr, _ = g.get_neighbours()
+    order, ranges, rep = g.partition(world, y=x)
+    _check_partition(len(x), order, ranges, world)
+    assert rep["components"] == 2 and rep["imbalance"] < 0.05
+    if world == 1:
+        assert rep["cross_mass"] == 0.0 and rep["splits"] == 0
+    else:
+        assert rep["cross_mass"] < 0.25 and abs(_cross_fraction(indptr, nbr, order, ranges) - rep["cross_mass"]) < 1e-9
+    tiny = A.KGraph.bruteforce_l2(rng.normal(size=(40, 2)).astype(np.float32), 3)
+    o2, r2, _ = tiny.partition(min(world, 4))
+    _check_partition(40, o2, r2, min(world, 4))
+    with pytest.raises(A.AnnembedError):
+        tiny.partition(65)     # more ranks than the library supports
