@@ -127,6 +127,7 @@ struct ae_entropy_optim {
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
     DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
+    DevBuf<unsigned long long> sl_dep;          // merged slices: per node, classes through with the node << 32 | classes with an event on it; all zero between slices
     DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
     DevBuf<uint32_t> sl_hub_pool;               // (hubness weighting) the batch's pool of NodeSampler draws for the tiles of negatives
     // internal node numbering of the time-sliced mode (one device): node v lives in row sl_perm[v] of sl_y / the static records during a

@@ -418,6 +418,24 @@ __global__ void __launch_bounds__(256) sl_hub_tab_kernel(uint64_t n, const uint3
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// merged slices (sl_slice_kernel, ce_slice_kernels.h)
+// ------------------------------------------------------------------------------------------------------------------
+// before the launch: every event of the slice enters its class in the words of its two nodes (fire-and-forget atomics)
+__global__ void __launch_bounds__(256) sl_dep_mark_kernel(SliceRunArgs a) {
+    __shared__ uint32_t s_ptr[kDepBits + 1];
+    if (threadIdx.x <= a.classes) s_ptr[threadIdx.x] = a.sptr[threadIdx.x];
+    __syncthreads();
+    const uint32_t p = s_ptr[0] + blockIdx.x * 256u + threadIdx.x;
+    if (p >= s_ptr[a.classes]) return;
+    uint32_t q = 0;
+    while (q + 1u < a.classes && p >= s_ptr[q + 1u]) q++;
+    const Event e = a.d.ev[p];
+    uint32_t* words = reinterpret_cast<uint32_t*>(a.dep);   // (little endian: the low word of a node's 64 bits holds the classes)
+    if (!ev_half(e.j)) atomicOr(words + 2ull * (e.im >> 5), 1u << q);   // (a half event reads its source's row from the replica: nobody here writes it)
+    atomicOr(words + 2ull * ev_node(e.j), 1u << q);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // the overflow class of a slice: optimistic passes
 // ------------------------------------------------------------------------------------------------------------------
 // start of a slice: pending list = what the previous slice left + the slice's own overflow events; every one marks its two rows.
@@ -1004,6 +1022,27 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             try { for (uint64_t x = done; x < owed; x++) ce_comm_exchange(o); } catch (...) {}
         }
     } owe{o, exchanges_done, (uint64_t)segments * exchanges};
+    // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
+    // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
+    // Full steps stay one launch per class: they are bound by requests, and the two dependency words per event would only add to them.
+    const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
+    const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
+                        (debug_knob("AE_SL_MERGE") || step_events < 0.2 * sl_resident_events(o));   // (measured: 31 k events per step 60.5 -> 53.1 ms, 62 k: 71.0 -> 75.2)
+    if (merged) {
+        if (o->sl_dep.n < n) o->sl_dep.alloc(n);
+        o->sl_dep.zero();
+    }
+    uint32_t step_seq_base = 0;
+    auto slice_args = [&](uint32_t s) {
+        SliceRunArgs ra;
+        ra.d = da;
+        ra.d.ept = 1;
+        ra.sptr = o->sl_sptr.p + (size_t)s * (classes + 1u);
+        ra.classes = classes;
+        ra.step_seq0 = step_seq_base + s * classes;
+        ra.dep = o->sl_dep.p;
+        return ra;
+    };
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
@@ -1060,8 +1099,25 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         da.key = key;
         // NOTE: event indices are positions in this segment's sorted array; what is still pending when a segment ends is
         // finished (the drain below) before the next segment reuses the arrays
+        if (merged) {
+            step_seq_base = step_seq;
+            step_seq += n_slices * classes;
+        }
         for (uint32_t s = 0; s < n_slices; s++) {
             const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
+            if (merged) {
+                // every class of the slice in ONE launch, the order between events kept node by node (sl_slice_kernel); its dependency words
+                // are filled by a pass over its events first.  (Filling the next slice's on a side stream while this one runs -- two sets
+                // of words, events both ways -- was built and measured: 50.8 against 50.0 ms; the pass is 29 us of random atomics.)
+                if (sp[classes] > sp[0]) {
+                    const SliceRunArgs ra = slice_args(s);
+                    unsigned grid = 0;
+                    for (uint32_t q = 0; q < classes; q++) grid += (sp[q + 1] - sp[q] + 255u) / 256u;
+                    hipLaunchKernelGGL(sl_dep_mark_kernel, dim3(blocks_for(sp[classes] - sp[0], 256)), dim3(256), 0, stream(), ra);
+                    const bool tile_run = use_tile && !y_in_cache && (uint64_t)(sp[classes] - sp[0]) / classes >= tile_min_events;
+                    AE_DISPATCH_DIM(o->dev.dim, launch_slice, ra, grid, o->sl_srec_floats, f64, tile_run);
+                }
+            } else
             for (uint32_t q = 0; q < classes; q++) {  // the slice's matchings, in this slice's order
                 if (sp[q + 1] == sp[q]) continue;
                 da.begin = sp[q];
@@ -1200,6 +1256,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         o->sl_counts.zero();
         sync();
         if (h[1024] & 2ull) fail(AE_ERR_STATE, "AE_CE_SLICED: a hub chain waited for the previous chunk beyond the poll budget (is another process using this GPU?)");
+        if (h[1024] & (unsigned long long)kErrDepPoll)
+            fail(AE_ERR_STATE, "AE_CE_SLICED: an event of a merged slice waited for an earlier class on one of its nodes beyond the poll budget (is another process using this GPU?)");
         fail(AE_ERR_STATE, "AE_CE_SLICED: pending list overflow");
     }
     // samples executed, into the common counter

@@ -661,6 +661,196 @@ __global__ void __launch_bounds__(256, (F64 && TILE && DIM <= 8) ? 3 : 1) sl_dir
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// a whole SLICE in one launch: the classes of a slice side by side, ordered node by node instead of launch by launch
+// ------------------------------------------------------------------------------------------------------------------
+// A step with few events (a rank's share of a sharded batch, any graph of ~10^6 nodes) is a chain of latencies: 19-24 us however
+// little it holds, and a slice is k + 5 of them.  But only ~17 % of a slice's events share a node with another event of the slice
+// (half an event per node and slice): the launch boundary between two classes orders ALL events of the one before ALL of the other
+// where the law only asks for an order between events that share a node.  Here every class of a slice runs in ONE launch, a workgroup
+// holding events of one class only, and the order between two events on a node is kept node by node: a per-node word (`dep`) holds
+// the classes that have an event on the node (set by a pass over the slice's events before the launch: two fire-and-forget
+// atomics per event) and the classes that are through with it; the node's last event of the slice wipes the word.  An event whose node has an earlier class waits for that class's bit (polls, a budget
+// instead of a hang), then reads the row with agent-scope loads; an event whose node has a later class writes the row through
+// (agent-scope stores), waits for them and sets its bit.  The other ~83 % run exactly as in sl_step_body.  Workgroups are
+// dispatched in index order and a class's workgroups come before the next class's: an event only ever waits for a workgroup that
+// is already running.  Chains through a shared target stay what they were; the chain as a whole takes the target's place in the
+// node's order (its head waits, its tail signals).
+constexpr uint32_t kDepBits = 32;                       // classes a merged slice can hold
+constexpr uint32_t kErrDepPoll = 16u;                   // done_counter[1024] flag: a dependency inside a merged slice was not met within the poll budget
+struct SliceRunArgs {
+    DirectArgs d;                  // c, srec, ev, key, step, done_counter, chunk_flag, hub_pool (begin / end / step_seq / ept / tile: per class, below)
+    const uint32_t* sptr;          // this slice's class pointers: class position q = [sptr[q], sptr[q + 1])
+    uint32_t classes;
+    uint32_t step_seq0;            // running step number of the slice's first class
+    unsigned long long* dep;       // [n]: classes through with the node << 32 | classes with an event on the node; all zero between slices
+};
+__device__ __forceinline__ uint32_t dep_classes(unsigned long long w) { return (uint32_t)w; }
+__device__ __forceinline__ uint32_t dep_done(unsigned long long w) { return (uint32_t)(w >> 32); }
+// (sl_dep_mark_kernel, the pass over a slice's events that fills the words before the launch: ce_slice.hip)
+template <int DIM, int SREC, bool F64, bool TILE>
+__global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
+    constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
+    __shared__ StepShared<DIM, SREC, F64, TILE> sh;
+    const DirectArgs& a = ra.d;
+    const CeDev c = a.c;
+    const bool hub = c.hub_odds != nullptr;
+    float* stage = sh.stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
+    const uint32_t nkey = pcg_hash((uint32_t)c.seed ^ a.key ^ kTagSlNeg);
+    const int lane = threadIdx.x & 63;
+    // this workgroup's class and its place in the class (uniform)
+    uint32_t q = 0, block = blockIdx.x, s_begin = ra.sptr[0], s_end = ra.sptr[1];
+    for (;;) {
+        const uint32_t nb = (s_end - s_begin + 255u) >> 8;
+        if (block < nb || q + 1u >= ra.classes) break;
+        block -= nb;
+        q++;
+        s_begin = s_end;
+        s_end = ra.sptr[q + 1u];
+    }
+    const uint32_t s_seq = ra.step_seq0 + q;
+    const uint32_t wkey = pcg_hash(nkey + s_seq * 0x85EBCA6Bu) + block * 64u;
+    const uint32_t p = s_begin + block * 256u + threadIdx.x;
+    uint32_t done = 0;
+    // hop 1: the event and its two neighbours in the array, the tile
+    const bool act0 = p < s_end;
+    Event e{0u, kNoNode}, pv{0u, kNoNode}, nx{0u, kNoNode};
+    if (act0) {
+        e = a.ev[p];
+        if (p > s_begin) pv = a.ev[p - 1];
+        if (p + 1 < s_end) nx = a.ev[p + 1];
+    }
+    TileFetch<DIM> ft;
+    if constexpr (TILE) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
+    const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;
+    const bool half = act0 && ev_half(e.j);
+    const bool inrun = act0 && p > s_begin && ev_node(pv.j) == j;
+    const bool next_inrun = act0 && p + 1u < s_end && ev_node(nx.j) == j;
+    const bool absorbed = inrun && pv.im == e.im;
+    const bool cmp = act0 && !absorbed;
+    uint32_t rep = 1;
+    if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < s_end && a.ev[p + rep].im == e.im && ev_node(a.ev[p + rep].j) == j) rep++; }
+    const unsigned long long run_mask = __ballot(inrun);
+    const bool cont = (run_mask & 1ull) != 0ull;
+    const unsigned long long heads = ~run_mask | 1ull;
+    const int head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+    const uint32_t runpos = act0 ? (uint32_t)(lane - head) + ((cont && head == 0) ? 1u : 0u) : 0u;
+    const bool last_in_seg = lane == 63 || !((run_mask >> (lane + 1)) & 1ull);
+    const bool hand_over = act0 && lane == 63 && next_inrun;
+    float yi[DIM], yj[DIM], scale_f = 1.f, w = 0.f;
+    uint32_t nbr_reg[KREG];
+    // hop 2: record, rows -- and the two dependency words
+    RecFetch<SREC, KREG> fr;
+    RowFetch<DIM> fi, fj;
+    unsigned long long wi = 0ull, wj = 0ull;
+    if (cmp && !half) wi = __hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (act0) wj = __hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
+    fi.issue(c.y, i, cmp, yi);
+    fj.issue(c.y, j, cmp && !inrun, yj);
+    if constexpr (TILE) ft.land(sh.tile, sh.tnode);
+    fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
+    fi.land(stage, yi);
+    fj.land(stage, yj);
+    // the node-by-node order: classes before this one that hold the node must be through with it; classes after it will wait for us
+    const uint32_t below = (1u << q) - 1u;
+    const uint32_t above = q >= 31u ? 0u : ~((2u << q) - 1u);
+    const uint32_t need_i = (cmp && !half) ? (dep_classes(wi) & below) : 0u;
+    const uint32_t need_j = (cmp && !inrun) ? (dep_classes(wj) & below) : 0u;   // (a chain's head stands for the chain)
+    const bool succ_i = cmp && !half && (dep_classes(wi) & above) != 0u;
+    const bool succ_j = act0 && (dep_classes(wj) & above) != 0u;
+    if (need_i | need_j) {
+        uint32_t polls = 0;
+        for (;;) {
+            const bool ok_i = !need_i || (dep_done(__hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_i) == need_i;
+            const bool ok_j = !need_j || (dep_done(__hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_j) == need_j;
+            if (ok_i && ok_j) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > (1u << 22)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), kErrDepPoll); break; }
+        }
+        if (need_i) load_row_agent<DIM>(c.y, i, yi);
+        if (need_j) load_row_agent<DIM>(c.y, j, yj);
+    }
+    const uint32_t chunk = (s_begin >> 6) + ((p - s_begin) >> 6);
+    SplitSample<DIM, F64, TILE> sm;
+    uint32_t neg[5], got = 0;
+    if (cmp && !half) {
+        got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
+        sm.fetch(c, sh.tile, neg);
+    }
+    for (uint32_t t = 0;; t++) {
+        if (t >= 1u) {   // (only chunks with chains get here)
+            float in[DIM];
+#pragma unroll
+            for (int z = 0; z < DIM; z++) in[z] = __shfl_up(yj[z], 1);
+            if (t == 1u && cont && lane == 0) {   // the target's row as the previous chunk left it
+                const uint32_t token = s_seq + 1u;
+                uint32_t polls = 0;
+                while (__hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1u << 24)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 2u); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                load_row_agent<DIM>(c.y, j, in);
+            }
+            if (act0 && runpos == t) {
+#pragma unroll
+                for (int z = 0; z < DIM; z++) yj[z] = in[z];
+            }
+        }
+        if (cmp && runpos == t) {
+            for (uint32_t z = 0; z + 1u < rep; z++) {   // earlier repetitions of the edge: whole samples, one after the other
+                uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
+                const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + z)), i, nbr_reg, ng);
+                run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
+            }
+            sm.attract(c, yi, yj, w, scale_f, a.step);
+        }
+        if (!__ballot(act0 && runpos > t)) break;
+    }
+    if (cmp && !half) {
+        sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
+        done += rep;
+    }
+    // stores: as sl_step_body for the rows no later class of the slice will ask for; the others are written through, waited for, and
+    // announced in the node's word
+    const bool store_j = act0 && last_in_seg && !hand_over;
+    const bool store_i = cmp && !half;
+    row_store<DIM>(c.y, j, store_j && !succ_j, stage, yj);   // :1239
+    row_store<DIM>(c.y, i, store_i && !succ_i, stage, yi);   // :1301
+    const bool sig_i = store_i && succ_i, sig_j = store_j && succ_j;
+    if (sig_i) store_row_agent<DIM>(c.y, i, yi);
+    if (sig_j) store_row_agent<DIM>(c.y, j, yj);
+    if (sig_i | sig_j) {   // write-through stores, waited for, then the bit (the guide's flag hand-off: no cache write-back in between)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (sig_i) atomicOr(ra.dep + i, 1ull << (32u + q));
+        if (sig_j) atomicOr(ra.dep + j, 1ull << (32u + q));
+    }
+    // the node's last event of the slice wipes its word (everybody who had to read it has: they are earlier classes, or this chain)
+    if (store_i && !succ_i) ra.dep[i] = 0ull;
+    if (store_j && !succ_j) ra.dep[j] = 0ull;
+    if (hand_over) {
+        store_row_agent<DIM>(c.y, j, yj);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&a.chunk_flag[chunk], s_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
+}
+template <int DIM, bool F64, bool TILE>
+void launch_slice3(const SliceRunArgs& a, unsigned grid, uint32_t srec) {
+    if (srec == 16) hipLaunchKernelGGL((sl_slice_kernel<DIM, 16, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else if (srec == 32) hipLaunchKernelGGL((sl_slice_kernel<DIM, 32, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else if (srec == 64) hipLaunchKernelGGL((sl_slice_kernel<DIM, 64, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+    else hipLaunchKernelGGL((sl_slice_kernel<DIM, 128, F64, TILE>), dim3(grid), dim3(256), 0, stream(), a);
+}
+template <int DIM>
+void launch_slice(const SliceRunArgs& a, unsigned grid, uint32_t srec, bool f64, bool tile_wanted) {
+    const bool tile = tile_wanted && a.d.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    if (f64) { if (tile) launch_slice3<DIM, true, true>(a, grid, srec); else launch_slice3<DIM, true, false>(a, grid, srec); }
+    else { if (tile) launch_slice3<DIM, false, true>(a, grid, srec); else launch_slice3<DIM, false, false>(a, grid, srec); }
+}
+
 // (A persistent form of this kernel -- the class steps of a run of slices in ONE launch, a grid barrier between steps, the next step's
 // events and static records requested before the wait -- was built and measured in round 5 and is not kept: on a rank's share of a
 // configs[3] batch, 31 k events per step, it ran 24.3 us per step against 23.6 us for one launch per step; the counter barrier with its
@@ -881,6 +1071,7 @@ void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
 #define AE_SL_LAUNCHERS(PREFIX, D)                                                                                                        \
     PREFIX template void launch_direct<D>(const DirectArgs&, uint32_t, bool);                                                             \
     PREFIX template void direct_blocks_per_cu<D>(uint32_t, bool, bool, int*);                                                             \
+    PREFIX template void launch_slice<D>(const SliceRunArgs&, unsigned, uint32_t, bool, bool);                                            \
     PREFIX template void launch_exec<D>(const SliceArgs&, unsigned, uint32_t, bool);                                                      \
     PREFIX template void launch_chain_run<D>(const SliceArgs&, unsigned, uint32_t, bool, const uint32_t*, const uint32_t*);
 #ifdef AE_SL_INSTANTIATE_DIM

@@ -37,7 +37,7 @@ print("RESULT n %%d world %%d: %%.1f ms per batch and rank, %%d classes, overflo
 
 n = sys.argv[1] if len(sys.argv) > 1 else "11000000"
 for world in (sys.argv[2:] or ["8", "4", "2", "1"]):
-    variants = [("launches", {"AE_DEBUG_KNOBS": "1", "AE_SL_NO_PERSIST": "1"}), ("persistent", {"AE_DEBUG_KNOBS": "1", "AE_SL_PERSIST": "1"}), ("default", {})]
+    variants = [("one launch per class", {"AE_DEBUG_KNOBS": "1", "AE_SL_NO_MERGE": "1"}), ("merged slices", {"AE_DEBUG_KNOBS": "1", "AE_SL_MERGE": "1"}), ("default", {})]
     if os.environ.get("AE_AB_DBG"):   # timing experiments (results are wrong): 16 no release fence, 32 no acquire fence, 64 no barrier wait
         variants = [("persistent dbg %s" % v, {"AE_DEBUG_KNOBS": "1", "AE_SL_PERSIST": "1", "AE_SL_DBG": v}) for v in os.environ["AE_AB_DBG"].split(",")]
     if os.environ.get("AE_AB_LAUNCH_DBG"):   # the launch path's debug variants: 1 no arithmetic, 2 no stores, 4 no negatives, 8 no static record
