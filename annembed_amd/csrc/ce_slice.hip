@@ -420,7 +420,8 @@ __global__ void __launch_bounds__(256) sl_hub_tab_kernel(uint64_t n, const uint3
 // ------------------------------------------------------------------------------------------------------------------
 // merged slices (sl_slice_kernel, ce_slice_kernels.h)
 // ------------------------------------------------------------------------------------------------------------------
-// before the launch: every event of the slice enters its class in the words of its two nodes (fire-and-forget atomics)
+// before the launch: every event of the slice enters its class in the words of its two nodes (fire-and-forget atomics).  Only for a slice
+// whose predecessor could not do it (the first of a segment, one after an empty slice): sl_slice_kernel prepares the next slice itself.
 __global__ void __launch_bounds__(256) sl_dep_mark_kernel(SliceRunArgs a) {
     __shared__ uint32_t s_ptr[kDepBits + 1];
     if (threadIdx.x <= a.classes) s_ptr[threadIdx.x] = a.sptr[threadIdx.x];
@@ -429,10 +430,7 @@ __global__ void __launch_bounds__(256) sl_dep_mark_kernel(SliceRunArgs a) {
     if (p >= s_ptr[a.classes]) return;
     uint32_t q = 0;
     while (q + 1u < a.classes && p >= s_ptr[q + 1u]) q++;
-    const Event e = a.d.ev[p];
-    uint32_t* words = reinterpret_cast<uint32_t*>(a.dep);   // (little endian: the low word of a node's 64 bits holds the classes)
-    if (!ev_half(e.j)) atomicOr(words + 2ull * (e.im >> 5), 1u << q);   // (a half event reads its source's row from the replica: nobody here writes it)
-    atomicOr(words + 2ull * ev_node(e.j), 1u << q);
+    dep_mark_event(a.dep, a.d.ev[p], q);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1028,10 +1026,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
     const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
                         (debug_knob("AE_SL_MERGE") || step_events < 0.2 * sl_resident_events(o));   // (measured: 31 k events per step 60.5 -> 53.1 ms, 62 k: 71.0 -> 75.2)
-    if (merged) {
-        if (o->sl_dep.n < n) o->sl_dep.alloc(n);
+    if (merged) {   // two sets of words: a slice runs on one while the next slice's events enter the other
+        if (o->sl_dep.n < 2 * n) o->sl_dep.alloc(2 * n);
         o->sl_dep.zero();
     }
+    bool premarked = false;   // the slice about to run had its words filled by the slice before it
     uint32_t step_seq_base = 0;
     auto slice_args = [&](uint32_t s) {
         SliceRunArgs ra;
@@ -1040,7 +1039,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ra.sptr = o->sl_sptr.p + (size_t)s * (classes + 1u);
         ra.classes = classes;
         ra.step_seq0 = step_seq_base + s * classes;
-        ra.dep = o->sl_dep.p;
+        ra.dep = o->sl_dep.p + (size_t)(s & 1u) * n;
+        ra.next_sptr = nullptr;
+        ra.dep_next = o->sl_dep.p + (size_t)((s + 1u) & 1u) * n;
         return ra;
     };
     for (uint32_t sg = 0; sg < segments; sg++) {
@@ -1106,14 +1107,18 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         for (uint32_t s = 0; s < n_slices; s++) {
             const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
             if (merged) {
-                // every class of the slice in ONE launch, the order between events kept node by node (sl_slice_kernel); its dependency words
-                // are filled by a pass over its events first.  (Filling the next slice's on a side stream while this one runs -- two sets
-                // of words, events both ways -- was built and measured: 50.8 against 50.0 ms; the pass is 29 us of random atomics.)
+                // every class of the slice in ONE launch, the order between events kept node by node (sl_slice_kernel).  Its dependency words
+                // were filled by the slice before it, from inside its kernel (a wave that is through enters the next slice's events: the
+                // atomics run beside the other waves' work); only a slice without such a predecessor takes the pass of its own (29 us of
+                // random atomics at 344 k events).  (The same pass on a side stream bought nothing: 50.8 against 50.0 ms -- its workgroups
+                // wait for slots the slice's own hold.)
                 if (sp[classes] > sp[0]) {
-                    const SliceRunArgs ra = slice_args(s);
+                    SliceRunArgs ra = slice_args(s);
                     unsigned grid = 0;
                     for (uint32_t q = 0; q < classes; q++) grid += (sp[q + 1] - sp[q] + 255u) / 256u;
-                    hipLaunchKernelGGL(sl_dep_mark_kernel, dim3(blocks_for(sp[classes] - sp[0], 256)), dim3(256), 0, stream(), ra);
+                    if (!premarked) hipLaunchKernelGGL(sl_dep_mark_kernel, dim3(blocks_for(sp[classes] - sp[0], 256)), dim3(256), 0, stream(), ra);
+                    premarked = s + 1u < n_slices && sp[2u * classes + 1u] > sp[classes + 1u] && !debug_knob("AE_SL_NO_PREMARK");
+                    if (premarked) ra.next_sptr = ra.sptr + (classes + 1u);
                     const bool tile_run = use_tile && !y_in_cache && (uint64_t)(sp[classes] - sp[0]) / classes >= tile_min_events;
                     AE_DISPATCH_DIM(o->dev.dim, launch_slice, ra, grid, o->sl_srec_floats, f64, tile_run);
                 }

@@ -684,7 +684,15 @@ struct SliceRunArgs {
     uint32_t classes;
     uint32_t step_seq0;            // running step number of the slice's first class
     unsigned long long* dep;       // [n]: classes through with the node << 32 | classes with an event on the node; all zero between slices
+    const uint32_t* next_sptr;     // the NEXT slice's class pointers (nullptr: nothing to prepare): its events enter `dep_next` while this slice runs
+    unsigned long long* dep_next;  // [n]: the other set of words (a slice cleans its own set as it goes)
 };
+// an event of a slice enters its class in the words of its two nodes (fire-and-forget atomics on the words' low halves)
+__device__ __forceinline__ void dep_mark_event(unsigned long long* dep, const Event e, uint32_t q) {
+    uint32_t* words = reinterpret_cast<uint32_t*>(dep);   // (little endian: the low word of a node's 64 bits holds the classes)
+    if (!ev_half(e.j)) atomicOr(words + 2ull * (e.im >> 5), 1u << q);   // (a half event reads its source's row from the replica: nobody here writes it)
+    atomicOr(words + 2ull * ev_node(e.j), 1u << q);
+}
 __device__ __forceinline__ uint32_t dep_classes(unsigned long long w) { return (uint32_t)w; }
 __device__ __forceinline__ uint32_t dep_done(unsigned long long w) { return (uint32_t)(w >> 32); }
 // (sl_dep_mark_kernel, the pass over a slice's events that fills the words before the launch: ce_slice.hip)
@@ -712,6 +720,7 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     const uint32_t wkey = pcg_hash(nkey + s_seq * 0x85EBCA6Bu) + block * 64u;
     const uint32_t p = s_begin + block * 256u + threadIdx.x;
     uint32_t done = 0;
+    const uint32_t next_ptr = ra.next_sptr ? ra.next_sptr[min((uint32_t)lane, ra.classes)] : 0u;   // (lane l: where the next slice's class l starts)
     // hop 1: the event and its two neighbours in the array, the tile
     const bool act0 = p < s_end;
     Event e{0u, kNoNode}, pv{0u, kNoNode}, nx{0u, kNoNode};
@@ -731,10 +740,6 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     uint32_t rep = 1;
     if (cmp && next_inrun && nx.im == e.im) { rep = 2; while (p + rep < s_end && a.ev[p + rep].im == e.im && ev_node(a.ev[p + rep].j) == j) rep++; }
     const unsigned long long run_mask = __ballot(inrun);
-    const bool cont = (run_mask & 1ull) != 0ull;
-    const unsigned long long heads = ~run_mask | 1ull;
-    const int head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
-    const uint32_t runpos = act0 ? (uint32_t)(lane - head) + ((cont && head == 0) ? 1u : 0u) : 0u;
     const bool last_in_seg = lane == 63 || !((run_mask >> (lane + 1)) & 1ull);
     const bool hand_over = act0 && lane == 63 && next_inrun;
     float yi[DIM], yj[DIM], scale_f = 1.f, w = 0.f;
@@ -759,80 +764,106 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     const uint32_t need_j = (cmp && !inrun) ? (dep_classes(wj) & below) : 0u;   // (a chain's head stands for the chain)
     const bool succ_i = cmp && !half && (dep_classes(wi) & above) != 0u;
     const bool succ_j = act0 && (dep_classes(wj) & above) != 0u;
-    if (need_i | need_j) {
-        uint32_t polls = 0;
-        for (;;) {
-            const bool ok_i = !need_i || (dep_done(__hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_i) == need_i;
-            const bool ok_j = !need_j || (dep_done(__hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_j) == need_j;
-            if (ok_i && ok_j) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1u << 22)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), kErrDepPoll); break; }
-        }
-        if (need_i) load_row_agent<DIM>(c.y, i, yi);
-        if (need_j) load_row_agent<DIM>(c.y, j, yj);
-    }
     const uint32_t chunk = (s_begin >> 6) + ((p - s_begin) >> 6);
     SplitSample<DIM, F64, TILE> sm;
     uint32_t neg[5], got = 0;
-    if (cmp && !half) {
+    if (cmp && !half) {   // (the negatives do not wait for anybody: drawn and requested before the first poll)
         got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
         sm.fetch(c, sh.tile, neg);
     }
-    for (uint32_t t = 0;; t++) {
-        if (t >= 1u) {   // (only chunks with chains get here)
-            float in[DIM];
-#pragma unroll
-            for (int z = 0; z < DIM; z++) in[z] = __shfl_up(yj[z], 1);
-            if (t == 1u && cont && lane == 0) {   // the target's row as the previous chunk left it
-                const uint32_t token = s_seq + 1u;
-                uint32_t polls = 0;
-                while (__hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1u << 24)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 2u); break; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                load_row_agent<DIM>(c.y, j, in);
-            }
-            if (act0 && runpos == t) {
-#pragma unroll
-                for (int z = 0; z < DIM; z++) yj[z] = in[z];
-            }
-        }
-        if (cmp && runpos == t) {
-            for (uint32_t z = 0; z + 1u < rep; z++) {   // earlier repetitions of the edge: whole samples, one after the other
-                uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
-                const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + z)), i, nbr_reg, ng);
-                run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
-            }
-            sm.attract(c, yi, yj, w, scale_f, a.step);
-        }
-        if (!__ballot(act0 && runpos > t)) break;
-    }
-    if (cmp && !half) {
-        sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
-        done += rep;
-    }
-    // stores: as sl_step_body for the rows no later class of the slice will ask for; the others are written through, waited for, and
-    // announced in the node's word
+    // LANE BY LANE: a lane runs as soon as ITS OWN predecessors are through -- the classes before it on its two nodes, the lane
+    // before it in a chain -- and announces its rows at once.  (The first form waited for all 64 lanes' predecessors before any
+    // lane ran: since nearly every wave holds some lane with a predecessor, and that one sat in a wave that waited likewise, the
+    // slice ran as a chain of waves k + 5 deep -- 140 us for 344 k events -- although an event's own chain is 1-2 events long.)
+    //   phase 0: waiting / ready for the attraction; 1: attracted, the target's row handed on; 2: through.
+    // The repulsions (y_i only) and the stores wait while a chain is taking its turns in this wave: a turn stays one attraction.
+    const bool follows = inrun && lane > 0;            // the target's row comes from the lane before (wave shuffle)
+    const bool from_prev_chunk = inrun && lane == 0;   // ... from the chunk before (memory, the chunk's flag)
     const bool store_j = act0 && last_in_seg && !hand_over;
     const bool store_i = cmp && !half;
-    row_store<DIM>(c.y, j, store_j && !succ_j, stage, yj);   // :1239
-    row_store<DIM>(c.y, i, store_i && !succ_i, stage, yi);   // :1301
-    const bool sig_i = store_i && succ_i, sig_j = store_j && succ_j;
-    if (sig_i) store_row_agent<DIM>(c.y, i, yi);
-    if (sig_j) store_row_agent<DIM>(c.y, j, yj);
-    if (sig_i | sig_j) {   // write-through stores, waited for, then the bit (the guide's flag hand-off: no cache write-back in between)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (sig_i) atomicOr(ra.dep + i, 1ull << (32u + q));
-        if (sig_j) atomicOr(ra.dep + j, 1ull << (32u + q));
+    uint32_t phase = act0 ? 0u : 2u;
+    bool ok_dep = !(need_i | need_j), ok_flag = !from_prev_chunk;
+    uint32_t idle = 0;
+    for (;;) {
+        float in[DIM];
+#pragma unroll
+        for (int z = 0; z < DIM; z++) in[z] = __shfl_up(yj[z], 1);
+        const uint32_t pphase = __shfl_up(phase, 1);
+        if (phase == 0u && !ok_dep) {
+            const bool ok_i = !need_i || (dep_done(__hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_i) == need_i;
+            const bool ok_j = !need_j || (dep_done(__hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_j) == need_j;
+            ok_dep = ok_i && ok_j;
+        }
+        if (phase == 0u && !ok_flag) ok_flag = __hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s_seq + 1u;
+        const bool go = phase == 0u && ok_dep && ok_flag && (!follows || pphase >= 1u);
+        if (go) {
+            if (follows) {
+#pragma unroll
+                for (int z = 0; z < DIM; z++) yj[z] = in[z];
+            } else if (from_prev_chunk) {   // the target's row as the previous chunk left it
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                load_row_agent<DIM>(c.y, j, yj);
+            } else if (need_j) load_row_agent<DIM>(c.y, j, yj);
+            if (need_i) load_row_agent<DIM>(c.y, i, yi);
+            if (cmp) {
+                for (uint32_t z = 0; z + 1u < rep; z++) {   // earlier repetitions of the edge: whole samples, one after the other
+                    uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
+                    const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + z)), i, nbr_reg, ng);
+                    run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
+                }
+                sm.attract(c, yi, yj, w, scale_f, a.step);
+            }
+            // the target's row is final for this class once its chain segment's last lane has attracted: handed to the next chunk, or
+            // to the classes behind, NOW (write-through stores, waited for, then the flag / the bit: no cache write-back in between)
+            if (hand_over) {
+                store_row_agent<DIM>(c.y, j, yj);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(&a.chunk_flag[chunk], s_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (store_j && succ_j) {
+                store_row_agent<DIM>(c.y, j, yj);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                atomicOr(ra.dep + j, 1ull << (32u + q));
+            }
+            phase = 1u;
+        }
+        const bool moving = __ballot(go && next_inrun && lane < 63) != 0ull;   // a lane of this wave takes its turn next time round
+        if (!moving && __ballot(phase == 1u)) {
+            const bool fin = phase == 1u;
+            if (fin && store_i) {
+                sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
+                done += rep;
+            }
+            // stores: as sl_step_body for the rows no later class of the slice will ask for; the node's last event of the slice wipes its
+            // word (everybody who had to read it has: they are earlier classes, or this chain)
+            row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj);   // :1239
+            row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi);   // :1301
+            if (fin && store_i && succ_i) {
+                store_row_agent<DIM>(c.y, i, yi);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                atomicOr(ra.dep + i, 1ull << (32u + q));
+            }
+            if (fin && store_i && !succ_i) ra.dep[i] = 0ull;
+            if (fin && store_j && !succ_j) ra.dep[j] = 0ull;
+            if (fin) phase = 2u;
+        }
+        if (!__ballot(phase != 2u)) break;
+        if (!__ballot(go)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++idle > (1u << 22)) {   // a budget instead of a hang: the batch fails with the flag's message
+                if (phase != 2u) atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), (!ok_flag) ? 2u : kErrDepPoll);
+                break;
+            }
+        } else idle = 0;
     }
-    // the node's last event of the slice wipes its word (everybody who had to read it has: they are earlier classes, or this chain)
-    if (store_i && !succ_i) ra.dep[i] = 0ull;
-    if (store_j && !succ_j) ra.dep[j] = 0ull;
-    if (hand_over) {
-        store_row_agent<DIM>(c.y, j, yj);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&a.chunk_flag[chunk], s_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The NEXT slice's events enter their words now: two fire-and-forget atomics per event (~24 G/s: 29 us for a slice of 344 k events
+    // as a launch of its own) that nothing in this slice waits for -- issued when a wave is through, they run beside the other waves' work.
+    if (ra.next_sptr) {
+        const uint32_t n_begin = __shfl(next_ptr, 0), n_end = __shfl(next_ptr, (int)ra.classes);
+        for (uint32_t t = n_begin + blockIdx.x * 256u + threadIdx.x; t < n_end; t += gridDim.x * 256u) {
+            uint32_t qn = 0;
+            for (uint32_t l = 1; l < ra.classes; l++) qn += t >= (uint32_t)__shfl(next_ptr, (int)l) ? 1u : 0u;
+            dep_mark_event(ra.dep_next, a.ev[t], qn);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
