@@ -543,6 +543,10 @@ const char* ce_slice_unsupported(const ae_entropy_optim* o) {
 // the edge colouring of the graph (see the kernels above): sl_color[e] = class of edge e or kOverflowColor, and the event-generation
 // order of the edges (the edges of a class that share a target side by side)
 static double sl_resident_events(ae_entropy_optim* o);
+// Slices run merged (sl_slice_kernel) while a class step holds less than this share of what the device holds at once.  Measured on a
+// rank's share of an 11 M-node graph (resident step 190 k events): 31 k events per step 59.8 -> 33.2 ms per batch, 62 k 68.5 -> 57.2,
+// 125 k 85.8 -> 112 (full steps are bound by requests, and the dependency words add four per event to the step's six).
+constexpr double kMergeBelow = 0.45;
 static void slice_color_edges(ae_entropy_optim* o) {
     const uint64_t n = o->dev.n, nnz = o->dev.nnz;
     EdgeRec* erec = reinterpret_cast<EdgeRec*>(o->sl_erec.p);
@@ -658,6 +662,19 @@ static void slice_color_edges(ae_entropy_optim* o) {
         const double fit = events / (sl_resident_events(o) * slices_lambda);
         if (fit > (double)classes && fit < 4.0 * (double)classes)   // (the regime in which the slices are thinned: a step of 1 ... 4 device loads)
             classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, classes + 4u), (uint32_t)fit);
+    }
+    // ... and where the slices run MERGED (under-filled steps: a rank's share of a sharded batch, a graph of ~10^6 nodes; the rule of
+    // ce_slice_gradient_iteration): one launch holds every class of a slice, so four more classes cost nothing and leave next to nothing
+    // to the overflow class and its passes (configs[3]'s graph, a rank of 8: 11 classes 1.9 % -- 39.3 ms per batch; 15: 0.07 % --
+    // 35.6; 19: 35.2).  The ranks of a sharded run must agree on the palette: the share that enters is the LARGEST rank's.
+    {
+        double share = (double)(o->dev.node_hi - o->dev.node_lo) / (double)n;
+        if (o->comm)
+            for (size_t q = 0; 2 * q + 1 < o->comm_ranges.size(); q++) share = std::max(share, (double)(o->comm_ranges[2 * q + 1] - o->comm_ranges[2 * q]) / (double)n);
+        const double slices_lambda = std::max(1.0, std::ceil(2.0 * events / (double)n / 0.5));
+        const double per_step = events * share / (slices_lambda * (double)classes);
+        if (per_step < kMergeBelow * sl_resident_events(o) && !debug_knob("AE_SL_NO_MERGE") && !debug_knob("AE_SL_BASE_CLASSES"))
+            classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, kDepBits), classes + 4u);
     }
     if (debug_knob("AE_SL_CLASS_CAP")) classes = std::min<uint32_t>(kMaxClasses, std::max<int>((int)kmax + 1, atoi(debug_knob("AE_SL_CLASS_CAP"))));
     const double slices = std::max(1.0, 4.0 * events / (double)n);
@@ -1025,7 +1042,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // Full steps stay one launch per class: they are bound by requests, and the two dependency words per event would only add to them.
     const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
     const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
-                        (debug_knob("AE_SL_MERGE") || step_events < 0.2 * sl_resident_events(o));   // (measured: 31 k events per step 60.5 -> 53.1 ms, 62 k: 71.0 -> 75.2)
+                        (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
     if (merged) {   // two sets of words: a slice runs on one while the next slice's events enter the other
         if (o->sl_dep.n < 2 * n) o->sl_dep.alloc(2 * n);
         o->sl_dep.zero();
@@ -1119,7 +1136,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                     if (!premarked) hipLaunchKernelGGL(sl_dep_mark_kernel, dim3(blocks_for(sp[classes] - sp[0], 256)), dim3(256), 0, stream(), ra);
                     premarked = s + 1u < n_slices && sp[2u * classes + 1u] > sp[classes + 1u] && !debug_knob("AE_SL_NO_PREMARK");
                     if (premarked) ra.next_sptr = ra.sptr + (classes + 1u);
-                    const bool tile_run = use_tile && !y_in_cache && (uint64_t)(sp[classes] - sp[0]) / classes >= tile_min_events;
+                    const bool tile_run = use_tile && !y_in_cache && (uint64_t)(sp[classes] - sp[0]) >= tile_min_events;   // (a workgroup's tile serves its 256 events whatever their class)
                     AE_DISPATCH_DIM(o->dev.dim, launch_slice, ra, grid, o->sl_srec_floats, f64, tile_run);
                 }
             } else
