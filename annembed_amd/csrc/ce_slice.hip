@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
-                                                      uint32_t* __restrict__ keys, Event* __restrict__ vals) {
+                                                      uint32_t ov_every, uint32_t* __restrict__ keys, Event* __restrict__ vals) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
     if (e >= n_gen) return;
     const uint32_t k = cnt[e], o = offs[e];
@@ -328,8 +328,9 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
         }
     }
     for (uint32_t r = 0; r < k; r++) {
-        const uint32_t s = sorted ? SL(r) : __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
+        uint32_t s = sorted ? SL(r) : __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
         const uint32_t pos = cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes;
+        if (cl >= classes && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
         keys[o + r] = s * (classes + 1u) + pos;
         vals[o + r] = evv;
     }
@@ -875,6 +876,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             n_slices = (uint32_t)std::max(1.0, std::ceil(2.0 * seg_samples / (double)n / lam));
         }
     }
+    // An overflow class that is next to empty (a wide palette: < 0.2 % of the events) still costs a mark and two passes per slice --
+    // three launches of ~5 us for a few hundred events, 4 ms of a 33 ms rank share at N = 8.  Its events are dealt to every 8th slice
+    // instead (the middle one of their group of eight: sl_fill_kernel; an event of the class moves by at most four slices of ~240, its
+    // place in the batch stays uniform and independent of every other event's), and only those slices run the class.
+    const uint32_t ov_every = (o->sl_classes && o->sl_ov_frac > 0. && o->sl_ov_frac < 0.002 && n_slices >= 64u && !debug_knob("AE_SL_OV_EVERY_SLICE")) ? 8u : 1u;
+    const uint32_t ov_slices = (n_slices + ov_every - 1u) / ov_every;   // slices that run the overflow class
     // passes per slice of the overflow class: a thin one (a few per cent of the events: conflicts among them are rare) runs once and
     // carries its losers into the next slice
     int passes = debug_knob("AE_SL_PASSES") ? atoi(debug_knob("AE_SL_PASSES")) : (o->sl_ov_frac < 0.05 ? 1 : 3);
@@ -884,7 +891,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // events per slice on the busiest rows ended at CE 0.90-0.96x the sequential mode's (edge lengths +5 ... +20 %) although the late
     // events were < 1 % of all (the round-3 criterion for draining inside the slice); 6-8 passes: 1.000.
     if (!debug_knob("AE_SL_PASSES") && o->sl_ov_frac > 0.) {
-        const double busiest = (double)o->sl_node_ov_max * (seg_samples / (double)n) / (double)n_slices;
+        const double busiest = (double)o->sl_node_ov_max * (seg_samples / (double)n) / (double)ov_slices;
         passes = std::max(passes, (int)std::min(16.0, std::ceil(1.5 * busiest + 1.0)));
     }
     const int spread = debug_knob("AE_SL_NO_SPREAD") ? 0 : (debug_knob("AE_SL_SPREAD_ALL") ? 1 : 2);
@@ -898,7 +905,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint64_t ev_cap = (uint64_t)(seg_local + 8.0 * std::sqrt(seg_local) + 1024.0);
     // pending lists of the overflow class: a slice's overflow events (+ 16 sigma) four times over, plus what the rows that receive
     // more overflow events than a slice's passes can run (hubs) accumulate until the drain
-    const double per_slice_ov = seg_local / n_slices * o->sl_ov_frac;
+    const double per_slice_ov = seg_local / ov_slices * o->sl_ov_frac;
     double backlog = 0.;
     if (has_overflow && passes == 1 && !debug_knob("AE_SL_PASSES")) {
         // One pass per slice serves a thin overflow class only while no ROW is busy in it: a row that receives more than a quarter of
@@ -910,7 +917,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_busy.zero();
         double busy = 0.;
         hipLaunchKernelGGL(sl_backlog_kernel, dim3(grid_cap(n, 256, 1024)), dim3(256), 0, stream(), n, (const float*)o->sl_node_ov.p,
-                           (float)(seg_samples / (double)n), 0.25f * (float)n_slices, d_busy.p);
+                           (float)(seg_samples / (double)n), 0.25f * (float)ov_slices, d_busy.p);
         d_busy.download(&busy, 1);
         if (busy > 0.) passes = 3;
     }
@@ -919,7 +926,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_backlog.alloc_pooled(1);
         d_backlog.zero();
         hipLaunchKernelGGL(sl_backlog_kernel, dim3(grid_cap(n, 256, 1024)), dim3(256), 0, stream(), n, (const float*)o->sl_node_ov.p,
-                           (float)(seg_samples / (double)n), (float)(passes * n_slices), d_backlog.p);
+                           (float)(seg_samples / (double)n), (float)(passes * ov_slices), d_backlog.p);
         d_backlog.download(&backlog, 1);
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list
@@ -1094,7 +1101,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
-                           (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices), o->sl_keys0.p, ev0);
+                           (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices), ov_every, o->sl_keys0.p, ev0);
         if (prof) sync();
         const double t_fill = wall();
         const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbits);
@@ -1151,7 +1158,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 da.step_seq = step_seq++;
                 AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
             }
-            if (!has_overflow) { exchange_after(s); continue; }
+            if (!has_overflow || (ov_every > 1u && s != std::min(n_slices - 1u, s - s % ov_every + ov_every / 2u))) { exchange_after(s); continue; }
             a.f0 = sp[classes];
             a.f1 = sp[classes + 1u];
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;

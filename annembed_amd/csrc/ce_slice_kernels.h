@@ -748,8 +748,8 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     RecFetch<SREC, KREG> fr;
     RowFetch<DIM> fi, fj;
     unsigned long long wi = 0ull, wj = 0ull;
-    if (cmp && !half) wi = __hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (act0) wj = __hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cmp && !half && !(a.dbg & 32)) wi = __hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (dbg 16 / 32: timing experiments, wrong results)
+    if (act0 && !(a.dbg & 32)) wj = __hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
     fi.issue(c.y, i, cmp, yi);
     fj.issue(c.y, j, cmp && !inrun, yj);
@@ -842,8 +842,8 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 atomicOr(ra.dep + i, 1ull << (32u + q));
             }
-            if (fin && store_i && !succ_i) ra.dep[i] = 0ull;
-            if (fin && store_j && !succ_j) ra.dep[j] = 0ull;
+            if (fin && store_i && !succ_i && !(a.dbg & 16)) ra.dep[i] = 0ull;
+            if (fin && store_j && !succ_j && !(a.dbg & 16)) ra.dep[j] = 0ull;
             if (fin) phase = 2u;
         }
         if (!__ballot(phase != 2u)) break;
