@@ -615,7 +615,7 @@ def test_sharded_sliced_class_path_with_the_tile_on_component_ordered_labels(A, 
     os.environ.update(knobs)
     rows = []
     try:
-        for sd in SEEDS[:3]:
+        for sd in SEEDS + (SEEDS[0] + 1, SEEDS[1] + 1):
             y, ce, nbytes = _run_sharded_sliced(A, tmp_path, indptr, nbr, dist, k, y0, 1.0, world, 4, nb_batch, "cls", seed=sd)
             assert nbytes == nb_batch * 4 * (n - n // world) * d * 4
             rows.append(_metrics(indptr, nbr, y, ce))
@@ -637,11 +637,13 @@ def test_sharded_sliced_class_path_with_the_tile_on_component_ordered_labels(A, 
         exact.append(_metrics(indptr, nbr, eo.get_embedded(), eo.ce_compute_threaded()))
         del eo
     # Round 4 held ONE run to -20 ... +30 % on the quartiles (nine single runs scattered 0.87 ... 1.19: two processes on one GPU interleave
-    # differently from run to run, and tight components amplify it).  Three seeds a side, mean against mean: the cross entropy within
-    # 2 SE + 2 %, the quartiles within 2 SE + 6 % -- the floors are what ce_slice.hip documents for this arrangement (edges +4 ... +9 % at
-    # 600 k nodes in 2 shards with 4 exchanges per batch: the other shard's rows are a quarter of a batch old); in the caller's labels,
-    # without the relabelling, the quartiles sat at 0.75 ... 0.84.
-    assert_means_close(rows, exact, METRIC_NAMES, (0.02, 0.09, 0.09, 0.09), "sharded class path + tile, 600 k nodes in component order, 2 shards, 4 exchanges")
+    # differently from run to run, and tight components amplify it).  SIX sharded seeds against three exact ones, mean against mean: the
+    # cross entropy within 3 SE + 2 %, the quartiles within 3 SE + 9 % -- the floors are what ce_slice.hip documents for this arrangement
+    # (edges +4 ... +9 % at 600 k nodes in 2 shards with 4 exchanges per batch: the other shard's rows are a quarter of a batch old); in the
+    # caller's labels, without the relabelling, the quartiles sat at 0.75 ... 0.84.  (Six repeats of the three-seed form of this test,
+    # round 5 with merged slices: CE 0.988 ... 1.015, median edge 0.906 ... 1.088 around 1.001 / 0.997 -- and 2 SE estimated from three
+    # runs anywhere between 3 % and 11 %: it failed once in ~10 suite runs.  Six seeds and 3 SE.)
+    assert_means_close(rows, exact, METRIC_NAMES, (0.02, 0.09, 0.09, 0.09), "sharded class path + tile, 600 k nodes in component order, 2 shards, 4 exchanges", k_se=3.0)
 
 
 def test_sharded_sliced_locality_partition_with_cross_edges(A, tmp_path):
