@@ -956,7 +956,10 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 // current rows and reads the other shards' rows as of the last exchange -- faithful where few edges cross shards (a partition by
 // connected components / locality; ce_slice_prepare refuses a shard with more than 10 % of its edge mass on cross-shard edges, and
 // the caller then asks for the approximate rounds mode, AE_CE_HOGWILD, by name).
-constexpr uint64_t kAutoOrderedSamples = 1ull << 27;
+// Round 5: the time-sliced mode runs under-filled slices MERGED (one launch per slice, ce_slice_kernels.h) and takes over earlier: exact
+// kNN graphs of Higgs-shaped points with hubness weighting, ordered / time-sliced ms per batch: 24 M samples 11.8 / 18.5, 48 M 23.4 /
+// 21.4, 72 M 34.5 / 27.1, 99 M (configs[2]'s large graph) 49.5 / 33.8 -- break-even at ~48 M (tools/run_auto_crossover.py).
+constexpr uint64_t kAutoOrderedSamples = 3ull << 24;   // 50.3 M
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
     if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;

@@ -664,6 +664,7 @@ static void slice_color_edges(ae_entropy_optim* o) {
         if (fit > (double)classes && fit < 4.0 * (double)classes)   // (the regime in which the slices are thinned: a step of 1 ... 4 device loads)
             classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, classes + 4u), (uint32_t)fit);
     }
+    bool merged_regime = false;
     // ... and where the slices run MERGED (under-filled steps: a rank's share of a sharded batch, a graph of ~10^6 nodes; the rule of
     // ce_slice_gradient_iteration): one launch holds every class of a slice, so four more classes cost nothing and leave next to nothing
     // to the overflow class and its passes (configs[3]'s graph, a rank of 8: 11 classes 1.9 % -- 39.3 ms per batch; 15: 0.07 % --
@@ -674,16 +675,26 @@ static void slice_color_edges(ae_entropy_optim* o) {
             for (size_t q = 0; 2 * q + 1 < o->comm_ranges.size(); q++) share = std::max(share, (double)(o->comm_ranges[2 * q + 1] - o->comm_ranges[2 * q]) / (double)n);
         const double slices_lambda = std::max(1.0, std::ceil(2.0 * events / (double)n / 0.5));
         const double per_step = events * share / (slices_lambda * (double)classes);
-        if (per_step < kMergeBelow * sl_resident_events(o) && !debug_knob("AE_SL_NO_MERGE") && !debug_knob("AE_SL_BASE_CLASSES"))
-            classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, kDepBits), classes + 4u);
+        merged_regime = per_step < kMergeBelow * sl_resident_events(o) && !debug_knob("AE_SL_NO_MERGE");
+        if (merged_regime && !debug_knob("AE_SL_BASE_CLASSES")) classes = std::min<uint32_t>(std::min<uint32_t>(kMaxClasses, kDepBits), classes + 4u);
     }
     if (debug_knob("AE_SL_CLASS_CAP")) classes = std::min<uint32_t>(kMaxClasses, std::max<int>((int)kmax + 1, atoi(debug_knob("AE_SL_CLASS_CAP"))));
     const double slices = std::max(1.0, 4.0 * events / (double)n);
     const double busiest = 0.5 * (double)(indeg_max + kmax) * (double)n / (double)(2 * nnz);   // events per slice on the busiest row
     const double c_match = o->dev.dim <= 8 ? 0.14e-9 : 0.24e-9;
     const double c_opt = debug_knob("AE_SL_COPT") ? atof(debug_knob("AE_SL_COPT")) * 1e-9 : (o->dev.dim <= 8 ? 0.30e-9 : 0.28e-9);
-    const double cost_none = slices * std::max(4.0, busiest) * 9e-6 + events * c_opt;
-    const double cost_classes = slices * (classes + 2.0) * (9e-6 + busiest / classes * 0.4e-6) + events * (0.99 * c_match + 0.01 * c_opt);
+    double cost_none = slices * std::max(4.0, busiest) * 9e-6 + events * c_opt;
+    double cost_classes = slices * (classes + 2.0) * (9e-6 + busiest / classes * 0.4e-6) + events * (0.99 * c_match + 0.01 * c_opt);
+    if (merged_regime && !debug_knob("AE_SL_COPT")) {
+        // Merged slices: ONE launch per slice whatever the palette.  Measured on exact kNN graphs of Higgs-shaped points (k = 6, 2
+        // columns, in-degrees to ~140; tools/run_auto_crossover.py), ms per batch at 24 / 48 / 72 / 99 M events: class path merged 18.5 /
+        // 21.4 / 27.1 / 33.8 (57 us per slice + 0.20 ns per event), everything optimistic 29.7 / 34.5 / 44.1 / 51.1 (the busiest row's
+        // ~6 events per slice at 16 us each + 0.285 ns per event: hubs lose passes to conflicts); on a lattice (uniform in-degree)
+        // the optimistic passes take 28.4 ms at 99 M events (4 launches of 9 us per slice + 0.20 ns per event) and win.
+        const bool skewed = indeg_max > 4u * kmax;
+        cost_classes = slices * 57e-6 + events * 0.20e-9;
+        cost_none = slices * std::max(4.0, busiest) * (skewed ? 16e-6 : 9e-6) + events * (skewed ? 0.285e-9 : 0.20e-9);
+    }
     if (cost_none <= cost_classes && !debug_knob("AE_SL_CLASS_CAP") && !debug_knob("AE_SL_FORCE_CLASSES")) {
         all_optimistic();
         return;
