@@ -1027,7 +1027,7 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         }
         CeDev& d = o->dev;
         memset(&d, 0, sizeof(d));
-        d.n = n; d.nnz = g->nnz; d.dim = (uint32_t)dim; d.uniform_k = g->uniform_k;
+        d.n = n; d.nnz = g->nnz; d.dim = (uint32_t)dim; d.ystride = (uint32_t)dim; d.uniform_k = g->uniform_k;
         d.indptr = g->indptr.p; d.nbr = g->nbr.p; d.proba = np->proba.p; d.emb_scale = o->emb_scale.p; d.y = o->y.p;
         d.b = params->b; d.seed = params->seed; d.sampler = params->ce_sampler;
         d.node_lo = node_lo; d.node_hi = node_hi; d.edge_lo = edge_lo; d.shard_edges = edge_hi - edge_lo;

@@ -23,6 +23,7 @@ struct CeDev {
     const float* hub_odds;       // non-null = hubness-weighted negative sampling (NodeSampler, embedder.rs:915-930)
     const uint32_t* hub_alias;
     const uint2* hub_tab;        // the same alias table, one 8-byte entry per node {odds bits, alias}: one random access per draw
+    uint32_t ystride;            // floats from one node's row of `y` to the next: dim, or more where the time-sliced mode keeps a node's dependency words behind its row (ce_slice_kernels.h)
 };
 
 // one in-edge (u -> v) of the transposed graph: everything thread v needs to replay the sample's

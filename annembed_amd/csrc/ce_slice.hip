@@ -403,14 +403,18 @@ __global__ void __launch_bounds__(256) sl_perm_invert_kernel(uint64_t n, const u
     const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
     if (x < n) perm[order[x]] = (uint32_t)x;
 }
-// rows of `dim` floats: to_internal: dst[perm[v]] = src[v]; else dst[v] = src[perm[v]]
-__global__ void __launch_bounds__(256) sl_move_rows_kernel(uint64_t n, uint32_t dim, const uint32_t* __restrict__ perm, const float* __restrict__ src,
-                                                           float* __restrict__ dst, int to_internal) {
-    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < n * dim; t += (uint64_t)gridDim.x * 256ull) {   // (n x dim may pass 2^32)
-        const uint64_t v = t / dim, q = t % dim;
-        const uint64_t p = perm[v];
-        if (to_internal) dst[p * dim + q] = src[v * dim + q];
-        else dst[v * dim + q] = src[p * dim + q];
+// rows of `dim` floats: to_internal: dst[perm[v]] = src[v]; else dst[v] = src[perm[v]] (perm null: the identity).  The internal copy's
+// rows are `stride` floats apart (dim, or more: a node's dependency words sit behind its row, ce_slice_kernels.h -- zeroed on the way in);
+// [v_lo, v_hi) \ [skip_lo, skip_hi): the rows moved (internal numbers: an exchange moves a rank's own rows out and the others' in)
+__global__ void __launch_bounds__(256) sl_move_rows_kernel(uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, uint32_t dim, uint32_t stride,
+                                                           const uint32_t* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst, int to_internal, int zero_words) {
+    const uint32_t cols = (to_internal && zero_words) ? stride : dim;
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < (v_hi - v_lo) * cols; t += (uint64_t)gridDim.x * 256ull) {   // (n x dim may pass 2^32)
+        const uint64_t v = v_lo + t / cols, q = t % cols;
+        if (v >= skip_lo && v < skip_hi) continue;
+        const uint64_t p = perm ? perm[v] : v;
+        if (to_internal) dst[p * stride + q] = q < dim ? src[v * dim + q] : 0.f;
+        else dst[v * dim + q] = src[p * stride + q];
     }
 }
 __global__ void __launch_bounds__(256) sl_hub_tab_kernel(uint64_t n, const uint32_t* __restrict__ perm, const uint2* __restrict__ tab, uint2* __restrict__ out) {
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(256) sl_dep_mark_kernel(SliceRunArgs a) {
     if (p >= s_ptr[a.classes]) return;
     uint32_t q = 0;
     while (q + 1u < a.classes && p >= s_ptr[q + 1u]) q++;
-    dep_mark_event(a.dep, a.d.ev[p], q);
+    dep_mark_event(a.dep, a.dep_stride, a.d.ev[p], q);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -954,22 +958,42 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) o->sl_class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
     unsigned kbits = 1;
     while (kbits < 32 && (n_keys >> kbits)) kbits++;
+    // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
+    // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
+    // Full steps stay one launch per class: they are bound by requests, and the dependency words would only add to them.
+    const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
+    const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
+                        (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
+    // Rows of <= 8 columns keep the two sets of dependency words BEHIND the node's row in the batch's internal copy (rows 32 / 64
+    // bytes apart instead of 8 ... 32): a word comes with the line of the row the event reads anyway and is wiped into the line it
+    // writes anyway -- four of a merged event's six extra requests.
+    const bool words_in_rows = merged && o->dev.dim <= 8 && !debug_knob("AE_SL_DEP_ARRAY");
+    const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (uint32_t)o->dev.dim;
+    const uint32_t word_at = ((uint32_t)o->dev.dim + 1u) & ~1u;   // (floats: the first set; the second two floats further)
     // internal numbering (ce_slice_prepare): the batch runs on a relabelled copy of the coordinates
     CeDev cdev = o->dev;
+    cdev.ystride = ystride;
     const bool relabelled = o->sl_perm.n != 0;
-    if (relabelled) {
-        if (o->sl_y.n < n * o->dev.dim) o->sl_y.alloc(n * o->dev.dim);
-        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap(n * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
-                           (const uint32_t*)o->sl_perm.p, (const float*)o->dev.y, o->sl_y.p, 1);
+    const bool own_copy = relabelled || words_in_rows;
+    const uint32_t* perm = relabelled ? (const uint32_t*)o->sl_perm.p : nullptr;
+    auto move_rows = [&](uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, const float* src, float* dst, int to_internal, int zero_words) {
+        if (v_hi <= v_lo) return;
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap((v_hi - v_lo) * ystride, 256, 1u << 20)), dim3(256), 0, stream(), v_lo, v_hi, skip_lo, skip_hi,
+                           (uint32_t)o->dev.dim, ystride, perm, src, dst, to_internal, zero_words);
+    };
+    if (own_copy) {
+        if (o->sl_y.n < n * ystride) o->sl_y.alloc(n * ystride);
+        move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p, 1, words_in_rows ? 1 : 0);
         cdev.y = o->sl_y.p;
-        if (o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
+        if (relabelled && o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
     }
-    // (a sharded range: the in-batch exchanges act on the internal copy -- a rank's rows are the same contiguous run in both numberings)
+    // (a sharded range: the in-batch exchanges act on the internal copy -- a rank's rows are the same contiguous run in both numberings --;
+    // with the words behind the rows, on the caller's array as a dense staging area: the rank's rows are moved out before, the others' in after)
     struct CommY {
         ae_entropy_optim* o;
         CommY(ae_entropy_optim* oo, float* y) : o(oo) { o->comm_y = y; }
         ~CommY() { o->comm_y = nullptr; }
-    } comm_y_scope(o, relabelled ? o->sl_y.p : nullptr);
+    } comm_y_scope(o, (own_copy && !words_in_rows) ? o->sl_y.p : nullptr);
     SliceArgs a;
     a.c = cdev;
     a.srec = o->sl_srec.p;
@@ -1040,7 +1064,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // edges -- as of the last one.  Every rank has the same slices (they follow the whole graph's totals), hence the same exchange points.
     const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
     uint64_t exchanges_done = 0;
-    auto exchange_now = [&] { ce_comm_exchange(o); exchanges_done++; };
+    auto exchange_now = [&] {
+        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)o->sl_y.p, o->dev.y, 0, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
+        ce_comm_exchange(o);
+        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p, 1, 0);
+        exchanges_done++;
+    };
     auto exchange_after = [&](uint32_t s) {
         if (exchanges < 2u) return;
         const uint32_t q = (uint32_t)(((uint64_t)(s + 1u) * exchanges) / n_slices), q0 = (uint32_t)(((uint64_t)s * exchanges) / n_slices);
@@ -1055,13 +1084,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             try { for (uint64_t x = done; x < owed; x++) ce_comm_exchange(o); } catch (...) {}
         }
     } owe{o, exchanges_done, (uint64_t)segments * exchanges};
-    // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
-    // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
-    // Full steps stay one launch per class: they are bound by requests, and the two dependency words per event would only add to them.
-    const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
-    const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
-                        (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
-    if (merged) {   // two sets of words: a slice runs on one while the next slice's events enter the other
+    if (merged && !words_in_rows) {   // two sets of words: a slice runs on one while the next slice's events enter the other
         if (o->sl_dep.n < 2 * n) o->sl_dep.alloc(2 * n);
         o->sl_dep.zero();
     }
@@ -1074,9 +1097,16 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ra.sptr = o->sl_sptr.p + (size_t)s * (classes + 1u);
         ra.classes = classes;
         ra.step_seq0 = step_seq_base + s * classes;
-        ra.dep = o->sl_dep.p + (size_t)(s & 1u) * n;
         ra.next_sptr = nullptr;
-        ra.dep_next = o->sl_dep.p + (size_t)((s + 1u) & 1u) * n;
+        if (words_in_rows) {
+            ra.dep = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at + 2u * (s & 1u));
+            ra.dep_next = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at + 2u * ((s + 1u) & 1u));
+            ra.dep_stride = ystride / 2u;
+        } else {
+            ra.dep = o->sl_dep.p + (size_t)(s & 1u) * n;
+            ra.dep_next = o->sl_dep.p + (size_t)((s + 1u) & 1u) * n;
+            ra.dep_stride = 1u;
+        }
         return ra;
     };
     for (uint32_t sg = 0; sg < segments; sg++) {
@@ -1284,9 +1314,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         t_drain += wall() - t_enq;
     }
     owe.armed = false;
-    if (relabelled)   // back to the caller's labels
-        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap(n * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), (uint64_t)n, (uint32_t)o->dev.dim,
-                           (const uint32_t*)o->sl_perm.p, (const float*)o->sl_y.p, o->dev.y, 0);
+    if (own_copy) move_rows(0, n, 0, 0, (const float*)o->sl_y.p, o->dev.y, 0, 0);   // back to the caller's labels and row stride
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");

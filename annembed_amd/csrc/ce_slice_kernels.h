@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t x, int t) {
 // the stage to the owners.  Issue everything a sample needs first, land afterwards: one memory round trip, not one per record.
 // idx < 2^31; the top bit of the broadcast word carries `want`.
 template <int NF>
-__device__ __forceinline__ void coop_issue(const float* __restrict__ base, uint32_t idx, bool want, f4 (&pc)[NF / 4]) {
+__device__ __forceinline__ void coop_issue(const float* __restrict__ base, uint32_t idx, bool want, f4 (&pc)[NF / 4], uint32_t stride = NF) {   // (stride: floats from record to record)
     constexpr int G = NF / 4;
     const uint32_t sub = (threadIdx.x & 63) & (G - 1);
     // UNCONDITIONAL loads (a lane that wants nothing asks for record 0: one shared line): a load under `if (want)` makes the register
@@ -132,7 +132,7 @@ __device__ __forceinline__ void coop_issue(const float* __restrict__ base, uint3
 #pragma unroll
     for (int t = 0; t < G; t++) {
         const uint32_t wt = group_bcast<G>(word, t);
-        pc[t] = *reinterpret_cast<const f4*>(base + (uint64_t)wt * NF + sub * 4u);
+        pc[t] = *reinterpret_cast<const f4*>(base + (uint64_t)wt * stride + sub * 4u);
     }
 }
 template <int NF>
@@ -144,7 +144,7 @@ __device__ __forceinline__ void coop_land(const f4 (&pc)[NF / 4], float* stage) 
     wave_lds_sync();
 }
 template <int NF>
-__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage) {
+__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride = NF) {
     constexpr int G = NF / 4, RS = NF + 4;
     const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
     const uint32_t word = idx | (want ? 0x80000000u : 0u);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t id
     for (int t = 0; t < G; t++) {
         const uint32_t wt = group_bcast<G>(word, t);
         if (wt & 0x80000000u)
-            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * NF + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
+            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
     }
     wave_lds_sync();
 }
@@ -169,9 +169,9 @@ constexpr int kStageFloats = (kCoopRow<DIM> || kCoopRec<SREC>) ? 64 * ((((kCoopR
 template <int DIM>
 struct RowFetch {  // a coordinate row on its way to its lane
     f4 pc[kCoopRow<DIM> ? DIM / 4 : 1];
-    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want, float* out) {
-        if constexpr (kCoopRow<DIM>) coop_issue<DIM>(y, node, want, pc);
-        else load_row<DIM>(y, want ? node : 0u, out);
+    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want, float* out, uint32_t stride) {
+        if constexpr (kCoopRow<DIM>) coop_issue<DIM>(y, node, want, pc, stride);
+        else load_row<DIM>(y + (uint64_t)(want ? node : 0u) * stride, 0u, out);
     }
     __device__ __forceinline__ void land(float* stage, float* out) {
         if constexpr (kCoopRow<DIM>) {
@@ -187,7 +187,7 @@ struct RowFetch {  // a coordinate row on its way to its lane
     }
 };
 template <int DIM>
-__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in) {
+__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride) {
     if constexpr (kCoopRow<DIM>) {
         float* p = stage + (threadIdx.x & 63) * (DIM + 4);
 #pragma unroll
@@ -195,9 +195,9 @@ __device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, 
             f4 v; v.x = in[4 * q]; v.y = in[4 * q + 1]; v.z = in[4 * q + 2]; v.w = in[4 * q + 3];
             *reinterpret_cast<f4*>(p + 4 * q) = v;
         }
-        coop_store<DIM>(y, node, want, stage);
+        coop_store<DIM>(y, node, want, stage, stride);
     } else {
-        if (want) store_row<DIM>(y, node, in);
+        if (want) store_row<DIM>(y + (uint64_t)node * stride, 0u, in);
     }
 }
 // the source's static record: embedded scale, the neighbour ids (rejection test of the negatives), the sampled edge's probability
@@ -284,8 +284,8 @@ struct TileFetch {
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
             const uint32_t x = (uint32_t)z * 256u + threadIdx.x, q = x % Q;
-            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node[z] * DIM + 4u * q);
-            else pc[z].x = c.y[(uint64_t)node[z] * DIM + q];
+            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node[z] * c.ystride + 4u * q);
+            else pc[z].x = c.y[(uint64_t)node[z] * c.ystride + q];
         }
     }
     __device__ __forceinline__ void land(float* s_tile, uint32_t* s_tnode) {
@@ -427,7 +427,7 @@ struct SplitSample {
                 for (int t2 = 0; t2 < DIM; t2++) row[t2] = s_tile[x * DIM + t2];
             }
         } else {
-            load_row<DIM>(c.y, x, row);
+            load_row<DIM>(c.y + (uint64_t)x * c.ystride, 0u, row);
         }
     }
     __device__ __forceinline__ void fetch(const CeDev& c, const float* s_tile, const uint32_t (&neg)[5]) {
@@ -499,8 +499,8 @@ struct StepShared {
 };
 
 template <int DIM>
-__device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t node, const float* in) {
-    float* p = y + (uint64_t)node * DIM;
+__device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t node, const float* in, uint32_t stride) {
+    float* p = y + (uint64_t)node * stride;
     if constexpr (DIM % 2 == 0) {
 #pragma unroll
         for (int q = 0; q < DIM / 2; q++) {
@@ -513,8 +513,8 @@ __device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t 
     }
 }
 template <int DIM>
-__device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint32_t node, float* out) {
-    const float* p = y + (uint64_t)node * DIM;
+__device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint32_t node, float* out, uint32_t stride) {
+    const float* p = y + (uint64_t)node * stride;
     if constexpr (DIM % 2 == 0) {
 #pragma unroll
         for (int q = 0; q < DIM / 2; q++) {
@@ -579,8 +579,8 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         RowFetch<DIM> fi, fj;
         const bool want_rec = cmp && !(a.dbg & 8);
         fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
-        fi.issue(c.y, i, cmp, yi);             // :1185
-        fj.issue(c.y, j, cmp && !inrun, yj);   // :1186
+        fi.issue(c.y, i, cmp, yi, c.ystride);             // :1185
+        fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);   // :1186
         if constexpr (TILE && FIRST) ft.land(sh.tile, sh.tnode);
         fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
         fi.land(stage, yi);
@@ -609,7 +609,7 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
                         if (++polls > (1u << 24)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), 2u); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    load_row_agent<DIM>(c.y, j, in);
+                    load_row_agent<DIM>(c.y, j, in, c.ystride);
                 }
                 if (act0 && runpos == t) {
 #pragma unroll
@@ -635,13 +635,13 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         // and announced where the chain goes on in the next chunk
         const bool store_j = act0 && last_in_seg && !hand_over;
         if (!(a.dbg & 2)) {
-            row_store<DIM>(c.y, j, store_j, stage, yj);  // :1239
-            row_store<DIM>(c.y, i, cmp && !half, stage, yi);      // :1301
+            row_store<DIM>(c.y, j, store_j, stage, yj, c.ystride);  // :1239
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride);      // :1301
         } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
-            row_store<DIM>(c.y, i, cmp && !half, stage, yi);
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride);
         }
         if (hand_over) {
-            store_row_agent<DIM>(c.y, j, yj);
+            store_row_agent<DIM>(c.y, j, yj, c.ystride);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_store(&a.chunk_flag[chunk], a.step_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -686,12 +686,14 @@ struct SliceRunArgs {
     unsigned long long* dep;       // [n]: classes through with the node << 32 | classes with an event on the node; all zero between slices
     const uint32_t* next_sptr;     // the NEXT slice's class pointers (nullptr: nothing to prepare): its events enter `dep_next` while this slice runs
     unsigned long long* dep_next;  // [n]: the other set of words (a slice cleans its own set as it goes)
+    uint32_t dep_stride;           // 64-bit words from one node's word to the next: 1 (an array of its own), or the coordinate rows' stride / 2 where the words
+                                   // sit behind the node's row (rows of <= 8 columns: the word comes with the row's line and is wiped with its store)
 };
 // an event of a slice enters its class in the words of its two nodes (fire-and-forget atomics on the words' low halves)
-__device__ __forceinline__ void dep_mark_event(unsigned long long* dep, const Event e, uint32_t q) {
+__device__ __forceinline__ void dep_mark_event(unsigned long long* dep, uint32_t dep_stride, const Event e, uint32_t q) {
     uint32_t* words = reinterpret_cast<uint32_t*>(dep);   // (little endian: the low word of a node's 64 bits holds the classes)
-    if (!ev_half(e.j)) atomicOr(words + 2ull * (e.im >> 5), 1u << q);   // (a half event reads its source's row from the replica: nobody here writes it)
-    atomicOr(words + 2ull * ev_node(e.j), 1u << q);
+    if (!ev_half(e.j)) atomicOr(words + 2ull * dep_stride * (e.im >> 5), 1u << q);   // (a half event reads its source's row from the replica: nobody here writes it)
+    atomicOr(words + 2ull * dep_stride * ev_node(e.j), 1u << q);
 }
 __device__ __forceinline__ uint32_t dep_classes(unsigned long long w) { return (uint32_t)w; }
 __device__ __forceinline__ uint32_t dep_done(unsigned long long w) { return (uint32_t)(w >> 32); }
@@ -748,11 +750,14 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     RecFetch<SREC, KREG> fr;
     RowFetch<DIM> fi, fj;
     unsigned long long wi = 0ull, wj = 0ull;
-    if (cmp && !half && !(a.dbg & 32)) wi = __hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (dbg 16 / 32: timing experiments, wrong results)
-    if (act0 && !(a.dbg & 32)) wj = __hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* const dep_i = ra.dep + (uint64_t)i * ra.dep_stride;
+    unsigned long long* const dep_j = ra.dep + (uint64_t)j * ra.dep_stride;
+    // (the classes were entered by the launch before this one: plain loads -- behind the row, the word comes with the row's line)
+    if (cmp && !half && !(a.dbg & 32)) wi = *dep_i;   // (dbg 16 / 32: timing experiments, wrong results)
+    if (act0 && !(a.dbg & 32)) wj = *dep_j;
     fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
-    fi.issue(c.y, i, cmp, yi);
-    fj.issue(c.y, j, cmp && !inrun, yj);
+    fi.issue(c.y, i, cmp, yi, c.ystride);
+    fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);
     if constexpr (TILE) ft.land(sh.tile, sh.tnode);
     fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
     fi.land(stage, yi);
@@ -790,8 +795,8 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
         for (int z = 0; z < DIM; z++) in[z] = __shfl_up(yj[z], 1);
         const uint32_t pphase = __shfl_up(phase, 1);
         if (phase == 0u && !ok_dep) {
-            const bool ok_i = !need_i || (dep_done(__hip_atomic_load(ra.dep + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_i) == need_i;
-            const bool ok_j = !need_j || (dep_done(__hip_atomic_load(ra.dep + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_j) == need_j;
+            const bool ok_i = !need_i || (dep_done(__hip_atomic_load(dep_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_i) == need_i;
+            const bool ok_j = !need_j || (dep_done(__hip_atomic_load(dep_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & need_j) == need_j;
             ok_dep = ok_i && ok_j;
         }
         if (phase == 0u && !ok_flag) ok_flag = __hip_atomic_load(&a.chunk_flag[chunk - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s_seq + 1u;
@@ -802,9 +807,9 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
                 for (int z = 0; z < DIM; z++) yj[z] = in[z];
             } else if (from_prev_chunk) {   // the target's row as the previous chunk left it
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                load_row_agent<DIM>(c.y, j, yj);
-            } else if (need_j) load_row_agent<DIM>(c.y, j, yj);
-            if (need_i) load_row_agent<DIM>(c.y, i, yi);
+                load_row_agent<DIM>(c.y, j, yj, c.ystride);
+            } else if (need_j) load_row_agent<DIM>(c.y, j, yj, c.ystride);
+            if (need_i) load_row_agent<DIM>(c.y, i, yi, c.ystride);
             if (cmp) {
                 for (uint32_t z = 0; z + 1u < rep; z++) {   // earlier repetitions of the edge: whole samples, one after the other
                     uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
@@ -816,13 +821,13 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
             // the target's row is final for this class once its chain segment's last lane has attracted: handed to the next chunk, or
             // to the classes behind, NOW (write-through stores, waited for, then the flag / the bit: no cache write-back in between)
             if (hand_over) {
-                store_row_agent<DIM>(c.y, j, yj);
+                store_row_agent<DIM>(c.y, j, yj, c.ystride);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __hip_atomic_store(&a.chunk_flag[chunk], s_seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (store_j && succ_j) {
-                store_row_agent<DIM>(c.y, j, yj);
+                store_row_agent<DIM>(c.y, j, yj, c.ystride);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                atomicOr(ra.dep + j, 1ull << (32u + q));
+                atomicOr(dep_j, 1ull << (32u + q));
             }
             phase = 1u;
         }
@@ -835,15 +840,15 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
             }
             // stores: as sl_step_body for the rows no later class of the slice will ask for; the node's last event of the slice wipes its
             // word (everybody who had to read it has: they are earlier classes, or this chain)
-            row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj);   // :1239
-            row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi);   // :1301
+            row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride);   // :1239
+            row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, c.ystride);   // :1301
             if (fin && store_i && succ_i) {
-                store_row_agent<DIM>(c.y, i, yi);
+                store_row_agent<DIM>(c.y, i, yi, c.ystride);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                atomicOr(ra.dep + i, 1ull << (32u + q));
+                atomicOr(dep_i, 1ull << (32u + q));
             }
-            if (fin && store_i && !succ_i && !(a.dbg & 16)) ra.dep[i] = 0ull;
-            if (fin && store_j && !succ_j && !(a.dbg & 16)) ra.dep[j] = 0ull;
+            if (fin && store_i && !succ_i && !(a.dbg & 16)) *dep_i = 0ull;
+            if (fin && store_j && !succ_j && !(a.dbg & 16)) *dep_j = 0ull;
             if (fin) phase = 2u;
         }
         if (!__ballot(phase != 2u)) break;
@@ -862,7 +867,7 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
         for (uint32_t t = n_begin + blockIdx.x * 256u + threadIdx.x; t < n_end; t += gridDim.x * 256u) {
             uint32_t qn = 0;
             for (uint32_t l = 1; l < ra.classes; l++) qn += t >= (uint32_t)__shfl(next_ptr, (int)l) ? 1u : 0u;
-            dep_mark_event(ra.dep_next, a.ev[t], qn);
+            dep_mark_event(ra.dep_next, ra.dep_stride, a.ev[t], qn);
         }
     }
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
@@ -934,8 +939,8 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
         RecFetch<SREC, KREG> fr;
         RowFetch<DIM> fi, fj;
         fr.issue(a.srec, i, p.im & 31u, win, scale_f, w, nbr_reg);
-        fi.issue(c.y, i, win, yi);
-        fj.issue(c.y, pj, win, yj);
+        fi.issue(c.y, i, win, yi, c.ystride);
+        fj.issue(c.y, pj, win, yj, c.ystride);
         if constexpr (TILE && FIRST) ft.land(s_tile, s_tnode);
         fr.land(stage, p.im & 31u, win, scale_f, w, nbr_reg);
         fi.land(stage, yi);
@@ -946,8 +951,8 @@ __global__ void __launch_bounds__(256) sl_exec_kernel(SliceArgs a) {
             run_sample<DIM, F64, TILE>(c, s_tile, yi, yj, w, scale_f, a.step, neg, got);
             done += half ? 0u : 1u;
         }
-        row_store<DIM>(c.y, pj, win, stage, yj);           // :1239
-        row_store<DIM>(c.y, i, win && !half, stage, yi);   // :1301
+        row_store<DIM>(c.y, pj, win, stage, yj, c.ystride);           // :1239
+        row_store<DIM>(c.y, i, win && !half, stage, yi, c.ystride);   // :1301
         // deferred: append to the next list (one atomic per workgroup, on one of kSub counters), mark for the next pass
         const bool defer = have && !win;
         const unsigned long long m = __ballot(defer);
@@ -1004,7 +1009,7 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
         const uint32_t tj = ev_node(p0.j);
         if (head[tj] != pos) continue;  // the head of its target's list walks it
         float yj[DIM];
-        load_row<DIM>(c.y, tj, yj);
+        load_row<DIM>(c.y + (uint64_t)tj * c.ystride, 0u, yj);
         uint32_t cur = pos, nxt = next[pos];
         Pending e = p0;
         for (;;) {
@@ -1014,7 +1019,7 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
             const uint32_t i = e.im >> 5;
             if (a.owner[i] == e.idx && head[i] == kNil) {
                 float yi[DIM];
-                load_row<DIM>(c.y, i, yi);
+                load_row<DIM>(c.y + (uint64_t)i * c.ystride, 0u, yi);
                 const float* r = a.srec + (uint64_t)i * SREC;
                 const float scale_f = r[0], w = r[1 + KP + (e.im & 31u)];
                 uint32_t nbr_reg[KREG];
@@ -1024,7 +1029,7 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
                 const bool half = ev_half(e.j);
                 const uint32_t got = half ? 0u : draw_negatives<DIM, KREG, false>(c, hub, nullptr, pcg_hash(nkey + e.idx), i, nbr_reg, neg);
                 run_sample<DIM, F64, false>(c, nullptr, yi, yj, w, scale_f, a.step, neg, got);
-                if (!half) { store_row<DIM>(c.y, i, yi); done++; }  // :1301
+                if (!half) { store_row<DIM>(c.y + (uint64_t)i * c.ystride, 0u, yi); done++; }  // :1301
             } else {  // the source is claimed by another event or is a target of this round: next round
                 const uint32_t dsub = (cur + blockIdx.x) % (uint32_t)kSub;
                 const uint32_t at = atomicAdd(&a.counts[a.dst_list * kSub + dsub], 1u);
@@ -1034,7 +1039,7 @@ __global__ void __launch_bounds__(256) sl_chain_run_kernel(SliceArgs a, const ui
             if (nxt == kNil) break;
             cur = nxt; e = en; nxt = nn;
         }
-        store_row<DIM>(c.y, tj, yj);  // :1239
+        store_row<DIM>(c.y + (uint64_t)tj * c.ystride, 0u, yj);  // :1239
     }
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 64u) & 1023u], done);
