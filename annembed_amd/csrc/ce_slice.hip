@@ -969,7 +969,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // writes anyway -- four of a merged event's six extra requests.
     const bool words_in_rows = merged && o->dev.dim <= 8 && !debug_knob("AE_SL_DEP_ARRAY");
     const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (uint32_t)o->dev.dim;
-    const uint32_t word_at = ((uint32_t)o->dev.dim + 1u) & ~1u;   // (floats: the first set; the second two floats further)
+    // (floats from the start of a node's line: rows of 8 columns sit in the middle of their line, a set of words on either side --
+    // ce_slice_kernels.h: LineFetch --; shorter rows at its start, the two sets behind them)
+    const bool lines = words_in_rows && o->dev.dim == 8;
+    const uint32_t row_at = lines ? (uint32_t)kLineRowAt : 0u;
+    const uint32_t word_at[2] = {lines ? 0u : (((uint32_t)o->dev.dim + 1u) & ~1u), lines ? (uint32_t)kLineRowAt + 8u : (((uint32_t)o->dev.dim + 1u) & ~1u) + 2u};
     // internal numbering (ce_slice_prepare): the batch runs on a relabelled copy of the coordinates
     CeDev cdev = o->dev;
     cdev.ystride = ystride;
@@ -983,8 +987,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     };
     if (own_copy) {
         if (o->sl_y.n < n * ystride) o->sl_y.alloc(n * ystride);
-        move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p, 1, words_in_rows ? 1 : 0);
-        cdev.y = o->sl_y.p;
+        if (words_in_rows) o->sl_y.zero();
+        move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p + row_at, 1, 0);
+        cdev.y = o->sl_y.p + row_at;
         if (relabelled && o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
     }
     // (a sharded range: the in-batch exchanges act on the internal copy -- a rank's rows are the same contiguous run in both numberings --;
@@ -1065,9 +1070,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
     uint64_t exchanges_done = 0;
     auto exchange_now = [&] {
-        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)o->sl_y.p, o->dev.y, 0, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
+        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
         ce_comm_exchange(o);
-        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p, 1, 0);
+        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p + row_at, 1, 0);
         exchanges_done++;
     };
     auto exchange_after = [&](uint32_t s) {
@@ -1098,9 +1103,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ra.classes = classes;
         ra.step_seq0 = step_seq_base + s * classes;
         ra.next_sptr = nullptr;
+        ra.set = s & 1u;
         if (words_in_rows) {
-            ra.dep = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at + 2u * (s & 1u));
-            ra.dep_next = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at + 2u * ((s + 1u) & 1u));
+            ra.dep = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at[s & 1u]);
+            ra.dep_next = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at[(s + 1u) & 1u]);
             ra.dep_stride = ystride / 2u;
         } else {
             ra.dep = o->sl_dep.p + (size_t)(s & 1u) * n;
@@ -1314,7 +1320,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         t_drain += wall() - t_enq;
     }
     owe.armed = false;
-    if (own_copy) move_rows(0, n, 0, 0, (const float*)o->sl_y.p, o->dev.y, 0, 0);   // back to the caller's labels and row stride
+    if (own_copy) move_rows(0, n, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0, 0);   // back to the caller's labels and row stride
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");

@@ -157,14 +157,64 @@ __device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t id
     }
     wave_lds_sync();
 }
+// ... of the pieces [lo, hi] of the record only
+template <int NF>
+__device__ __forceinline__ void coop_store_pieces(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride, int lo, int hi) {
+    constexpr int G = NF / 4, RS = NF + 4;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
+    const uint32_t word = idx | (want ? 0x80000000u : 0u);
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        const uint32_t wt = group_bcast<G>(word, t);
+        if ((wt & 0x80000000u) && sub >= lo && sub <= hi)
+            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
+    }
+    wave_lds_sync();
+}
+// A node's LINE in a merged batch on rows of 8 columns (ce_slice_gradient_iteration: words_in_rows): 64 bytes =
+// {word of the even slices, 8 spare bytes | the row, 32 bytes | word of the odd slices, 8 spare bytes}; c.y points at the ROW of node 0
+// (every other kernel of the mode sees rows 16 floats apart).  One request of four lanes brings row and words; the row's store takes
+// the slice's word along, zeroed (the event that stores a row the plain way is the node's last of the slice: it wipes the word).
+constexpr int kLineFloats = 16, kLineRowAt = 4;
+struct LineFetch {
+    f4 pc[kLineFloats / 4];
+    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want) { coop_issue<kLineFloats>(y - kLineRowAt, node, want, pc, kLineFloats); }
+    __device__ __forceinline__ void land(float* stage, float* row, unsigned long long& word, uint32_t set) {
+        coop_land<kLineFloats>(pc, stage);
+        const float* p = stage + (threadIdx.x & 63) * (kLineFloats + 4);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const f4 v = *reinterpret_cast<const f4*>(p + kLineRowAt + 4 * q);
+            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+        }
+        const float* wp = p + (set ? kLineRowAt + 8 : 0);
+        word = ((unsigned long long)__float_as_uint(wp[1]) << 32) | __float_as_uint(wp[0]);
+        wave_lds_sync();
+    }
+};
+__device__ __forceinline__ void line_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* row, uint32_t set) {
+    float* p = stage + (threadIdx.x & 63) * (kLineFloats + 4);
+    f4 z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f;
+    *reinterpret_cast<f4*>(p) = z;
+    *reinterpret_cast<f4*>(p + 12) = z;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        f4 v; v.x = row[4 * q]; v.y = row[4 * q + 1]; v.z = row[4 * q + 2]; v.w = row[4 * q + 3];
+        *reinterpret_cast<f4*>(p + kLineRowAt + 4 * q) = v;
+    }
+    coop_store_pieces<kLineFloats>(y - kLineRowAt, node, want, stage, kLineFloats, set ? 1 : 0, set ? 3 : 2);
+}
 // rows: cooperative for 8 and 16 columns (2 / 4 lanes per row), one lane per row otherwise (<= 4 columns: one request anyway;
 // 32 / 64 columns: rare, kept simple)
 template <int DIM>
 constexpr bool kCoopRow = DIM == 8 || DIM == 16;
 template <int SREC>
 constexpr bool kCoopRec = SREC <= 32;
+template <int DIM>
+constexpr int kRowStage = DIM == 8 ? 16 : DIM;   // (rows of 8 columns may travel as whole node lines: LineFetch)
 template <int DIM, int SREC>
-constexpr int kStageFloats = (kCoopRow<DIM> || kCoopRec<SREC>) ? 64 * ((((kCoopRow<DIM> ? DIM : 0) > (kCoopRec<SREC> ? SREC : 0)) ? DIM : SREC) + 4) : 1;
+constexpr int kStageFloats = (kCoopRow<DIM> || kCoopRec<SREC>) ? 64 * ((((kCoopRow<DIM> ? kRowStage<DIM> : 0) > (kCoopRec<SREC> ? SREC : 0)) ? kRowStage<DIM> : SREC) + 4) : 1;
 
 template <int DIM>
 struct RowFetch {  // a coordinate row on its way to its lane
@@ -686,6 +736,7 @@ struct SliceRunArgs {
     unsigned long long* dep;       // [n]: classes through with the node << 32 | classes with an event on the node; all zero between slices
     const uint32_t* next_sptr;     // the NEXT slice's class pointers (nullptr: nothing to prepare): its events enter `dep_next` while this slice runs
     unsigned long long* dep_next;  // [n]: the other set of words (a slice cleans its own set as it goes)
+    uint32_t set;                  // 0 / 1: which of the two sets of words this slice runs on
     uint32_t dep_stride;           // 64-bit words from one node's word to the next: 1 (an array of its own), or the coordinate rows' stride / 2 where the words
                                    // sit behind the node's row (rows of <= 8 columns: the word comes with the row's line and is wiped with its store)
 };
@@ -753,15 +804,30 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     unsigned long long* const dep_i = ra.dep + (uint64_t)i * ra.dep_stride;
     unsigned long long* const dep_j = ra.dep + (uint64_t)j * ra.dep_stride;
     // (the classes were entered by the launch before this one: plain loads -- behind the row, the word comes with the row's line)
-    if (cmp && !half && !(a.dbg & 32)) wi = *dep_i;   // (dbg 16 / 32: timing experiments, wrong results)
-    if (act0 && !(a.dbg & 32)) wj = *dep_j;
-    fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
-    fi.issue(c.y, i, cmp, yi, c.ystride);
-    fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);
-    if constexpr (TILE) ft.land(sh.tile, sh.tnode);
-    fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
-    fi.land(stage, yi);
-    fj.land(stage, yj);
+    const bool lines = DIM == 8 && ra.dep_stride == (uint32_t)kLineFloats / 2u;   // (uniform) rows of 8 columns with the words in the node's line
+    if (lines) {
+        if constexpr (DIM == 8) {
+            LineFetch li, lj;
+            fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
+            li.issue(c.y, i, cmp);
+            lj.issue(c.y, j, act0);   // (a chain's followers want the word: the last of them announces the chain)
+            if constexpr (TILE) ft.land(sh.tile, sh.tnode);
+            fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
+            li.land(stage, yi, wi, ra.set);
+            lj.land(stage, yj, wj, ra.set);
+            if (half) wi = 0ull;
+        }
+    } else {
+        if (cmp && !half && !(a.dbg & 32)) wi = *dep_i;   // (dbg 16 / 32: timing experiments, wrong results)
+        if (act0 && !(a.dbg & 32)) wj = *dep_j;
+        fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
+        fi.issue(c.y, i, cmp, yi, c.ystride);
+        fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);
+        if constexpr (TILE) ft.land(sh.tile, sh.tnode);
+        fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
+        fi.land(stage, yi);
+        fj.land(stage, yj);
+    }
     // the node-by-node order: classes before this one that hold the node must be through with it; classes after it will wait for us
     const uint32_t below = (1u << q) - 1u;
     const uint32_t above = q >= 31u ? 0u : ~((2u << q) - 1u);
@@ -840,15 +906,22 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
             }
             // stores: as sl_step_body for the rows no later class of the slice will ask for; the node's last event of the slice wipes its
             // word (everybody who had to read it has: they are earlier classes, or this chain)
-            row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride);   // :1239
-            row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, c.ystride);   // :1301
+            if (lines) {   // (the row's store takes the wiped word along: one request)
+                if constexpr (DIM == 8) {
+                    line_store(c.y, j, fin && store_j && !succ_j, stage, yj, ra.set);   // :1239
+                    line_store(c.y, i, fin && store_i && !succ_i, stage, yi, ra.set);   // :1301
+                }
+            } else {
+                row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride);   // :1239
+                row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, c.ystride);   // :1301
+                if (fin && store_i && !succ_i && !(a.dbg & 16)) *dep_i = 0ull;
+                if (fin && store_j && !succ_j && !(a.dbg & 16)) *dep_j = 0ull;
+            }
             if (fin && store_i && succ_i) {
                 store_row_agent<DIM>(c.y, i, yi, c.ystride);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 atomicOr(dep_i, 1ull << (32u + q));
             }
-            if (fin && store_i && !succ_i && !(a.dbg & 16)) *dep_i = 0ull;
-            if (fin && store_j && !succ_j && !(a.dbg & 16)) *dep_j = 0ull;
             if (fin) phase = 2u;
         }
         if (!__ballot(phase != 2u)) break;
