@@ -971,9 +971,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (uint32_t)o->dev.dim;
     // (floats from the start of a node's line: rows of 8 columns sit in the middle of their line, a set of words on either side --
     // ce_slice_kernels.h: LineFetch --; shorter rows at its start, the two sets behind them)
-    const bool lines = words_in_rows && o->dev.dim == 8;
-    const uint32_t row_at = lines ? (uint32_t)kLineRowAt : 0u;
-    const uint32_t word_at[2] = {lines ? 0u : (((uint32_t)o->dev.dim + 1u) & ~1u), lines ? (uint32_t)kLineRowAt + 8u : (((uint32_t)o->dev.dim + 1u) & ~1u) + 2u};
+    const bool lines = words_in_rows && (o->dev.dim == 8 || o->dev.dim == 2);
+    const uint32_t row_at = !lines ? 0u : (o->dev.dim == 8 ? (uint32_t)LineShape<8>::kRowAt : (uint32_t)LineShape<2>::kRowAt);
+    const uint32_t odd_at = !lines ? 0u : (o->dev.dim == 8 ? (uint32_t)LineShape<8>::kOddWordAt : (uint32_t)LineShape<2>::kOddWordAt);
+    const uint32_t word_at[2] = {lines ? 0u : (((uint32_t)o->dev.dim + 1u) & ~1u), lines ? odd_at : (((uint32_t)o->dev.dim + 1u) & ~1u) + 2u};
     // internal numbering (ce_slice_prepare): the batch runs on a relabelled copy of the coordinates
     CeDev cdev = o->dev;
     cdev.ystride = ystride;
@@ -1104,6 +1105,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ra.step_seq0 = step_seq_base + s * classes;
         ra.next_sptr = nullptr;
         ra.set = s & 1u;
+        ra.lines = lines ? 1u : 0u;
         if (words_in_rows) {
             ra.dep = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at[s & 1u]);
             ra.dep_next = reinterpret_cast<unsigned long long*>(o->sl_y.p + word_at[(s + 1u) & 1u]);

@@ -157,53 +157,70 @@ __device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t id
     }
     wave_lds_sync();
 }
-// ... of the pieces [lo, hi] of the record only
-template <int NF>
-__device__ __forceinline__ void coop_store_pieces(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride, int lo, int hi) {
-    constexpr int G = NF / 4, RS = NF + 4;
-    const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
-    const uint32_t word = idx | (want ? 0x80000000u : 0u);
-    wave_lds_sync();
-#pragma unroll
-    for (int t = 0; t < G; t++) {
-        const uint32_t wt = group_bcast<G>(word, t);
-        if ((wt & 0x80000000u) && sub >= lo && sub <= hi)
-            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
-    }
-    wave_lds_sync();
-}
-// A node's LINE in a merged batch on rows of 8 columns (ce_slice_gradient_iteration: words_in_rows): 64 bytes =
-// {word of the even slices, 8 spare bytes | the row, 32 bytes | word of the odd slices, 8 spare bytes}; c.y points at the ROW of node 0
-// (every other kernel of the mode sees rows 16 floats apart).  One request of four lanes brings row and words; the row's store takes
-// the slice's word along, zeroed (the event that stores a row the plain way is the node's last of the slice: it wipes the word).
-constexpr int kLineFloats = 16, kLineRowAt = 4;
+// A node's LINE in a merged batch on rows of 8 or of 2 columns (ce_slice_gradient_iteration: words_in_rows): four pieces --
+//   8 columns: 64 bytes = {word of the even slices, 8 spare bytes | the row, 2 pieces | word of the odd slices, 8 spare bytes}
+//   2 columns: 32 bytes = {word of the even slices | the row | word of the odd slices | 8 spare bytes}
+// c.y points at the ROW of node 0 (every other kernel of the mode sees rows kFloats apart).  One request of four lanes brings row
+// and words; the row's store takes the slice's word along, zeroed (the event that stores a row the plain way is the node's last of
+// the slice: it wipes the word) -- the pieces [0, kRowPieces] on an even slice, [1, kRowPieces + 1] on an odd one.
+template <int DIM>
+struct LineShape {
+    static constexpr int kFloats = DIM == 8 ? 16 : 8;      // a node's line (= the stride of the rows)
+    static constexpr int kPiece = kFloats / 4;             // floats per piece: one lane's share of a request
+    static constexpr int kRowPieces = DIM == 8 ? 2 : 1;
+    static constexpr int kRowAt = kPiece;                  // floats from the start of the line
+    static constexpr int kOddWordAt = kPiece * (kRowPieces + 1);
+    static constexpr int kStageRow = kFloats + 4;
+};
+template <int DIM>
+constexpr bool kHasLines = DIM == 8 || DIM == 2;
+template <int DIM>
 struct LineFetch {
-    f4 pc[kLineFloats / 4];
-    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want) { coop_issue<kLineFloats>(y - kLineRowAt, node, want, pc, kLineFloats); }
-    __device__ __forceinline__ void land(float* stage, float* row, unsigned long long& word, uint32_t set) {
-        coop_land<kLineFloats>(pc, stage);
-        const float* p = stage + (threadIdx.x & 63) * (kLineFloats + 4);
+    using S = LineShape<DIM>;
+    using piece_t = float __attribute__((ext_vector_type(S::kPiece)));
+    piece_t pc[4];
+    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want) {
+        const uint32_t sub = (threadIdx.x & 63) & 3u, word = want ? node : 0u;   // (unconditional loads: coop_issue says why)
+        const float* base = y - S::kRowAt;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const f4 v = *reinterpret_cast<const f4*>(p + kLineRowAt + 4 * q);
-            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+        for (int t = 0; t < 4; t++) {
+            const uint32_t wt = group_bcast<4>(word, t);
+            pc[t] = *reinterpret_cast<const piece_t*>(base + (uint64_t)wt * S::kFloats + sub * (uint32_t)S::kPiece);
         }
-        const float* wp = p + (set ? kLineRowAt + 8 : 0);
+    }
+    __device__ __forceinline__ void land(float* stage, float* row, unsigned long long& word, uint32_t set) {
+        const int lane = threadIdx.x & 63, sub = lane & 3, gb = lane & ~3;
+#pragma unroll
+        for (int t = 0; t < 4; t++) *reinterpret_cast<piece_t*>(stage + (gb + t) * S::kStageRow + sub * S::kPiece) = pc[t];
+        wave_lds_sync();
+        const float* p = stage + lane * S::kStageRow;
+#pragma unroll
+        for (int q = 0; q < DIM; q++) row[q] = p[S::kRowAt + q];
+        const float* wp = p + (set ? S::kOddWordAt : 0);
         word = ((unsigned long long)__float_as_uint(wp[1]) << 32) | __float_as_uint(wp[0]);
         wave_lds_sync();
     }
 };
+template <int DIM>
 __device__ __forceinline__ void line_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* row, uint32_t set) {
-    float* p = stage + (threadIdx.x & 63) * (kLineFloats + 4);
-    f4 z; z.x = 0.f; z.y = 0.f; z.z = 0.f; z.w = 0.f;
-    *reinterpret_cast<f4*>(p) = z;
-    *reinterpret_cast<f4*>(p + 12) = z;
+    using S = LineShape<DIM>;
+    using piece_t = float __attribute__((ext_vector_type(S::kPiece)));
+    const int lane = threadIdx.x & 63, sub = lane & 3, gb = lane & ~3;
+    float* p = stage + lane * S::kStageRow;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        f4 v; v.x = row[4 * q]; v.y = row[4 * q + 1]; v.z = row[4 * q + 2]; v.w = row[4 * q + 3];
-        *reinterpret_cast<f4*>(p + kLineRowAt + 4 * q) = v;
+    for (int q = 0; q < S::kFloats; q++) p[q] = (q >= S::kRowAt && q < S::kRowAt + DIM) ? row[q - S::kRowAt] : 0.f;
+    const uint32_t word = node | (want ? 0x80000000u : 0u);
+    const int lo = set ? 1 : 0, hi = (set ? 1 : 0) + S::kRowPieces;
+    float* base = y - S::kRowAt;
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t wt = group_bcast<4>(word, t);
+        if ((wt & 0x80000000u) && sub >= lo && sub <= hi)
+            *reinterpret_cast<piece_t*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * S::kFloats + (uint32_t)sub * (uint32_t)S::kPiece) =
+                *reinterpret_cast<const piece_t*>(stage + (gb + t) * S::kStageRow + sub * S::kPiece);
     }
-    coop_store_pieces<kLineFloats>(y - kLineRowAt, node, want, stage, kLineFloats, set ? 1 : 0, set ? 3 : 2);
+    wave_lds_sync();
 }
 // rows: cooperative for 8 and 16 columns (2 / 4 lanes per row), one lane per row otherwise (<= 4 columns: one request anyway;
 // 32 / 64 columns: rare, kept simple)
@@ -212,9 +229,9 @@ constexpr bool kCoopRow = DIM == 8 || DIM == 16;
 template <int SREC>
 constexpr bool kCoopRec = SREC <= 32;
 template <int DIM>
-constexpr int kRowStage = DIM == 8 ? 16 : DIM;   // (rows of 8 columns may travel as whole node lines: LineFetch)
+constexpr int kRowStage = kHasLines<DIM> ? LineShape<DIM>::kFloats : (kCoopRow<DIM> ? DIM : 0);   // (rows of 8 / 2 columns may travel as whole node lines: LineFetch)
 template <int DIM, int SREC>
-constexpr int kStageFloats = (kCoopRow<DIM> || kCoopRec<SREC>) ? 64 * ((((kCoopRow<DIM> ? kRowStage<DIM> : 0) > (kCoopRec<SREC> ? SREC : 0)) ? kRowStage<DIM> : SREC) + 4) : 1;
+constexpr int kStageFloats = (kRowStage<DIM> > 0 || kCoopRec<SREC>) ? 64 * (((kRowStage<DIM> > (kCoopRec<SREC> ? SREC : 0)) ? kRowStage<DIM> : SREC) + 4) : 1;
 
 template <int DIM>
 struct RowFetch {  // a coordinate row on its way to its lane
@@ -737,6 +754,7 @@ struct SliceRunArgs {
     const uint32_t* next_sptr;     // the NEXT slice's class pointers (nullptr: nothing to prepare): its events enter `dep_next` while this slice runs
     unsigned long long* dep_next;  // [n]: the other set of words (a slice cleans its own set as it goes)
     uint32_t set;                  // 0 / 1: which of the two sets of words this slice runs on
+    uint32_t lines;                // the words sit in the node's line around its row (LineShape: rows of 8 / 2 columns)
     uint32_t dep_stride;           // 64-bit words from one node's word to the next: 1 (an array of its own), or the coordinate rows' stride / 2 where the words
                                    // sit behind the node's row (rows of <= 8 columns: the word comes with the row's line and is wiped with its store)
 };
@@ -804,10 +822,10 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     unsigned long long* const dep_i = ra.dep + (uint64_t)i * ra.dep_stride;
     unsigned long long* const dep_j = ra.dep + (uint64_t)j * ra.dep_stride;
     // (the classes were entered by the launch before this one: plain loads -- behind the row, the word comes with the row's line)
-    const bool lines = DIM == 8 && ra.dep_stride == (uint32_t)kLineFloats / 2u;   // (uniform) rows of 8 columns with the words in the node's line
+    const bool lines = kHasLines<DIM> && ra.lines != 0u;   // (uniform) the words in the node's line
     if (lines) {
-        if constexpr (DIM == 8) {
-            LineFetch li, lj;
+        if constexpr (kHasLines<DIM>) {
+            LineFetch<DIM> li, lj;
             fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
             li.issue(c.y, i, cmp);
             lj.issue(c.y, j, act0);   // (a chain's followers want the word: the last of them announces the chain)
@@ -907,9 +925,9 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
             // stores: as sl_step_body for the rows no later class of the slice will ask for; the node's last event of the slice wipes its
             // word (everybody who had to read it has: they are earlier classes, or this chain)
             if (lines) {   // (the row's store takes the wiped word along: one request)
-                if constexpr (DIM == 8) {
-                    line_store(c.y, j, fin && store_j && !succ_j, stage, yj, ra.set);   // :1239
-                    line_store(c.y, i, fin && store_i && !succ_i, stage, yi, ra.set);   // :1301
+                if constexpr (kHasLines<DIM>) {
+                    line_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, ra.set);   // :1239
+                    line_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, ra.set);   // :1301
                 }
             } else {
                 row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride);   // :1239
