@@ -958,8 +958,10 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 // the caller then asks for the approximate rounds mode, AE_CE_HOGWILD, by name).
 // Round 5: the time-sliced mode runs under-filled slices MERGED (one launch per slice, ce_slice_kernels.h) and takes over earlier: exact
 // kNN graphs of Higgs-shaped points with hubness weighting, ordered / time-sliced ms per batch: 24 M samples 11.8 / 18.5, 48 M 23.4 /
-// 21.4, 72 M 34.5 / 27.1, 99 M (configs[2]'s large graph) 49.5 / 33.8 -- break-even at ~48 M (tools/run_auto_crossover.py).
-constexpr uint64_t kAutoOrderedSamples = 3ull << 24;   // 50.3 M
+// 21.4, 72 M 34.5 / 27.1, 99 M (configs[2]'s large graph) 49.5 / 33.8 -- break-even at ~48 M (tools/run_auto_crossover.py); with the
+// dependency words in the rows' lines: 24 M 11.8 / 14.9, 36 M 19.9 / 14.9, 48 M 23.5 / 17.1, 72 M 36.1 / 22.4, 99 M 49.5 / 27.2 --
+// break-even at ~29 M.
+constexpr uint64_t kAutoOrderedSamples = 1ull << 25;   // 33.6 M
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
     if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;

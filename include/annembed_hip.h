@@ -132,8 +132,8 @@ enum {
        statistics are those of the sequential loop.  asked_dim in {2,3,4,8,16}, rows of <= 32 neighbours, one device,
        at most as many nodes as the device holds resident lanes (~80 k on MI355X); otherwise AE_ERR_INVALID_ARG. */
     AE_CE_EVENT = 3,
-    /* Default: the fastest mode whose output is the reference's.  AE_CE_ORDERED for batches of up to 50 M samples (3 * 2^24; 2^27 before round 5's merged slices), AE_CE_SLICED
-       beyond (measured cross-over: ~48 M samples per batch on an exact kNN graph with hubs -- its under-filled time slices run as one
+    /* Default: the fastest mode whose output is the reference's.  AE_CE_ORDERED for batches of up to 2^25 (33.6 M) samples (2^27 before round 5's merged slices), AE_CE_SLICED
+       beyond (measured cross-over: ~29 M samples per batch on an exact kNN graph with hubs -- its under-filled time slices run as one
        launch each --, ~30 M on a lattice of uniform in-degree); both statistically faithful (as the reference's own threaded loop is
        not reproducible sample by sample either) -- the bit-exact replay of the reference's sequential loop is AE_CE_SEQUENTIAL,
        by name.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero

@@ -1,6 +1,6 @@
 """GPU tests at the sizes of BASELINE.json's configs (run with -m gpu on an MI355X).
 
-What is compared with what: the statistically faithful modes -- the default (AE_CE_AUTO -> the ordered dataflow up to 50 M samples per
+What is compared with what: the statistically faithful modes -- the default (AE_CE_AUTO -> the ordered dataflow up to 2^25 samples per
 batch, the time-sliced mode beyond), AE_CE_EVENT, AE_CE_SLICED -- are held against the HIP SEQUENTIAL mode (AE_CE_SEQUENTIAL) on the
 full schedules of the reference's examples, NOT against the oracle directly: the oracle's sequential loop takes minutes at these sizes.
 That is sound only because the sequential mode itself is pinned to the oracle bit for bit elsewhere -- tests/test_gpu_parity.py:
@@ -215,7 +215,7 @@ def test_c3_schedule_hierarchical_60k(A):
 def test_c3_full_size_properties(A):
     """configs[2] at full size: 1 650 000 x 28 Higgs-shaped points, k = 6, hierarchical (small graph = first n / 24 points),
     through Embedder.from_hkgraph(...).embed() with the default mode (the ordered dataflow on the small graph, the time-sliced mode --
-    merged slices -- on the large one: 99 M samples per batch, beyond AE_CE_AUTO's 50 M).  Size-independent properties: finite, centred initial box, embedding inside the reference's
+    merged slices -- on the large one: 99 M samples per batch, beyond AE_CE_AUTO's 2^25).  Size-independent properties: finite, centred initial box, embedding inside the reference's
     clipping envelope, CE reported for both ends."""
     import torch
     n, k = 1650000, 6
