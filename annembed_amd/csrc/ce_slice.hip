@@ -404,16 +404,15 @@ __global__ void __launch_bounds__(256) sl_perm_invert_kernel(uint64_t n, const u
     if (x < n) perm[order[x]] = (uint32_t)x;
 }
 // rows of `dim` floats: to_internal: dst[perm[v]] = src[v]; else dst[v] = src[perm[v]] (perm null: the identity).  The internal copy's
-// rows are `stride` floats apart (dim, or more: a node's dependency words sit behind its row, ce_slice_kernels.h -- zeroed on the way in);
+// rows are `stride` floats apart (dim, or more: a node's dependency words sit around its row, ce_slice_kernels.h -- the copy is zeroed first);
 // [v_lo, v_hi) \ [skip_lo, skip_hi): the rows moved (internal numbers: an exchange moves a rank's own rows out and the others' in)
 __global__ void __launch_bounds__(256) sl_move_rows_kernel(uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, uint32_t dim, uint32_t stride,
-                                                           const uint32_t* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst, int to_internal, int zero_words) {
-    const uint32_t cols = (to_internal && zero_words) ? stride : dim;
-    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < (v_hi - v_lo) * cols; t += (uint64_t)gridDim.x * 256ull) {   // (n x dim may pass 2^32)
-        const uint64_t v = v_lo + t / cols, q = t % cols;
+                                                           const uint32_t* __restrict__ perm, const float* __restrict__ src, float* __restrict__ dst, int to_internal) {
+    for (uint64_t t = blockIdx.x * 256ull + threadIdx.x; t < (v_hi - v_lo) * dim; t += (uint64_t)gridDim.x * 256ull) {   // (n x dim may pass 2^32)
+        const uint64_t v = v_lo + t / dim, q = t % dim;
         if (v >= skip_lo && v < skip_hi) continue;
         const uint64_t p = perm ? perm[v] : v;
-        if (to_internal) dst[p * stride + q] = q < dim ? src[v * dim + q] : 0.f;
+        if (to_internal) dst[p * stride + q] = src[v * dim + q];
         else dst[v * dim + q] = src[p * stride + q];
     }
 }
@@ -981,15 +980,15 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const bool relabelled = o->sl_perm.n != 0;
     const bool own_copy = relabelled || words_in_rows;
     const uint32_t* perm = relabelled ? (const uint32_t*)o->sl_perm.p : nullptr;
-    auto move_rows = [&](uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, const float* src, float* dst, int to_internal, int zero_words) {
+    auto move_rows = [&](uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, const float* src, float* dst, int to_internal) {
         if (v_hi <= v_lo) return;
-        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap((v_hi - v_lo) * ystride, 256, 1u << 20)), dim3(256), 0, stream(), v_lo, v_hi, skip_lo, skip_hi,
-                           (uint32_t)o->dev.dim, ystride, perm, src, dst, to_internal, zero_words);
+        hipLaunchKernelGGL(sl_move_rows_kernel, dim3(grid_cap((v_hi - v_lo) * o->dev.dim, 256, 1u << 20)), dim3(256), 0, stream(), v_lo, v_hi, skip_lo, skip_hi,
+                           (uint32_t)o->dev.dim, ystride, perm, src, dst, to_internal);
     };
     if (own_copy) {
         if (o->sl_y.n < n * ystride) o->sl_y.alloc(n * ystride);
         if (words_in_rows) o->sl_y.zero();
-        move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p + row_at, 1, 0);
+        move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p + row_at, 1);
         cdev.y = o->sl_y.p + row_at;
         if (relabelled && o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
     }
@@ -1071,9 +1070,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
     uint64_t exchanges_done = 0;
     auto exchange_now = [&] {
-        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
+        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
         ce_comm_exchange(o);
-        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p + row_at, 1, 0);
+        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p + row_at, 1);
         exchanges_done++;
     };
     auto exchange_after = [&](uint32_t s) {
@@ -1322,7 +1321,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         t_drain += wall() - t_enq;
     }
     owe.armed = false;
-    if (own_copy) move_rows(0, n, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0, 0);   // back to the caller's labels and row stride
+    if (own_copy) move_rows(0, n, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // back to the caller's labels and row stride
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");
