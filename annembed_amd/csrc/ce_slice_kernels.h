@@ -735,14 +735,22 @@ __global__ void __launch_bounds__(256, (F64 && TILE && DIM <= 8) ? 3 : 1) sl_dir
 // little it holds, and a slice is k + 5 of them.  But only ~17 % of a slice's events share a node with another event of the slice
 // (half an event per node and slice): the launch boundary between two classes orders ALL events of the one before ALL of the other
 // where the law only asks for an order between events that share a node.  Here every class of a slice runs in ONE launch, a workgroup
-// holding events of one class only, and the order between two events on a node is kept node by node: a per-node word (`dep`) holds
-// the classes that have an event on the node (set by a pass over the slice's events before the launch: two fire-and-forget
-// atomics per event) and the classes that are through with it; the node's last event of the slice wipes the word.  An event whose node has an earlier class waits for that class's bit (polls, a budget
-// instead of a hang), then reads the row with agent-scope loads; an event whose node has a later class writes the row through
-// (agent-scope stores), waits for them and sets its bit.  The other ~83 % run exactly as in sl_step_body.  Workgroups are
-// dispatched in index order and a class's workgroups come before the next class's: an event only ever waits for a workgroup that
-// is already running.  Chains through a shared target stay what they were; the chain as a whole takes the target's place in the
-// node's order (its head waits, its tail signals).
+// holding events of one class only, and the order between two events on a node is kept node by node:
+//   * a per-node 64-bit word holds the classes that have an event on the node (low half) and the classes that are through with it
+//     (high half).  The low halves are entered by the slice BEFORE this one, from inside its launch (a wave that is through enters
+//     the next slice's events: two fire-and-forget atomics per event, beside the other waves' work), into the other of two sets of
+//     words; a slice without such a predecessor takes a pass of its own (sl_dep_mark_kernel, ce_slice.hip).
+//   * LANE BY LANE: a lane whose node has an earlier class polls that class's bit (a budget instead of a hang), then reads the row
+//     with agent-scope loads -- while the other lanes of its wave run (the body is a loop over the lanes that are ready); a lane whose
+//     node has a later class writes the row through (agent-scope stores), waits for them and sets its bit: the target's row the
+//     moment its chain's last lane has attracted, the source's row after its repulsions.  The node's last event of the slice wipes
+//     the word.  The other ~83 % run as in sl_step_body.
+//   * Workgroups are dispatched in index order and a class's workgroups come before the next class's: an event only ever waits for a
+//     workgroup that is already running.  Chains through a shared target take their turns inside the same loop; the chain as a whole
+//     takes the target's place in the node's order (its head waits, its last lane announces it).
+//   * Where the words live: rows of 8 / 2 columns keep them in the node's own line of the batch's internal copy (LineShape: one
+//     request brings row and word, the row's store takes the wiped word along), rows of 3 / 4 columns behind the row, longer rows
+//     in an array of their own (SliceRunArgs::dep_stride).
 constexpr uint32_t kDepBits = 32;                       // classes a merged slice can hold
 constexpr uint32_t kErrDepPoll = 16u;                   // done_counter[1024] flag: a dependency inside a merged slice was not met within the poll budget
 struct SliceRunArgs {

@@ -1,13 +1,16 @@
 #!/bin/bash
 # usage (GPU box): tools/prof_rank_share_pmc.sh <tag> <world>  -- HBM counters of the merged slice kernel on a rank's share of configs[3]'s graph (tools/run_shard_time.py);
+#                  tools/prof_rank_share_pmc.sh <tag> c3         -- ... on configs[2]'s large graph, one device (tools/run_c3knn_sliced.py; 2 columns)
 # FETCH_SIZE and WRITE_SIZE in their own passes, as the guide prescribes (gfx950: FETCH_SIZE doubled)
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/rankpmc_$1; mkdir -p $OUT
 export NEEDLE="sl_slice_kernel<8, 16, true, true>"
+PROG="$R/tools/run_shard_time.py $2"
+if [ "$2" = "c3" ]; then export NEEDLE="sl_slice_kernel<2, 16, true"; PROG="$R/tools/run_c3knn_sliced.py 1650000 2"; fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/tools/run_shard_time.py $2 > $OUT/run.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $R/tools/run_shard_time.py $2 > $OUT/run_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $R/tools/run_shard_time.py $2 > $OUT/run_write.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python3 $PROG > $OUT/run.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python3 $PROG > $OUT/run_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python3 $PROG > $OUT/run_write.log 2>&1
 cd $OUT
 python3 - <<'PY'
 import csv, glob, json, os
@@ -31,5 +34,5 @@ out.update({"FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": wri
 json.dump(out, open('pmc_slice_kernel.json', 'w'), indent=1)
 print(out)
 PY
-grep world run.log
+grep 'world\|sliced ms' run.log
 find . -name "*.db" -delete; find . -name "*kernel_trace.csv" -delete; find . -name "*counter_collection.csv" -size +1M -delete
