@@ -138,7 +138,8 @@ def _partition_report(rep):
 
 
 def set_summation_order(tree):
-    """ae_set_summation_order: True = f64 tree reductions in the stage-level entry points, False = the reference's sequential f32 order"""
+    """ae_set_summation_order: True (the library's default) = f64 tree reductions in the stage-level entry points, False = the reference's
+    sequential f32 order (single-lane chains: what bit parity with the oracle needs).  Embedder.embed / EntropyOptim choose by their CE mode."""
     check(L.load().ae_set_summation_order(1 if tree else 0))
 
 

@@ -961,7 +961,10 @@ static void run_sequential(ae_entropy_optim* o, uint64_t nb_sample, double step,
 // 21.4, 72 M 34.5 / 27.1, 99 M (configs[2]'s large graph) 49.5 / 33.8 -- break-even at ~48 M (tools/run_auto_crossover.py); with the
 // dependency words in the rows' lines: 24 M 11.8 / 14.9, 36 M 19.9 / 14.9, 48 M 23.5 / 17.1, 72 M 36.1 / 22.4, 99 M 49.5 / 27.2 --
 // break-even at ~29 M.
-constexpr uint64_t kAutoOrderedSamples = 1ull << 25;   // 33.6 M
+// The ~29 M break-even belongs to rows of <= 8 columns, whose dependency words ride in the rows' own lines; wider rows keep the words
+// in an array of their own (the first set of figures above: break-even ~48 M samples per batch).
+constexpr uint64_t kAutoOrderedSamples = 1ull << 25;        // 33.6 M: rows of <= 8 columns
+constexpr uint64_t kAutoOrderedSamplesWide = 48ull << 20;   // 50.3 M: wider rows
 uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t samples_per_batch, uint32_t max_nbng, uint64_t nnz) {
     if (mode > AE_CE_ORDERED) fail(AE_ERR_INVALID_ARG, "unknown ce_mode %u", mode);
     if (mode != AE_CE_AUTO) return mode;
@@ -974,7 +977,8 @@ uint32_t ae::resolve_ce_mode(uint32_t mode, uint64_t dim, bool sharded, uint64_t
     // (the ordered dataflow's scratch: 92 bytes of plan, sorted events and predecessors per sample + two published rows; long rows
     // at the top of the range would ask for more than a sixth of the device: 48 GB is the line)
     const uint64_t ordered_scratch = samples_per_batch * (92ull + 8ull * ae_pad_dim((uint32_t)dim));
-    if ((samples_per_batch <= kAutoOrderedSamples && ordered_scratch <= (48ull << 30)) || !sliced_ok) {
+    const uint64_t ordered_up_to = ae_pad_dim((uint32_t)dim) <= 8 ? kAutoOrderedSamples : kAutoOrderedSamplesWide;
+    if ((samples_per_batch <= ordered_up_to && ordered_scratch <= (48ull << 30)) || !sliced_ok) {
         if (samples_per_batch >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "no faithful CE mode fits: rows of more than 32 neighbours or >= 2^32 edges with >= 2^31 samples per batch");
         return AE_CE_ORDERED;
     }
@@ -1006,7 +1010,9 @@ ae_entropy_optim* ae::entropy_optim_create_impl(const ae_kgraph* g, const ae_nod
         // tree reduction while the embedder has switched the summation order for a mode that is not the bit-exact one: linalg.h)
         // (AE_CE_AUTO never resolves to the bit-exact mode: it runs by name only)
         const bool bit_exact_follows = params->ce_mode == AE_CE_SEQUENTIAL;
-        TreeSums sums(tree_sums() || !bit_exact_follows);
+        // (an enclosing scope -- the embedder's, which applied the same rule to the mode it resolved -- is kept; a stage-level call decides
+        // by its own mode, whatever the process-wide default says)
+        TreeSums sums(tree_sums_scope() >= 0 ? tree_sums() : !bit_exact_follows);
         const float mean_scale = seq_sum_f32(np->scale.p, n) / (float)n;
         o->emb_scale.alloc(n);
         hipLaunchKernelGGL(embedded_scales_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), n, np->scale.p, mean_scale,

@@ -960,7 +960,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
     // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
     // Full steps stay one launch per class: they are bound by requests, and the dependency words would only add to them.
-    const double step_events = classes ? seg_local * (1.0 - o->sl_ov_frac) / ((double)n_slices * (double)classes) : 0.;
+    // (a sharded run: decided from what every rank shares -- the rank-agreed share of a segment and overflow fraction, as the slice
+    // count above -- because the form decides which label space the in-batch exchanges move: ranks on different sides of the
+    // threshold would read each other's rows in the wrong numbering)
+    const double step_events = classes ? seg_rank * (1.0 - ov_sched) / ((double)n_slices * (double)classes) : 0.;
     const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
                         (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
     // Rows of <= 8 columns keep the two sets of dependency words BEHIND the node's row in the batch's internal copy (rows 32 / 64

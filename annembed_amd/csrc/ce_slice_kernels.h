@@ -799,7 +799,6 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     const uint32_t wkey = pcg_hash(nkey + s_seq * 0x85EBCA6Bu) + block * 64u;
     const uint32_t p = s_begin + block * 256u + threadIdx.x;
     uint32_t done = 0;
-    const uint32_t next_ptr = ra.next_sptr ? ra.next_sptr[min((uint32_t)lane, ra.classes)] : 0u;   // (lane l: where the next slice's class l starts)
     // hop 1: the event and its two neighbours in the array, the tile
     const bool act0 = p < s_end;
     Event e{0u, kNoNode}, pv{0u, kNoNode}, nx{0u, kNoNode};
@@ -962,10 +961,13 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     // The NEXT slice's events enter their words now: two fire-and-forget atomics per event (~24 G/s: 29 us for a slice of 344 k events
     // as a launch of its own) that nothing in this slice waits for -- issued when a wave is through, they run beside the other waves' work.
     if (ra.next_sptr) {
-        const uint32_t n_begin = __shfl(next_ptr, 0), n_end = __shfl(next_ptr, (int)ra.classes);
+        // (the class pointers are read as uniform scalar loads, not shuffled out of a register: the loop's trip count differs from lane
+        // to lane, and a shuffle FROM a lane that has left the loop is undefined -- an empty trailing class would have been marked
+        // in a wrong class bit)
+        const uint32_t n_begin = ra.next_sptr[0], n_end = ra.next_sptr[ra.classes];
         for (uint32_t t = n_begin + blockIdx.x * 256u + threadIdx.x; t < n_end; t += gridDim.x * 256u) {
             uint32_t qn = 0;
-            for (uint32_t l = 1; l < ra.classes; l++) qn += t >= (uint32_t)__shfl(next_ptr, (int)l) ? 1u : 0u;
+            for (uint32_t l = 1; l < ra.classes; l++) qn += t >= ra.next_sptr[l] ? 1u : 0u;
             dep_mark_event(ra.dep_next, ra.dep_stride, a.ev[t], qn);
         }
     }

@@ -37,16 +37,18 @@ bool orthonormalize_fast_failed();
 // evals[l] descending, evecs[l x l] row-major with eigenvectors in columns.
 void jacobi_eigh_device(const double* d_g, uint32_t l, double* d_evals, double* d_evecs);
 
-// Summation order of the three sums below.  By default they reproduce the reference's f32 orders with single-lane
-// chains (bit parity of the dmap initialisation with the oracle: 40-100 ms each at 11 M nodes).  While a TreeSums(true) is
-// alive on this thread they are two-level f64 tree reductions instead (deterministic, microseconds): the embedder
-// switches to them when the CE mode it resolved is not the bit-exact one, so nothing downstream is bit-comparable anyway.
+// Summation order of the three sums below: two-level f64 tree reductions (deterministic, microseconds) or the reference's f32 orders as
+// single-lane chains (bit parity of the dmap initialisation with the oracle: 40-100 ms each at 11 M nodes).  A TreeSums scope alive on
+// this thread decides (true: trees, false: the reference order -- the embedder and EntropyOptim::new open one: the reference order exactly
+// when the CE mode that follows is the bit-exact one); without a scope the process-wide default does (ae_set_summation_order: trees unless
+// the caller asked for the reference order).
 struct TreeSums {
     explicit TreeSums(bool on);
     ~TreeSums();
-    bool prev;
+    int prev;
 };
 bool tree_sums();
+int tree_sums_scope();   // -1: no scope on this thread, 0 / 1: the innermost scope's choice
 void set_tree_sums_default(bool on);
 
 // exact sequential f32 sum (the reference's iter().sum::<f32>() order) of d_x[0..n) with stride

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) smooth_norm_kernel(const uint32_t* __rest
 // sizes are steered back to the target every round).  Integer atomics only: the result does not depend on the order of execution.
 constexpr uint8_t kSideNone = 0, kSideLeft = 1, kSideRight = 2;
 __global__ void __launch_bounds__(256) refine_set_side_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint64_t left_count, uint8_t* __restrict__ side,
-                                                              int32_t* __restrict__ gain, int clear) {
+                                                              long long* __restrict__ gain, int clear) {
     const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
     if (p >= count) return;
     const uint32_t v = order[b + p];
@@ -239,14 +239,15 @@ __global__ void __launch_bounds__(256) refine_set_side_kernel(const uint32_t* __
 }
 __global__ void __launch_bounds__(256) refine_gain_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint32_t uniform_k, const uint64_t* __restrict__ indptr,
                                                           const uint32_t* __restrict__ nbr, const float* __restrict__ proba, const uint8_t* __restrict__ side,
-                                                          int32_t* __restrict__ gain) {
+                                                          long long* __restrict__ gain) {
+    // (64-bit gains: an edge weighs up to 4096 in both directions, and a hub of in-degree ~5e5 inside one piece would wrap 32 bits)
     const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
     if (p >= count) return;
     const uint32_t u = order[b + p];
     uint64_t rb, re;
     if (uniform_k) { rb = (uint64_t)u * uniform_k; re = rb + uniform_k; } else { rb = indptr[u]; re = indptr[u + 1]; }
     const uint8_t su = side[u];
-    int32_t mine = 0;
+    long long mine = 0;
     for (uint64_t x = rb; x < re; x++) {
         const uint32_t v = nbr[x];
         const uint8_t sv = side[v];
@@ -254,13 +255,13 @@ __global__ void __launch_bounds__(256) refine_gain_kernel(const uint32_t* __rest
         const int32_t w = proba ? max(1, (int32_t)(proba[x] * 4096.f)) : 1;
         const int32_t s = su == sv ? -w : w;
         mine += s;
-        atomicAdd(gain + v, s);
+        atomicAdd(reinterpret_cast<unsigned long long*>(gain + v), (unsigned long long)(long long)s);   // (two's complement: adds a signed weight)
     }
-    if (mine) atomicAdd(gain + u, mine);
+    if (mine) atomicAdd(reinterpret_cast<unsigned long long*>(gain + u), (unsigned long long)mine);
 }
 // counts[0 / 1]: candidates on the left / right (gain > 0 and this round's coin)
 __global__ void __launch_bounds__(256) refine_count_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, const uint8_t* __restrict__ side,
-                                                           const int32_t* __restrict__ gain, uint32_t round_key, unsigned long long* __restrict__ counts) {
+                                                           const long long* __restrict__ gain, uint32_t round_key, unsigned long long* __restrict__ counts) {
     const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
     unsigned long long cl = 0, cr = 0;
     if (p < count) {
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(256) refine_count_kernel(const uint32_t* __res
     if ((threadIdx.x & 63) == 0) { if (cl) atomicAdd(counts, cl); if (cr) atomicAdd(counts + 1, cr); }
 }
 // candidates move with probability thr / 2^32 of their side; gains are cleared for the next round; counts[2]: moved left -> right, [3]: right -> left
-__global__ void __launch_bounds__(256) refine_move_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint8_t* __restrict__ side, int32_t* __restrict__ gain,
+__global__ void __launch_bounds__(256) refine_move_kernel(const uint32_t* __restrict__ order, uint64_t b, uint64_t count, uint8_t* __restrict__ side, long long* __restrict__ gain,
                                                           uint32_t round_key, uint32_t thr_left, uint32_t thr_right, unsigned long long* __restrict__ counts) {
     const uint64_t p = blockIdx.x * 256ull + threadIdx.x;
     unsigned long long ml = 0, mr = 0;
@@ -464,7 +465,7 @@ void partition_nodes_device(const ae_kgraph* g, const float* d_proba, const floa
     DevBuf<uint32_t> skeys, skeys2, svals, svals2;
     DevBuf<uint8_t> d_side;
     DevBuf<float> d_z, d_z2;
-    DevBuf<int32_t> d_gain;
+    DevBuf<long long> d_gain;
     DevBuf<unsigned long long> d_counts;
     auto split_piece = [&](const Piece& pc, uint64_t left_count, Piece& left, Piece& right) {
         // sort order[begin, begin + size) along the piece's widest axis; the first left_count nodes are the left piece
@@ -538,7 +539,7 @@ void partition_nodes_device(const ae_kgraph* g, const float* d_proba, const floa
                 hipLaunchKernelGGL(refine_gain_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, g->uniform_k, (const uint64_t*)g->indptr.p,
                                    (const uint32_t*)g->nbr.p, d_proba, (const uint8_t*)d_side.p, d_gain.p);
                 hipLaunchKernelGGL(refine_count_kernel, dim3(pg), dim3(256), 0, stream(), (const uint32_t*)order.p, pc.begin, pc.size, (const uint8_t*)d_side.p,
-                                   (const int32_t*)d_gain.p, round_key, d_counts.p);
+                                   (const long long*)d_gain.p, round_key, d_counts.p);
                 unsigned long long hc[4];
                 d_counts.download(hc, 4);
                 // how many may move each way: the same number, corrected by what the sides are off their target

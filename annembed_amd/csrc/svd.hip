@@ -911,11 +911,15 @@ __global__ void __launch_bounds__(128) tree_sum_cols_final_kernel(const double* 
     for (uint32_t b = 0; b < nblocks; b++) s += partial[(uint64_t)b * dim + threadIdx.x];
     out[threadIdx.x] = (float)s;
 }
-static thread_local bool g_tree_sums = false;
-static bool g_tree_sums_default = false;   // ae_set_summation_order: what the stage-level entry points do outside an Embedder
-TreeSums::TreeSums(bool on) : prev(g_tree_sums) { g_tree_sums = on; }
-TreeSums::~TreeSums() { g_tree_sums = prev; }
-bool tree_sums() { return g_tree_sums || g_tree_sums_default; }
+// Three states per thread: no scope (-1: the process-wide default decides), an explicit scope asking for the reference order (0) or for
+// tree sums (1).  An explicit scope always wins: Embedder::embed / EntropyOptim::new in the bit-exact mode get the reference order
+// whatever ae_set_summation_order says.
+static thread_local int g_tree_scope = -1;
+static bool g_tree_sums_default = true;   // ae_set_summation_order: what the stage-level entry points do outside an Embedder
+TreeSums::TreeSums(bool on) : prev(g_tree_scope) { g_tree_scope = on ? 1 : 0; }
+TreeSums::~TreeSums() { g_tree_scope = prev; }
+bool tree_sums() { return g_tree_scope >= 0 ? g_tree_scope == 1 : g_tree_sums_default; }
+int tree_sums_scope() { return g_tree_scope; }
 void set_tree_sums_default(bool on) { g_tree_sums_default = on; }
 // x: n rows of `dim` consecutive values, `stride` floats apart
 static void tree_sum_cols(const float* d_x, uint64_t n, uint32_t dim, uint64_t stride, float* host_out) {

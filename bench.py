@@ -98,12 +98,11 @@ def svd_init_of(A, L, kg, d, reps=3):
     """the diffusion-map initialisation's randomized SVD (graphlaplace.rs:97-125: rank 20, 5 iterations) of a graph's laplacian, timed alone
     (U stays in HBM as in the embedder's own call): ms, GFLOP/s and HBM fraction by the SURVEY 8d formulas"""
     dp = A.DiffusionParams(d, 5.0, 12)
-    A.set_summation_order(True)   # (no bit-exact CE mode follows this call: f64 tree sums, as Embedder::embed chooses by itself)
+    # (stage-level calls sum as f64 trees by default -- ae_set_summation_order --, as Embedder::embed does when no bit-exact CE mode follows)
     t0 = time.perf_counter()
     lap = A.DiffusionMaps(dp).laplacian_from_kgraph(kg)
     L.check(L.load().ae_synchronize())
     lap_s = time.perf_counter() - t0
-    A.set_summation_order(False)
     _, n, nnz_a = lap.info()
     lap.do_svd(want_u=False)  # warm
     L.check(L.load().ae_synchronize())

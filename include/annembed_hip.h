@@ -62,11 +62,12 @@ int32_t ae_device_count(int32_t *count);
 int32_t ae_set_device(int32_t device);
 /* synchronise the library's stream on the current device */
 int32_t ae_synchronize(void);
-/* Summation order of the global f32 sums of the STAGE-LEVEL entry points (mean of the scales, column means of set_data_box, the
-   laplacian's normalisers ...).  AE_SUM_REFERENCE_ORDER (default): the reference's sequential f32 order, as single-lane chains -- what
-   bit parity with the oracle needs, 40-100 ms each at 11 M nodes.  AE_SUM_TREE: two-level f64 tree reductions (deterministic,
-   microseconds; the results differ from the reference order in the last bits).  ae_embedder_embed and ae_entropy_optim_create choose
-   by themselves: reference order exactly when the CE mode that follows is the bit-exact AE_CE_SEQUENTIAL. */
+/* Summation order of the global f32 sums of the STAGE-LEVEL entry points (ae_dmap_*, ae_set_data_box ...: the mean of the scales, the
+   column means of set_data_box, the laplacian's normalisers).  AE_SUM_TREE (the default since round 6): two-level f64 tree reductions --
+   deterministic, microseconds; the results differ from the reference's order in the last bits.  AE_SUM_REFERENCE_ORDER: the reference's
+   sequential f32 order as single-lane chains -- what bit parity with the oracle needs (the parity tests ask for it), 40-100 ms each at
+   11 M nodes (src/diffmaps.rs:801-822).  ae_embedder_embed and ae_entropy_optim_create do not look at this setting: they take the
+   reference order exactly when the CE mode that follows is the bit-exact AE_CE_SEQUENTIAL, trees otherwise. */
 enum { AE_SUM_REFERENCE_ORDER = 0, AE_SUM_TREE = 1 };
 int32_t ae_set_summation_order(uint32_t order);
 /* raw hipStream_t the library launches on (for hipEvent timing by the caller) */
@@ -136,7 +137,12 @@ enum {
        beyond (measured cross-over: ~29 M samples per batch on an exact kNN graph with hubs -- its under-filled time slices run as one
        launch each --, ~30 M on a lattice of uniform in-degree); both statistically faithful (as the reference's own threaded loop is
        not reproducible sample by sample either) -- the bit-exact replay of the reference's sequential loop is AE_CE_SEQUENTIAL,
-       by name.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
+       by name.  How faithful, measured (48 seeds a side on the stiffest graph of the suite -- 60 k points in 64 blobs, k = 6, 2-D,
+       40 batches; ratios to AE_CE_SEQUENTIAL's means, 2 SE = 0.005 / 0.009): AE_CE_ORDERED final cross entropy 1.000-1.007, median edge
+       length 0.987-1.003; AE_CE_SLICED with one launch per class 0.998 / 1.003; AE_CE_SLICED where its slices run MERGED or through the
+       optimistic passes (what AE_CE_AUTO runs from 2^25 samples per batch on up to a few 10^8, and on the ranks of a sharded run from
+       4 ranks on): cross entropy +0.7 %, median edge -1.5 % (-2.7 % on a 400 k-node graph of that kind at 8 seeds) -- a RESOLVED bias of
+       these two forms on stiff 2-D graphs, not visible at 8 columns (profiles/r05/r5_fidelity_means.txt).  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
        column adds +0 to every distance and never moves).  A sharded node range (several GPUs) runs AE_CE_SLICED whatever the
        batch size (see there; refused with AE_ERR_INVALID_ARG when more than 10 % of the range's edge mass crosses shards: the
        approximate AE_CE_HOGWILD still shards, by name).  ae_entropy_optim_get_ce_mode reports the choice. */
@@ -155,7 +161,8 @@ enum {
        communicator is attached).
        Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
        parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
-       standard error), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
+       standard error on graphs of 8 columns; on stiff 2-column graphs the merged-slice and optimistic forms sit at CE +0.7 %, median
+       edge -1.5 % against the exact mode at 48 seeds, one launch per class at -0.2 % / +0.3 %: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
        sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
        the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
        exchange. */

@@ -17,3 +17,16 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+@pytest.fixture(scope="session", autouse=True)
+def reference_summation_order():
+    """The stage-level entry points sum as f64 trees by default (ae_set_summation_order, round 6); the parity tests compare them bit for
+    bit with the oracle, which adds in the reference's sequential f32 order: ask for that order, for the whole session.  (Embedder.embed and
+    EntropyOptim choose by their CE mode whatever this says.)  No GPU needed: the call only sets a flag."""
+    try:
+        import annembed_amd as A
+        A.set_summation_order(False)
+    except Exception:  # the library is not built: the tests that need it say so themselves
+        pass
+    yield
