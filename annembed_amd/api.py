@@ -538,7 +538,9 @@ class SvdApprox:
     def __init__(self, data):
         self.data = data
 
-    def direct_svd(self, mode):
+    def direct_svd(self, mode, want_u=True, want_vt=True):
+        """-> SvdResult(s, u, vt).  want_u / want_vt False (RANK mode): that factor is not copied to the host -- None in the result; Vt is
+        then not computed at all (ae_svd_approx_rank with null pointers) -- for timing the device path on tall matrices."""
         m, n = self.data.shape
         if isinstance(mode, RangePrecision):  # RangeApproxMode::EPSIL
             cap = min(mode.max_rank, 64)
@@ -549,10 +551,10 @@ class SvdApprox:
             return SvdResult(s[:l].copy(), u[:m * l].reshape(m, l).copy(), vt[:l * n].reshape(l, n).copy())
         l = min(m, n, mode.rank)
         s = np.zeros(l, np.float32)
-        u = np.zeros((m, l), np.float32)
-        vt = np.zeros((l, n), np.float32)
+        u = np.zeros((m, l), np.float32) if want_u else None
+        vt = np.zeros((l, n), np.float32) if want_vt else None
         lo = C.c_uint64()
-        check(L.load().ae_svd_approx_rank(self.data.handle, mode.rank, mode.nbiter, ptr(s), ptr(u), ptr(vt), C.byref(lo)))
+        check(L.load().ae_svd_approx_rank(self.data.handle, mode.rank, mode.nbiter, ptr(s), ptr(u) if want_u else None, ptr(vt) if want_vt else None, C.byref(lo)))
         return SvdResult(s, u, vt)
 
 

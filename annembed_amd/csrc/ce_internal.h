@@ -135,6 +135,7 @@ struct ae_entropy_optim {
     // batch (a uniform random relabelling: what runs of consecutive rows hold has nothing to do with the caller's labels)
     DevBuf<uint32_t> sl_perm;
     DevBuf<float> sl_y;
+    uint32_t sl_y_lines = 0;                    // floats per node line whose static part (embedded scale, neighbour ids) sl_y currently holds; 0: none
     DevBuf<uint2> sl_hub_tab;                   // the NodeSampler's alias table in internal numbering
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)
     uint64_t sl_gen_edges = 0;                  // edges this handle generates events for (a shard: those with an end in its node range)

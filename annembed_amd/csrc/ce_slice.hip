@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     const uint32_t tk = pcg_hash(round_hash_key(key, c.seed) ^ kTagSlTime);
     const uint8_t cl = color[e];
     const EdgeRec er = erec[e];
-    const Event evv{er.im, er.j | (er.flags & kHalfEvent)};
+    const Event evv{er.im, er.j | (er.flags & kHalfEvent), er.w};
     constexpr uint32_t kSortMax = 24;
     __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge (dynamic indexing: LDS, not scratch)
     uint32_t* sl = s_sl + threadIdx.x;
@@ -382,6 +382,20 @@ __global__ void sl_static_rec_kernel(CeDev c, uint32_t srec, const uint32_t* __r
         r[1 + kp + m] = m < k ? c.proba[b + m] : 0.f;
     }
     for (uint32_t m = 1 + 2 * kp; m < srec; m++) r[m] = 0.f;
+}
+
+// node lines (ce_slice_kernels.h: LineRec): what is static about node i as a source -- embedded scale, neighbour ids in internal numbers,
+// padded with ~0 -- behind its row in the batch's internal copy of the coordinates (row perm[i], `line` floats per node)
+__global__ void sl_line_static_kernel(CeDev c, uint32_t line, const uint32_t* __restrict__ perm, float* __restrict__ lines) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    uint64_t b;
+    uint32_t k;
+    if (c.uniform_k) { b = i * c.uniform_k; k = c.uniform_k; }
+    else { b = c.indptr[i]; k = (uint32_t)(c.indptr[i + 1] - b); }
+    float* r = lines + (uint64_t)(perm ? perm[i] : (uint32_t)i) * line;
+    r[c.dim] = c.emb_scale[i];
+    for (uint32_t m = 0; c.dim + 1u + m < line; m++) r[c.dim + 1u + m] = __uint_as_float(m < k ? (perm ? perm[c.nbr[b + m]] : c.nbr[b + m]) : 0xFFFFFFFFu);
 }
 
 // internal numbering: keys for the random order, its inverse, and the row moves of a batch's start and end
@@ -518,9 +532,9 @@ __global__ void __launch_bounds__(256) sl_chain_unlink_kernel(SliceArgs a, uint3
 // batch's event count: whenever a batch set a new record the stream-ordered pool had to get a fresh block from the driver, 1.5-2 s,
 // a few times per run.  Found in round 3 as C4-shape batches of 300-900 ms among batches of 121 ms.)
 bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned end_bit) {
-    static_assert(sizeof(Event) == 8, "events are sorted as 64-bit values");
+    static_assert(sizeof(Event) == 12, "events are sorted as 12-byte values");
     rocprim::double_buffer<uint32_t> dk(keys_a, keys_b);
-    rocprim::double_buffer<unsigned long long> dv(reinterpret_cast<unsigned long long*>(vals_a), reinterpret_cast<unsigned long long*>(vals_b));
+    rocprim::double_buffer<Event> dv(vals_a, vals_b);
     size_t tmp_bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, 0, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
@@ -816,6 +830,25 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     o->sl_prepared = true;
 }
 
+// Floats of a node's line where a batch with one launch per class keeps rows and static records together (ce_slice_kernels.h: LineRec);
+// 0: this handle's steps read dense rows and the static records (rows of more than 16 columns, lines of more than 128 bytes, no
+// internal copy to keep them in).  Lines live in the relabelled internal copy of the coordinates: one device, or a sharded range whose
+// ranks' ranges are known.
+static uint32_t sl_node_line(const ae_entropy_optim* o) {
+    if (!o->sl_perm.n || debug_knob("AE_SL_NO_LINES")) return 0u;
+    return (uint32_t)node_line_floats((int)o->dev.dim, (int)o->g->max_nbng);
+}
+static void launch_step_line(uint32_t dim, const DirectArgs& da, uint32_t line, bool f64, bool tile, int* blocks_per_cu) {
+    switch (dim) {
+        case 2: launch_direct_line<2>(da, line, f64, tile, blocks_per_cu); break;
+        case 3: launch_direct_line<3>(da, line, f64, tile, blocks_per_cu); break;
+        case 4: launch_direct_line<4>(da, line, f64, tile, blocks_per_cu); break;
+        case 8: launch_direct_line<8>(da, line, f64, tile, blocks_per_cu); break;
+        case 16: launch_direct_line<16>(da, line, f64, tile, blocks_per_cu); break;
+        default: fail(AE_ERR_INVALID_ARG, "internal: no node lines for rows of %u columns", dim);
+    }
+}
+
 // events a step can hold with ALL its workgroups resident at once (the step kernel's occupancy x CUs x 256, less 3 %: the classes'
 // sizes and the Poisson totals scatter)
 static double sl_resident_events(ae_entropy_optim* o) {
@@ -826,7 +859,13 @@ static double sl_resident_events(ae_entropy_optim* o) {
     const bool sharded_range = o->dev.node_lo != 0 || o->dev.node_hi != o->dev.n;
     const bool tile_fit = !debug_knob("AE_SL_NO_TILE") && (!sharded_range || o->sl_perm.n != 0 || debug_knob("AE_SL_SHARD_TILE")) &&
                           (uint64_t)o->dev.n * o->dev.dim * 4ull > (4ull << 20);
-    AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
+    if (const uint32_t line = sl_node_line(o)) {   // (the instantiation a full step runs)
+        DirectArgs none{};
+        none.c = o->dev;
+        launch_step_line((uint32_t)o->dev.dim, none, line, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
+    } else {
+        AE_DISPATCH_DIM(o->dev.dim, direct_blocks_per_cu, o->sl_srec_floats, o->params.ce_precision != AE_PRECISION_F32, tile_fit, &bpc);
+    }
     return 0.97 * 256.0 * (double)bpc * (double)prop.multiProcessorCount;
 }
 
@@ -945,7 +984,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list
     if (o->sl_cnt.n < n_gen + 1) { o->sl_cnt.alloc(n_gen + 1); o->sl_offs.alloc(n_gen + 1); }
-    if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(2 * ev_cap); o->sl_vals1.alloc(2 * ev_cap); }
+    if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(3 * ev_cap); o->sl_vals1.alloc(3 * ev_cap); }   // (Event: three words)
     if (o->sl_sptr.n < n_keys + 2) o->sl_sptr.alloc(n_keys + 2);
     if (has_overflow && o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4);
     if ((uint64_t)kSub * cap >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: pending lists beyond 2^32 entries");
@@ -970,7 +1009,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // bytes apart instead of 8 ... 32): a word comes with the line of the row the event reads anyway and is wiped into the line it
     // writes anyway -- four of a merged event's six extra requests.
     const bool words_in_rows = merged && o->dev.dim <= 8 && !debug_knob("AE_SL_DEP_ARRAY");
-    const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (uint32_t)o->dev.dim;
+    // One launch per class (full steps, bound by the number of requests that miss the L2): NODE LINES -- the internal copy keeps a node's
+    // embedded scale and neighbour ids behind its row, the step kernel fetches a source's line as ONE request (ce_slice_kernels.h: LineRec)
+    const uint32_t line = (classes && !merged) ? sl_node_line(o) : 0u;
+    const bool strided = words_in_rows || line != 0u;   // the internal copy's rows are further apart than the caller's
+    const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (line ? line : (uint32_t)o->dev.dim);
     // (floats from the start of a node's line: rows of 8 columns sit in the middle of their line, a set of words on either side --
     // ce_slice_kernels.h: LineFetch --; shorter rows at its start, the two sets behind them)
     const bool lines = words_in_rows && (o->dev.dim == 8 || o->dev.dim == 2);
@@ -981,7 +1024,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     CeDev cdev = o->dev;
     cdev.ystride = ystride;
     const bool relabelled = o->sl_perm.n != 0;
-    const bool own_copy = relabelled || words_in_rows;
+    const bool own_copy = relabelled || strided;
     const uint32_t* perm = relabelled ? (const uint32_t*)o->sl_perm.p : nullptr;
     auto move_rows = [&](uint64_t v_lo, uint64_t v_hi, uint64_t skip_lo, uint64_t skip_hi, const float* src, float* dst, int to_internal) {
         if (v_hi <= v_lo) return;
@@ -989,8 +1032,13 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                            (uint32_t)o->dev.dim, ystride, perm, src, dst, to_internal);
     };
     if (own_copy) {
-        if (o->sl_y.n < n * ystride) o->sl_y.alloc(n * ystride);
+        if (o->sl_y.n < n * ystride) { o->sl_y.alloc(n * ystride); o->sl_y_lines = 0; }
         if (words_in_rows) o->sl_y.zero();
+        if (line && o->sl_y_lines != line) {   // the static part of the lines: once per handle (unless a batch of another layout came between)
+            hipLaunchKernelGGL(sl_line_static_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream(), o->dev, line, perm, o->sl_y.p);
+            check_launch("sl_line_static");
+        }
+        o->sl_y_lines = line;
         move_rows(0, n, 0, 0, (const float*)o->dev.y, o->sl_y.p + row_at, 1);
         cdev.y = o->sl_y.p + row_at;
         if (relabelled && o->dev.hub_odds) cdev.hub_tab = o->sl_hub_tab.p;
@@ -1001,7 +1049,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ae_entropy_optim* o;
         CommY(ae_entropy_optim* oo, float* y) : o(oo) { o->comm_y = y; }
         ~CommY() { o->comm_y = nullptr; }
-    } comm_y_scope(o, (own_copy && !words_in_rows) ? o->sl_y.p : nullptr);
+    } comm_y_scope(o, (own_copy && !strided) ? o->sl_y.p : nullptr);
     SliceArgs a;
     a.c = cdev;
     a.srec = o->sl_srec.p;
@@ -1073,9 +1121,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const uint32_t exchanges = o->comm ? std::max(1u, std::min(o->comm_exchanges, n_slices)) : 0u;
     uint64_t exchanges_done = 0;
     auto exchange_now = [&] {
-        if (words_in_rows && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
+        if (strided && o->comm) move_rows(o->dev.node_lo, o->dev.node_hi, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // (perm null or a relabelling inside the range: the rows land in the rank's run)
         ce_comm_exchange(o);
-        if (words_in_rows && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p + row_at, 1);
+        if (strided && o->comm) move_rows(0, n, o->dev.node_lo, o->dev.node_hi, (const float*)o->dev.y, o->sl_y.p + row_at, 1);
         exchanges_done++;
     };
     auto exchange_after = [&](uint32_t s) {
@@ -1207,7 +1255,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 da.ept = ept_force ? ept_force : std::min(4u, std::max(1u, cnt / (256u * 3072u)));
                 da.tile = (use_tile && !y_in_cache && cnt >= tile_min_events) ? 1 : 0;
                 da.step_seq = step_seq++;
-                AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
+                if (line) launch_step_line((uint32_t)o->dev.dim, da, line, f64, da.tile != 0, nullptr);
+                else AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
             }
             if (!has_overflow || (ov_every > 1u && s != std::min(n_slices - 1u, s - s % ov_every + ov_every / 2u))) { exchange_after(s); continue; }
             a.f0 = sp[classes];

@@ -32,11 +32,14 @@ constexpr uint32_t kNodeMask = 0x07FFFFFFu;
 constexpr uint32_t kHalfEvent = 0x80000000u;
 __host__ __device__ __forceinline__ uint32_t ev_node(uint32_t j) { return j & kNodeMask; }
 __host__ __device__ __forceinline__ bool ev_half(uint32_t j) { return (j & kHalfEvent) != 0u; }
-// An event in the sorted arrays: 8 bytes {source << 5 | slot of the edge in the source's row, target} -- the rows of both end
-// points and the source's static record are requested in ONE hop after the (coalesced) event load.  The events of a step are sorted
-// by target: those that share one are adjacent and run as a chain through the target's row (sl_step_body).
+// An event in the sorted arrays: 12 bytes {source << 5 | slot of the edge in the source's row, target, the edge's probability} -- the
+// rows of both end points and what is static about the source are requested in ONE hop after the (coalesced) event load.  The events
+// of a step are sorted by target: those that share one are adjacent and run as a chain through the target's row (sl_step_body).
+// (w rides in the event since round 6: with it a source's embedded scale and neighbour ids fit into the 64-byte LINE of its row --
+// NodeLine below -- and the source costs one request where record and row were two.)
 struct Event {
     uint32_t im, j;   // j: target, kHalfEvent in bit 31
+    float w;          // probability of the edge (embedder.rs:1184)
 };
 struct Pending {       // a pending event of the overflow class: 16 bytes, read and written coalesced
     uint32_t idx, im, j, pad;
@@ -71,7 +74,7 @@ struct DirectArgs {
     uint32_t key;               // (batch << 12) | segment
     uint32_t step_seq;          // running step number of the batch (RNG key of the tile windows)
     int tile;
-    int dbg;                    // debug knob AE_SL_DBG (measurement only): 1 no arithmetic, 2 no stores, 4 no negatives, 8 no static record
+    int dbg;                    // debug knob AE_SL_DBG (measurement only): 1 no arithmetic, 2 no stores, 4 no negatives, 8 no static record; 64: merged slices read their negatives late (see there)
     double step;
     unsigned long long* done_counter;   // [1024] spread counters of executed samples; [1024] = error flags (1: pending list overflow, 2: hand-over poll budget)
     uint32_t* chunk_flag;       // hand-over of a target's row between the 64-event chunks of a step: [chunk] = step token once the chunk's tail is through
@@ -293,6 +296,34 @@ struct RecFetch {
             w = p[1 + KP + (want ? m : 0u)];
             wave_lds_sync();
         }
+    }
+};
+
+// A node's LINE in a batch that runs one launch per class (ce_slice_gradient_iteration: `node_lines`): the batch's internal copy of the
+// coordinates keeps, behind every row, what is static about the node as a SOURCE -- LINE floats = {the row, DIM | embedded scale |
+// neighbour ids, LINE - DIM - 1 of them, padded with ~0} -- so that a source costs ONE request (a group of LINE / 4 lanes) where the
+// static record and the row were two, and half the bytes (configs[3]: 8 columns, 6 neighbours: 15 floats in a 64-byte line against a
+// 64-byte record + a 32-byte row out of another line).  The sampled edge's probability comes with the event.  A target's row and the
+// rows of the tile of negatives are the first DIM floats of their nodes' lines (CeDev::ystride = LINE), the stores go there too.  The
+// step kernel is bound by the NUMBER of requests that miss the L2 (tools/ubench_rowgather.hip): six per event became five.
+constexpr int node_line_floats(int dim, int max_nbng) {   // 0: no line form for this shape (the static record stays)
+    const int need = dim + 1 + max_nbng;
+    return dim > 16 ? 0 : (need <= 8 ? 8 : (need <= 16 ? 16 : (need <= 32 ? 32 : 0)));
+}
+template <int DIM, int LINE>
+struct LineRec {
+    static constexpr int KP = LINE - DIM - 1;
+    f4 pc[LINE / 4];
+    __device__ __forceinline__ void issue(const float* __restrict__ y, uint32_t node, bool want) { coop_issue<LINE>(y, node, want, pc, (uint32_t)LINE); }
+    __device__ __forceinline__ void land(float* stage, float* yi, float& scale, uint32_t (&nbr_reg)[KP]) {
+        coop_land<LINE>(pc, stage);
+        const float* p = stage + (threadIdx.x & 63) * (LINE + 4);
+#pragma unroll
+        for (int q = 0; q < DIM; q++) yi[q] = p[q];
+        scale = p[DIM];
+#pragma unroll
+        for (int q = 0; q < KP; q++) nbr_reg[q] = __float_as_uint(p[DIM + 1 + q]);
+        wave_lds_sync();
     }
 };
 
@@ -596,9 +627,11 @@ __device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint
 }
 
 // the events [a.begin, a.end) of one step, workgroup `block` of the step's grid (256 x a.ept events per workgroup)
-template <int DIM, int SREC, bool F64, bool TILE>
+// LINE > 0: the source's row, embedded scale and neighbour ids come as ONE line of LINE floats (NodeLine above; SREC == LINE then: it only
+// sizes the stage), the edge's probability from the event
+template <int DIM, int SREC, bool F64, bool TILE, int LINE = 0>
 __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block, StepShared<DIM, SREC, F64, TILE>& sh, uint32_t& done) {
-    constexpr int KREG = (SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32;
+    constexpr int KREG = LINE > 0 ? LINE - DIM - 1 : ((SREC - 1) / 2 < 32 ? (SREC - 1) / 2 : 32);
     const CeDev c = a.c;
     const bool hub = c.hub_odds != nullptr;
     float* stage = sh.stage + (threadIdx.x >> 6) * kStageFloats<DIM, SREC>;
@@ -642,17 +675,28 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         uint32_t nbr_reg[KREG];
         // hop 2: the source's record and both rows are requested together, then handed to their lanes (a target's row only by the
         // lane that starts its chain; a chain continued from the previous chunk receives it through memory below)
-        RecFetch<SREC, KREG> fr;
-        RowFetch<DIM> fi, fj;
-        const bool want_rec = cmp && !(a.dbg & 8);
-        fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
-        fi.issue(c.y, i, cmp, yi, c.ystride);             // :1185
-        fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);   // :1186
-        if constexpr (TILE && FIRST) ft.land(sh.tile, sh.tnode);
-        fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
-        fi.land(stage, yi);
-        fj.land(stage, yj);
-        if (a.dbg & 8) { for (int q = 0; q < KREG; q++) nbr_reg[q] = 0xFFFFFFFFu; w = 0.5f; scale_f = 1.f; }
+        RowFetch<DIM> fj;
+        if constexpr (LINE > 0) {
+            LineRec<DIM, LINE> fl;
+            fl.issue(c.y, i, cmp);                            // :1185, and what RecFetch brings
+            fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);   // :1186
+            if constexpr (TILE && FIRST) ft.land(sh.tile, sh.tnode);
+            fl.land(stage, yi, scale_f, nbr_reg);
+            fj.land(stage, yj);
+            w = e.w;
+        } else {
+            RecFetch<SREC, KREG> fr;
+            RowFetch<DIM> fi;
+            const bool want_rec = cmp && !(a.dbg & 8);
+            fr.issue(a.srec, i, e.im & 31u, want_rec, scale_f, w, nbr_reg);
+            fi.issue(c.y, i, cmp, yi, c.ystride);             // :1185
+            fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);   // :1186
+            if constexpr (TILE && FIRST) ft.land(sh.tile, sh.tnode);
+            fr.land(stage, e.im & 31u, want_rec, scale_f, w, nbr_reg);
+            fi.land(stage, yi);
+            fj.land(stage, yj);
+            if (a.dbg & 8) { for (int q = 0; q < KREG; q++) nbr_reg[q] = 0xFFFFFFFFu; w = 0.5f; scale_f = 1.f; }
+        }
         const uint32_t chunk = (a.begin >> 6) + ((p - a.begin) >> 6);
         // the sample's last repetition (its only one unless the edge repeats inside the step): negatives drawn and their rows requested
         // now; its attraction runs in the lane's turn, its repulsions -- they move y_i only -- after the turns, all lanes side by side
@@ -719,11 +763,11 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
 
 // (rows of <= 8 columns with f64 scalars and the LDS tile -- the big-graph path --: three waves per SIMD -- 168 VGPRs -- are worth a spill or two; the one-division arithmetic
 // sits at 171 without the bound, and a resident step of 190 k events instead of 127 k is what the slice count is sized by)
-template <int DIM, int SREC, bool F64, bool TILE>
+template <int DIM, int SREC, bool F64, bool TILE, int LINE = 0>
 __global__ void __launch_bounds__(256, (F64 && TILE && DIM <= 8) ? 3 : 1) sl_direct_kernel(DirectArgs a) {
     __shared__ StepShared<DIM, SREC, F64, TILE> sh;
     uint32_t done = 0;
-    sl_step_body<DIM, SREC, F64, TILE>(a, blockIdx.x, sh, done);
+    sl_step_body<DIM, SREC, F64, TILE, LINE>(a, blockIdx.x, sh, done);
     for (int off = 32; off > 0; off >>= 1) done += __shfl_xor(done, off);
     if ((threadIdx.x & 63) == 0 && done) atomicAdd(&a.done_counter[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 1023u], (unsigned long long)done);
 }
@@ -926,6 +970,14 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
         if (!moving && __ballot(phase == 1u)) {
             const bool fin = phase == 1u;
             if (fin && store_i) {
+                if constexpr (SplitSample<DIM, F64, TILE>::kAhead) {
+                    // AE_SL_DBG bit 64 (an experiment on the form's bias, tools/run_blobs_forms.py): the negatives' rows are read NOW, past the
+                    // caches (agent scope: what the other workgroups of this launch have written through), instead of before the first poll
+                    if (a.dbg & 64) {
+#pragma unroll
+                        for (int g = 0; g < 5; g++) load_row_agent<DIM>(c.y, neg[g], sm.nrow[g], c.ystride);
+                    }
+                }
                 sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
                 done += rep;
             }
@@ -1203,8 +1255,48 @@ void launch_direct(const DirectArgs& a, uint32_t srec, bool f64) {
     else { if (tile) launch_direct3<DIM, false, true>(a, srec); else launch_direct3<DIM, false, false>(a, srec); }
 }
 
-// The launchers are instantiated one row stride per translation unit (ce_slice_dim*.hip define AE_SL_INSTANTIATE_DIM); everybody else
-// only sees the declarations.
+// the step kernel on node lines (LineRec): LINE in {8, 16, 32} floats, longer than the row and its scale
+template <int DIM, int LINE, bool F64, bool TILE>
+void launch_direct_line4(const DirectArgs& a, int* blocks_per_cu) {
+    if constexpr (DIM <= 16 && LINE > DIM + 1) {
+        if (blocks_per_cu) {   // occupancy query (sl_resident_events), no launch
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sl_direct_kernel<DIM, LINE, F64, TILE, LINE>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+            *blocks_per_cu = nb;
+            return;
+        }
+        const unsigned grid = (a.end - a.begin + 256u * a.ept - 1u) / (256u * a.ept);
+        hipLaunchKernelGGL((sl_direct_kernel<DIM, LINE, F64, TILE, LINE>), dim3(grid), dim3(256), 0, stream(), a);
+    } else {
+        fail(AE_ERR_INVALID_ARG, "internal: no node-line step kernel for rows of %d columns in lines of %d floats", DIM, LINE);
+    }
+}
+template <int DIM, bool F64, bool TILE>
+void launch_direct_line3(const DirectArgs& a, uint32_t line, int* blocks_per_cu) {
+    if (line == 8) launch_direct_line4<DIM, 8, F64, TILE>(a, blocks_per_cu);
+    else if (line == 16) launch_direct_line4<DIM, 16, F64, TILE>(a, blocks_per_cu);
+    else launch_direct_line4<DIM, 32, F64, TILE>(a, blocks_per_cu);
+}
+// blocks_per_cu non-null: only the occupancy of the instantiation that `tile` / `f64` / `line` select is reported
+template <int DIM>
+void launch_direct_line(const DirectArgs& a, uint32_t line, bool f64, bool tile_wanted, int* blocks_per_cu) {
+    const bool tile = tile_wanted && a.c.n > (uint64_t)TileShape<DIM>::kRows * 4ull;
+    if (f64) { if (tile) launch_direct_line3<DIM, true, true>(a, line, blocks_per_cu); else launch_direct_line3<DIM, true, false>(a, line, blocks_per_cu); }
+    else { if (tile) launch_direct_line3<DIM, false, true>(a, line, blocks_per_cu); else launch_direct_line3<DIM, false, false>(a, line, blocks_per_cu); }
+}
+#define AE_SL_LINE_LAUNCHERS(PREFIX, D) PREFIX template void launch_direct_line<D>(const DirectArgs&, uint32_t, bool, bool, int*);
+#ifdef AE_SL_INSTANTIATE_LINE_DIM
+AE_SL_LINE_LAUNCHERS(, AE_SL_INSTANTIATE_LINE_DIM)
+#else
+AE_SL_LINE_LAUNCHERS(extern, 2)
+AE_SL_LINE_LAUNCHERS(extern, 3)
+AE_SL_LINE_LAUNCHERS(extern, 4)
+AE_SL_LINE_LAUNCHERS(extern, 8)
+AE_SL_LINE_LAUNCHERS(extern, 16)
+#endif
+
+// The launchers are instantiated one row stride per translation unit (ce_slice_dim*.hip define AE_SL_INSTANTIATE_DIM; the node-line
+// step kernels in units of their own, ce_slice_line_dim*.hip: AE_SL_INSTANTIATE_LINE_DIM); everybody else only sees the declarations.
 #define AE_SL_LAUNCHERS(PREFIX, D)                                                                                                        \
     PREFIX template void launch_direct<D>(const DirectArgs&, uint32_t, bool);                                                             \
     PREFIX template void direct_blocks_per_cu<D>(uint32_t, bool, bool, int*);                                                             \

@@ -223,6 +223,39 @@ def full_schedule(A, kg, node_params, y0, d, mode, nb_batch=25):
     return y, ce
 
 
+def dense_svd_flops(m, n, l=20, nbiter=5):
+    """SURVEY 8d, dense path (subspace_iteration_full + direct_svd, svdapprox.rs:285-333, 721-799)"""
+    return (2 * nbiter - 1) * 2 * m * n * l + nbiter * 4 * m * l * l + (nbiter - 1) * 4 * n * l * l + 2 * m * n * l
+
+
+def svd_dense_shape(A, L, m, n=128, reps=3):
+    """The dense range finder where SURVEY 8d puts it: `direct_svd` (RangeRank(20, 5)) of an m x 128 f32 block of configs[4]'s data matrix
+    (6.25 M rows = one GPU's eighth, 3.2 GB; 50 M rows = the whole matrix, 25.6 GB), the matrix resident in HBM, U left there (as the
+    embedder's own call leaves it), the spectrum back on the host.  ms, TFLOP/s by the SURVEY formula, fraction of the f32 MFMA peak and of
+    HBM by algorithmic bytes (4 m n per product, ten products)."""
+    import torch
+    x, _ = mixture_points_gpu(m, n, max(1, m // 50_000), seed=4, mean_sigma=10.0)
+    t0 = time.perf_counter()
+    mat = A.MatRepr.from_array2(x)
+    L.check(L.load().ae_synchronize())
+    upload_s = time.perf_counter() - t0
+    del x
+    svd, mode = A.SvdApprox(mat), A.RangeRank(20, 5)
+    svd.direct_svd(mode, want_u=False, want_vt=False)  # warm
+    L.check(L.load().ae_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = svd.direct_svd(mode, want_u=False, want_vt=False)
+    dt = (time.perf_counter() - t0) / reps
+    fl, by = dense_svd_flops(m, n), 10 * 4.0 * m * n
+    out = {"shape": "%dx%d rank 20 nbiter 5" % (m, n), "ms": dt * 1e3, "tflops": fl / dt / 1e12, "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
+           "hbm_gbps": by / dt / 1e9, "hbm_frac": by / dt / 8e12, "sigma0": float(res.s[0]), "sigma19": float(res.s[-1]), "upload_s": upload_s,
+           "ceiling_note": "a product moves 4 m n bytes for 2 m n l flops: 10 flop/B at l = 20, i.e. the HBM roof allows 80 TFLOP/s = 0.51 of the f32 MFMA peak"}
+    del svd, mat
+    torch.cuda.empty_cache()
+    return out
+
+
 def higgs_shaped_points(n, dim=28, ncomp=64, seed=2, with_labels=False):
     """configs[2] stand-in: mixture of 64 Gaussians in 28-D with per-column standardisation (examples/higgs.rs:158-176)"""
     rng = np.random.default_rng(seed)
@@ -505,7 +538,7 @@ def compact_line(full):
     if pm:
         out["parity_mode"] = {"ce_mode": "AE_CE_SEQUENTIAL (bit-exact vs the oracle)", "ms_per_step": pm["ms_per_step"], "points_per_s": pm["points_per_s"],
                               "frac": pm["roofline"]["frac"]}
-    for k in ("svd_init", "svd_init_c4", "svd_dense"):
+    for k in ("svd_init", "svd_init_c4", "svd_dense", "svd_dense_c5", "svd_dense_c5_full"):
         if full.get(k):
             out[k] = {kk: vv for kk, vv in full[k].items() if not isinstance(vv, (dict, list)) and not (isinstance(vv, str) and len(vv) > 80)}
     shapes = full.get("scale_shapes") or {}
@@ -522,7 +555,7 @@ def compact_line(full):
             out[k] = _short(full[k], 120)
     line = json.dumps(out)
     if len(line) >= FINAL_LINE_MAX:   # never: but a parseable short line beats a complete long one
-        for k in ("scale_shapes", "svd_dense", "svd_init_c4", "svd_init", "faithful"):
+        for k in ("scale_shapes", "svd_dense_c5_full", "svd_dense", "svd_dense_c5", "svd_init_c4", "svd_init", "faithful"):
             out.pop(k, None)
             line = json.dumps(out)
             if len(line) < FINAL_LINE_MAX:
@@ -677,14 +710,14 @@ def main():
         # direct_svd, rank 20, 5 iterations -- the MFMA tall-skinny products
         if not args.no_dense_svd:
             mat = A.MatRepr.from_array2(x.cpu().numpy())
-            A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))  # warm
+            A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5), want_u=False, want_vt=False)  # warm
             L.check(L.load().ae_synchronize())
             t0 = time.perf_counter()
-            for _ in range(3):
-                A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5))
-            dt = (time.perf_counter() - t0) / 3
+            for _ in range(5):   # (U stays in HBM, as in the embedder's own call; the spectrum comes back)
+                A.SvdApprox(mat).direct_svd(A.RangeRank(20, 5), want_u=False, want_vt=False)
+            dt = (time.perf_counter() - t0) / 5
             m_, n_, l_ = n, args.dim, 20
-            fl = 9 * 2 * m_ * n_ * l_ + 5 * 4 * m_ * l_ * l_ + 4 * 4 * n_ * l_ * l_ + 2 * m_ * n_ * l_  # SURVEY 8d, dense path
+            fl = dense_svd_flops(m_, n_, l_)  # SURVEY 8d, dense path
             svd_dense = {"shape": "%dx%d rank 20 nbiter 5" % (m_, n_), "ms": dt * 1e3, "tflops": fl / dt / 1e12,
                          "mfma_f32_peak_tflops": 157.3, "mfma_frac": fl / dt / 1e12 / 157.3,
                          "hbm_gbps": 10 * 4.0 * m_ * n_ / dt / 1e9}
@@ -795,6 +828,12 @@ def main():
         }
         if not args.no_full_size:   # configs[4] whole: 50 M points of the 128-D mixture, 5 G samples per batch, on this one GPU (~1 min, mostly the graph)
             scale_shapes["c5_full_shape"] = full_size_shape(A, L, "c5_full", 16, 2)
+    # configs[4]'s "MFMA SVD" leg: the dense range finder on the 128-column data matrix itself, a rank's share and the whole
+    svd_dense_c5 = svd_dense_c5_full = None
+    if not args.no_dense_svd and not args.lattice_graph and not args.no_scale_shapes:
+        svd_dense_c5 = svd_dense_shape(A, L, 6_250_000)
+        if not args.no_full_size:
+            svd_dense_c5_full = svd_dense_shape(A, L, 50_000_000, reps=2)
 
     roof = roofline_of(head, k, d)
     if head["mode"] in (1, 6):
@@ -838,6 +877,8 @@ def main():
         "svd_init": {"gflops": svd_flops(n, nnz_a) / svd_s / 1e9, "ms": svd_s * 1e3, "nnz_laplacian": int(nnz_a), "rank": 20, "nbiter": 5},
         "svd_init_c4": ((scale_shapes or {}).get("c4_knn_shape") or {}).get("svd_init") or ((scale_shapes or {}).get("c4_shape") or {}).get("svd_init"),
         "svd_dense": svd_dense,
+        "svd_dense_c5": svd_dense_c5,
+        "svd_dense_c5_full": svd_dense_c5_full,
         "knn_producer": knn_producer,
         "samples_per_s": head["nb_sample"] / (head["ms_per_step"] * 1e-3),
         "ce_before": head["ce_before"], "ce_after": head["ce_after"],
