@@ -1144,6 +1144,13 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (o->sl_dep.n < 2 * n) o->sl_dep.alloc(2 * n);
         o->sl_dep.zero();
     }
+    const int chains_dbg = (!merged && debug_knob("AE_SL_CHAINS_DBG")) ? std::min(8, atoi(debug_knob("AE_SL_CHAINS_DBG"))) : 0;
+    static hipStream_t dbg_streams[8] = {};
+    static hipEvent_t dbg_ev = nullptr;
+    if (chains_dbg > 1 && !dbg_ev) {
+        AE_HIP(hipEventCreateWithFlags(&dbg_ev, hipEventDisableTiming));
+        for (int pc = 0; pc < 8; pc++) AE_HIP(hipStreamCreateWithFlags(&dbg_streams[pc], hipStreamNonBlocking));
+    }
     bool premarked = false;   // the slice about to run had its words filled by the slice before it
     uint32_t step_seq_base = 0;
     auto slice_args = [&](uint32_t s) {
@@ -1227,6 +1234,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             step_seq_base = step_seq;
             step_seq += n_slices * classes;
         }
+        if (chains_dbg > 1) {   // fork: the side streams start behind the event generation
+            AE_HIP(hipEventRecord(dbg_ev, stream()));
+            for (int pc = 0; pc < chains_dbg; pc++) AE_HIP(hipStreamWaitEvent(dbg_streams[pc], dbg_ev, 0));
+        }
         for (uint32_t s = 0; s < n_slices; s++) {
             const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
             if (merged) {
@@ -1244,6 +1255,24 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                     if (premarked) ra.next_sptr = ra.sptr + (classes + 1u);
                     const bool tile_run = use_tile && !y_in_cache && (uint64_t)(sp[classes] - sp[0]) >= tile_min_events;   // (a workgroup's tile serves its 256 events whatever their class)
                     AE_DISPATCH_DIM(o->dev.dim, launch_slice, ra, grid, o->sl_srec_floats, f64, tile_run);
+                }
+            } else if (chains_dbg > 1) {
+                // TIMING EXPERIMENT (AE_SL_CHAINS_DBG = P, wrong results): every step cut into P launches on P streams that are never joined
+                // inside the batch -- what P desynchronised chains of steps would cost if the graph fell into P independent parts
+                for (uint32_t q = 0; q < classes; q++) {
+                    if (sp[q + 1] == sp[q]) continue;
+                    const uint32_t b0 = sp[q], cnt = sp[q + 1] - sp[q];
+                    da.step_seq = step_seq++;
+                    for (int pc = 0; pc < chains_dbg; pc++) {
+                        da.begin = b0 + (uint32_t)(((uint64_t)cnt * pc / chains_dbg) & ~63ull);
+                        da.end = pc + 1 == chains_dbg ? b0 + cnt : b0 + (uint32_t)(((uint64_t)cnt * (pc + 1) / chains_dbg) & ~63ull);
+                        if (da.end <= da.begin) continue;
+                        da.ept = 1;
+                        da.tile = (use_tile && !y_in_cache && da.end - da.begin >= tile_min_events) ? 1 : 0;
+                        StreamScope sc(dbg_streams[pc]);
+                        if (line) launch_step_line((uint32_t)o->dev.dim, da, line, f64, da.tile != 0, nullptr);
+                        else AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
+                    }
                 }
             } else
             for (uint32_t q = 0; q < classes; q++) {  // the slice's matchings, in this slice's order
@@ -1319,6 +1348,12 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             // the next slice's mark kernel marks in owner[0]; the last pass above marked in owner[(passes + extra) & 1]: the mark
             // kernel re-marks everything that is pending anyway
             exchange_after(s);
+        }
+        if (chains_dbg > 1) {   // join
+            for (int pc = 0; pc < chains_dbg; pc++) {
+                AE_HIP(hipEventRecord(dbg_ev, dbg_streams[pc]));
+                AE_HIP(hipStreamWaitEvent(stream(), dbg_ev, 0));
+            }
         }
         const double t_enq = wall();
         t_enqueue += t_enq - t_ev;

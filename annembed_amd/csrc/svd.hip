@@ -1412,6 +1412,91 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
     }
 }
 
+// x <- x R^-1 for one row held in registers (R upper triangular in LDS, read by broadcast; rinv = 1 / diag): forward substitution
+template <int LT>
+__device__ __forceinline__ void row_solve_upper(double (&xr)[LT], const double* R, const double* rinv, uint32_t l) {
+#pragma unroll
+    for (int c = 0; c < LT; c++) {
+        if ((uint32_t)c < l) {  // uniform
+            double a0 = xr[c], a1 = 0.;
+#pragma unroll
+            for (int k = 0; k < c; k++) {
+                if (k & 1) a1 -= xr[k] * R[k * l + c]; else a0 -= xr[k] * R[k * l + c];
+            }
+            xr[c] = (a0 + a1) * rinv[c];
+        }
+    }
+}
+// The SMALL side of a tall dense matrix's range iteration in ONE single-workgroup launch (n x l floats in LDS, l <= 32).  The tall panel
+// Y (m x l) is never orthonormalised explicitly: its Q = Y R^-1 (R^T R = g_tall, the f64 Gram of Y) enters the next product only through
+// Z = A^T Q = (A^T Y) R^-1 -- an n x l matrix.  So this kernel (1) factorises g_tall, (2) Z <- Z R^-1, and unless `apply_only` (3) QR of Z
+// itself: Gram in f64, Cholesky, Z <- Z R2^-1 -- what used to be a chol_apply over the m rows of Y (read + write of the tall panel), a
+// Gram launch and a chol_apply launch on Z.  g_zero: the Gram accumulator the NEXT tall panel adds into.  A pivot that is not safely
+// positive raises the sticky flag and leaves Z as it is (the caller redoes the iteration through the explicit route).
+__global__ void __launch_bounds__(512) small_panel_qr_kernel(float* __restrict__ z, uint32_t n, uint32_t l, const double* __restrict__ g_tall, double rel_tol,
+                                                              int* __restrict__ flag, double* __restrict__ g_zero, int apply_only) {
+    extern __shared__ double smem[];   // R[l * l] | rinv[l] | G2[l * l] | Zs[n * ls] (f32, ls = l | 1: odd row stride, conflict-free rows)
+    double* R = smem;
+    double* rinv = smem + (size_t)l * l;
+    double* G2 = rinv + l;
+    float* Zs = reinterpret_cast<float*>(G2 + (size_t)l * l);
+    __shared__ int s_bad;
+    const uint32_t tid = threadIdx.x, ls = l | 1u;
+    if (tid == 0) s_bad = 0;
+    for (uint32_t idx = tid; idx < l * l; idx += 512) { R[idx] = g_tall[idx]; if (g_zero) g_zero[idx] = 0.; }
+    for (uint32_t idx = tid; idx < n * l; idx += 512) Zs[(idx / l) * ls + idx % l] = z[idx];
+    __syncthreads();
+    auto factorise = [&](double* M) {   // wave 0: M (l x l, LDS) -> its upper Cholesky factor in place, rinv
+        if (tid < 64) {
+            double col[32];
+            const bool okc = chol_wave_registers<32>(M, l, rel_tol, (int)tid, col, rinv);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (!okc) { if (tid == 0) s_bad = 1; }
+            else if (tid < l) {
+#pragma unroll
+                for (int k = 0; k < 32; k++)
+                    if ((uint32_t)k < l) M[k * l + tid] = col[k];
+            }
+        }
+        __syncthreads();
+    };
+    auto solve_rows = [&](const double* M) {   // Zs <- Zs M^-1, one thread per row, the row in f64 registers
+        for (uint32_t r = tid; r < n; r += 512) {
+            double xr[32];
+            float* x = Zs + (size_t)r * ls;
+#pragma unroll
+            for (int c = 0; c < 32; c++) xr[c] = (uint32_t)c < l ? (double)x[c] : 0.;
+            row_solve_upper<32>(xr, M, rinv, l);
+#pragma unroll
+            for (int c = 0; c < 32; c++)
+                if ((uint32_t)c < l) x[c] = (float)xr[c];
+        }
+        __syncthreads();
+    };
+    factorise(R);
+    if (s_bad) { if (tid == 0) atomicOr(flag, 1); return; }
+    solve_rows(R);
+    if (!apply_only) {
+        // Gram of the (f32-rounded) rows in f64: entry (a, b) by one thread, two accumulators
+        for (uint32_t e = tid; e < l * l; e += 512) {
+            const uint32_t a = e / l, b = e % l;
+            double s0 = 0., s1 = 0.;
+            uint32_t r = 0;
+            for (; r + 2 <= n; r += 2) {
+                s0 += (double)Zs[(size_t)r * ls + a] * (double)Zs[(size_t)r * ls + b];
+                s1 += (double)Zs[(size_t)(r + 1) * ls + a] * (double)Zs[(size_t)(r + 1) * ls + b];
+            }
+            if (r < n) s0 += (double)Zs[(size_t)r * ls + a] * (double)Zs[(size_t)r * ls + b];
+            G2[e] = s0 + s1;
+        }
+        __syncthreads();
+        factorise(G2);
+        if (s_bad) { if (tid == 0) atomicOr(flag, 1); return; }
+        solve_rows(G2);
+    }
+    for (uint32_t idx = tid; idx < n * l; idx += 512) z[idx] = Zs[(idx / l) * ls + idx % l];
+}
+
 // optimistic orthonormalisation state: two Gram accumulators used alternately (the update kernel of call k clears
 // the accumulator of call k + 1) and the sticky failure flag
 struct FastOrth {
@@ -1491,8 +1576,33 @@ void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work)
     }
 }
 
-// subspace_iteration_full / _csr, svdapprox.rs:285-408.  d_q: m x l panel (output, orthonormal columns)
-static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, DevBuf<float>& q) {
+// A tall dense matrix (m >= n, the n x l panel fits one workgroup's LDS): the tall panel is kept UN-normalised with the f64 Gram that
+// defines its QR -- Q = Y R^-1, R^T R = g -- and the R^-1 is applied on the small side (small_panel_qr_kernel).  Per iteration: product,
+// Gram, transposed product (+ its reduction), one small launch -- instead of product, Gram, chol_apply over m rows, transposed
+// product, reduction, Gram, chol_apply; the tall panel is written once and read twice per iteration instead of written twice and read
+// four times.
+struct TallFactor {
+    bool deferred = false;   // q holds Y, not Q
+    const double* g = nullptr;
+};
+static size_t small_panel_lds(uint64_t n, uint32_t l) { return sizeof(double) * (2 * (size_t)l * l + l) + sizeof(float) * (size_t)n * (l | 1u); }
+static bool dense_deferred_ok(const ae_matrepr& a, uint32_t l) {
+    return !a.is_csr && a.nrows >= a.ncols && l <= 32 && small_panel_lds(a.ncols, l) <= 150 * 1024 && !debug_knob("AE_SVD_NO_DEFER");
+}
+static void launch_small_panel_qr(float* z, uint64_t n, uint32_t l, const double* g_tall, int* flag, double* g_zero, bool apply_only) {
+    const size_t lds = small_panel_lds(n, l);
+    static bool attr_set = false;
+    if (!attr_set) {   // (more than the 64 KB a launch may ask for by default: 784 x 20 floats + the factors = 71 KB)
+        AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(small_panel_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(small_panel_qr_kernel, dim3(1), dim3(512), lds, stream(), z, (uint32_t)n, l, g_tall, 1e-10, flag, g_zero, apply_only ? 1 : 0);
+    check_launch("small_panel_qr");
+}
+
+// subspace_iteration_full / _csr, svdapprox.rs:285-408.  d_q: m x l panel (output, orthonormal columns -- or, with `tf` and a tall dense
+// matrix, the un-normalised panel and its Gram: TallFactor)
+static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, DevBuf<float>& q, TallFactor* tf = nullptr, bool no_defer = false) {
     const uint64_t m = a.nrows, n = a.ncols;
     const uint32_t l = (uint32_t)std::min<uint64_t>(std::min(m, n), rank);  // :294 / :358
     if (l == 0 || l > kMaxL) fail(AE_ERR_INVALID_ARG, "rank %llu unsupported (1..%d)", (unsigned long long)rank, kMaxL);
@@ -1502,6 +1612,34 @@ static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t
     yn.alloc_pooled(n * l);
     work.alloc_pooled(3ull * l * l + l);
     q.alloc_pooled(m * l);
+    if (tf) *tf = TallFactor();
+    if (!no_defer && dense_deferred_ok(a, l)) {
+        FastOrth& f = fast_orth();
+        f.g[0].zero(); f.g[1].zero();
+        unsigned k = 0;
+        gaussian_fill_device(omega.p, n * l, kDefaultSeed, kTagOmega);  // :69-76, :299
+        mat_mul_panel(a, omega.p, q.p, l);                              // :300
+        launch_gram_mfma(q.p, m, l, f.g[k].p);                          // the Gram IS the QR of :307 (R^T R = g)
+        for (uint64_t j = 1; j < nbiter; j++) {                         // :308
+            mat_t_mul_panel(a, q.p, yn.p, l);                           // :311, on Y: (A^T Y) ...
+            launch_small_panel_qr(yn.p, n, l, f.g[k].p, f.flag.p, f.g[k ^ 1].p, false);   // ... R^-1, then the QR of :313-319
+            mat_mul_panel(a, yn.p, q.p, l);                             // :321
+            k ^= 1;
+            launch_gram_mfma(q.p, m, l, f.g[k].p);                      // :323-329
+        }
+        if (!orthonormalize_fast_failed()) {   // (synchronises)
+            if (tf) { tf->deferred = true; tf->g = f.g[k].p; return l; }
+            // the caller wants Q itself: one explicit Y <- Y R^-1
+            const uint32_t rp = l <= 24 ? 256u : (l <= 40 ? 128u : 32u);
+            const uint64_t ntiles = (m + rp - 1) / rp;
+            const size_t smem = sizeof(double) * ((size_t)l * l + l + rp * (size_t)(l + 1));
+            hipLaunchKernelGGL(chol_apply_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024))), dim3(256), smem, stream(), q.p, m, l,
+                               (const double*)f.g[k].p, 1e-10, f.flag.p, (double*)nullptr, rp);
+            check_launch("chol_apply");
+            if (!orthonormalize_fast_failed()) { f.g[0].zero(); f.g[1].zero(); sync(); return l; }   // (the accumulators are left zeroed: orthonormalize_panel_fast counts on it)
+        }
+        // a rank-deficient panel somewhere: the explicit route below (its own fallback turns dependent directions into zero columns)
+    }
     // do_qr (Householder, :998-1013) is replaced by CholeskyQR on an f64 Gram.  First optimistically (two launches per
     // QR, no host round trip); if any panel was rank deficient (sticky device flag) the whole iteration is redone
     // with the eigen route, which turns the dependent directions into zero columns.
@@ -1533,7 +1671,7 @@ struct SvdOut {
 };
 
 // SvdApprox::direct_svd (RANK mode), svdapprox.rs:721-799
-static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out);
+static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out, const TallFactor* tf = nullptr);
 
 // Eigendecomposition of the l x l (l <= 64) f64 Gram on the HOST: cyclic Jacobi, eigenvalues descending, eigenvectors
 // in the columns of v (row-major).  The callers need the spectrum on the host anyway (one synchronisation either
@@ -1583,16 +1721,51 @@ static void jacobi_eigh_host(const double* g_in, uint32_t l, std::vector<double>
 }
 static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, bool want_vt, SvdOut& out) {
     DevBuf<float> q;
-    const uint32_t l = subspace_iteration_device(a, rank, nbiter, q);
+    TallFactor tf;
+    uint32_t l = subspace_iteration_device(a, rank, nbiter, q, &tf);
+    if (direct_svd_from_q(a, q, l, want_vt, out, tf.deferred ? &tf : nullptr)) return;
+    // the last tall panel's Gram did not factorise (rank deficient): the explicit route
+    l = subspace_iteration_device(a, rank, nbiter, q, nullptr, true);
     direct_svd_from_q(a, q, l, want_vt, out);
 }
-// the part of direct_svd after the range approximation Q (m x l), :737-799
-static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out) {
+// host: upper Cholesky R of the l x l f64 Gram g (R^T R = g); false if a pivot is not safely positive
+static bool chol_upper_host(const double* g, uint32_t l, std::vector<double>& R) {
+    R.assign((size_t)l * l, 0.);
+    double dmax = 0.;
+    for (uint32_t i = 0; i < l; i++) dmax = std::max(dmax, g[(size_t)i * l + i]);
+    for (uint32_t j = 0; j < l; j++) {
+        for (uint32_t i = j; i < l; i++) {
+            double v = g[(size_t)j * l + i];
+            for (uint32_t k = 0; k < j; k++) v -= R[(size_t)k * l + j] * R[(size_t)k * l + i];
+            if (i == j) {
+                if (!(v > 1e-10 * dmax)) return false;
+                R[(size_t)j * l + j] = std::sqrt(v);
+            } else {
+                R[(size_t)j * l + i] = v / R[(size_t)j * l + j];
+            }
+        }
+    }
+    return true;
+}
+// the part of direct_svd after the range approximation Q (m x l), :737-799.  tf: q holds the un-normalised tall panel Y and tf->g its
+// Gram (Q = Y R^-1); returns false if that Gram does not factorise (nothing computed: the caller takes the explicit route)
+static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out, const TallFactor* tf) {
     const uint64_t m = a.nrows, n = a.ncols;
+    std::vector<double> hgt, hR;
+    if (tf) {
+        hgt.resize((size_t)l * l);
+        AE_HIP(hipMemcpyAsync(hgt.data(), tf->g, sizeof(double) * l * l, hipMemcpyDeviceToHost, stream()));
+        sync();
+        if (!chol_upper_host(hgt.data(), l, hR)) { fast_orth().g[0].zero(); fast_orth().g[1].zero(); return false; }
+    }
     // B = Q^T A (l x n), kept transposed: Bt = A^T Q (n x l)                       :737-743
     DevBuf<float> bt;
     bt.alloc_pooled(n * l);
     mat_t_mul_panel(a, q.p, bt.p, l);
+    if (tf) {   // ... = (A^T Y) R^-1, on the small side
+        FastOrth& f = fast_orth();
+        launch_small_panel_qr(bt.p, n, l, tf->g, f.flag.p, nullptr, true);
+    }
     // svd(B) through the l x l Gram B B^T = U_b S^2 U_b^T                          :758
     DevBuf<double> work;
     work.alloc_pooled(3ull * l * l + l);
@@ -1611,7 +1784,20 @@ static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
     for (uint32_t i = 0; i < l; i++) out.s[i] = (float)std::sqrt(std::max(hev[i], 0.));
     // U = Q U_b                                                                   :781
     out.u.alloc_pooled(m * l);
-    apply_panel(q.p, m, l, ub, l, out.u.p);
+    if (tf) {   // Q U_b = Y (R^-1 U_b): back substitution on the l x l side
+        std::vector<double> mm((size_t)l * l);
+        for (uint32_t c = 0; c < l; c++)
+            for (int i = (int)l - 1; i >= 0; i--) {
+                double v = hub_sorted[(size_t)i * l + c];
+                for (uint32_t k = (uint32_t)i + 1; k < l; k++) v -= hR[(size_t)i * l + k] * mm[(size_t)k * l + c];
+                mm[(size_t)i * l + c] = v / hR[(size_t)i * l + i];
+            }
+        AE_HIP(hipMemcpyAsync(ub, mm.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, stream()));
+        apply_panel(q.p, m, l, ub, l, out.u.p);
+        sync();   // (mm leaves scope)
+    } else {
+        apply_panel(q.p, m, l, ub, l, out.u.p);
+    }
     if (want_vt) {
         // Vt = S^-1 U_b^T B  <=>  V = Bt U_b S^-1 ; null directions get zero rows
         const std::vector<double>& hub = hub_sorted;
@@ -1627,6 +1813,12 @@ static void direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
         apply_panel(bt.p, n, l, dm.p, l, out.vtT.p);
     }
     sync();
+    if (tf) {
+        if (orthonormalize_fast_failed()) return false;   // (cannot happen after the host factorisation succeeded; kept as a guard)
+        fast_orth().g[0].zero(); fast_orth().g[1].zero();   // (the accumulators are left zeroed: orthonormalize_panel_fast counts on it)
+        sync();
+    }
+    return true;
 }
 
 // Leading singular triplets of a dense symmetric matrix, converged: stands in for the full LAPACK

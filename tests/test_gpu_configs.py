@@ -173,11 +173,14 @@ def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
 
 def test_c3_schedule_hierarchical_60k(A):
     """configs[2] schedule (examples/higgs.rs:204-242: hierarchical, grad_factor 5 x 40 batches on the small graph, 40 on the
-    large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: the time-sliced and the
-    event-ordered mode vs the default (sequential).  Two stages of stochastic optimisation in a strongly collapsed regime: the
+    large one, scale_rho 0.75, hubness weighting) at 60 k points of the Higgs-shaped generator: the time-sliced, the event-ordered
+    and the default mode against the sequential one, FOUR seeds a side through tests/util.py: assert_means_close (round 5: three-seed
+    means against fixed 5 % / 18 % and 8 % / 25 % bars).  Two stages of stochastic optimisation in a strongly collapsed regime: the
     sequential pipeline itself moves by 2 % (CE) / 6 % (quartiles) from run to run here (its dmap initialisation is not bitwise
-    reproducible).  Measured against it: time-sliced CE +1.5 %, quartiles -3 ... +10 % (bars 5 % / 18 %); event-ordered CE +3 ... +5 %,
-    quartiles -6 ... -17 % -- its known bias in this regime (bars 8 % / 25 %)."""
+    reproducible), which the standard error carries.  Floors = the systematic distance CLAIMED: time-sliced and default 2 % on the
+    cross entropy, 6 % on the quartiles (measured three-seed means over six runs of round 3: sliced CE 0.981-1.000, quartiles
+    0.97-1.105; default 0.998-1.023 / 0.91-1.02); event-ordered 5 % / 12 % -- its known bias in this regime (CE +3 ... +5 %, quartiles
+    -6 ... -17 %)."""
     n, k = 60000, 6
     x = _blobs(n)
     n_small = n // 24
@@ -191,25 +194,19 @@ def test_c3_schedule_hierarchical_60k(A):
     indptr, nbr, _ = large.get_neighbours()
     out = {}
     for name, mode in (("seq", A.AE_CE_SEQUENTIAL), ("sliced", A.AE_CE_SLICED), ("event", A.AE_CE_EVENT), ("default", A.AE_CE_AUTO)):
-        ces, qs = [], []
-        for rep in range(3):  # three runs per mode: every pipeline here, the sequential one included, moves by 2 % / 6 % from run to run
+        rows = []
+        for rep in range(4):
             par = A.EmbedderParams(asked_dim=2, nb_grad_batch=40, grad_factor=5, scale_rho=0.75, beta=1.0, grad_step=1.0,
                                    nb_sampling_by_edge=10, dmap_init=True, hubness_weighting=True, ce_mode=mode, seed=4664397 + rep)
             emb = A.Embedder.from_hkgraph(A.KGraphProjection(small, large, pn, pd), par)
             assert emb.embed() == 1
             y = emb.get_embedded()
             assert np.isfinite(y).all()
-            ces.append(emb.get_cross_entropy()[1])
-            qs.append(_edge_q(indptr, nbr, y))
-        out[name] = (np.mean(ces), np.mean(qs, axis=0))
-    # Spread of the three-seed means over six runs of this test (round 3, printed below): sliced CE 0.981-1.000, quantiles 0.97-1.105;
-    # event CE 1.028-1.046, quantiles 0.83-0.94; default (ordered) CE 0.998-1.023, quantiles 0.91-1.02 -- the quantile bars are that
-    # spread plus a margin (0.12 for sliced / default failed one run in eight on the 5 % quantile).
-    for name, tol_ce, tol_q in (("sliced", 0.05, 0.18), ("event", 0.08, 0.25), ("default", 0.05, 0.18)):
-        ce, q = out[name]
-        print("c3 hierarchical 60k %s: ce ratio %.4f, quantile ratios %s" % (name, ce / out["seq"][0], np.round(q / out["seq"][1], 3)))
-        assert abs(ce - out["seq"][0]) < tol_ce * out["seq"][0], (name, ce, out["seq"][0])
-        assert np.all(np.abs(q - out["seq"][1]) < tol_q * out["seq"][1]), (name, q, out["seq"][1])
+            rows.append([emb.get_cross_entropy()[1]] + [float(v) for v in _edge_q(indptr, nbr, y)])
+        out[name] = rows
+    names = ["ce", "q25", "q50", "q75"]
+    for name, floors in (("sliced", [0.02, 0.06, 0.06, 0.06]), ("default", [0.02, 0.06, 0.06, 0.06]), ("event", [0.05, 0.12, 0.12, 0.12])):
+        assert_means_close(out[name], out["seq"], names, floors, "c3 hierarchical 60k, %s / sequential" % name)
 
 
 def test_c3_full_size_properties(A):

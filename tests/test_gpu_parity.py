@@ -421,11 +421,11 @@ def _edge_len(indptr, nbr, y):
 
 def test_event_mode_statistics_match_oracle(A, oracle):
     """The event-ordered mode (AE_CE_EVENT) is not reproducible sample by sample (neither is the reference's rayon loop); its
-    statistics are the sequential loop's: final cross entropy within 3 % and edge-length quantiles within 5 % of the oracle's
-    sequential run (measured 1.8 % / 3 % -- the size of the oracle's own seed-to-seed spread at this n), and so are the
-    default's (AE_CE_AUTO -> the ordered dataflow at this size).  AE_CE_SEQUENTIAL reproduces the oracle bit for bit.  Kept as evidence next to them: the
-    rounds mode (AE_CE_HOGWILD, stale partner rows) and the literal racy per-sample transcription are NOT inside that
-    envelope."""
+    statistics are the sequential loop's, and so are the default's (AE_CE_AUTO -> the ordered dataflow at this size): FOUR seeds a side
+    against four seeds of the exact mode, |mean ratio - 1| < 2 SE + 1 % on the final cross entropy and the median edge, + 3 % on the
+    other quantiles (tests/util.py: assert_means_close; round 5 compared one run with one run at 3 % / 5 %).  AE_CE_SEQUENTIAL
+    reproduces the oracle bit for bit.  Kept as evidence next to them: the rounds mode (AE_CE_HOGWILD, stale partner rows) and the
+    literal racy per-sample transcription are NOT inside that envelope."""
     n = 20000
     indptr, nbr, dist, _, _ = synthetic_graph(n=n, dim=8, k=8, seed=2, ncomp=6)
     g = A.KGraph(indptr, nbr, dist)
@@ -438,14 +438,22 @@ def test_event_mode_statistics_match_oracle(A, oracle):
     yd, _, ced = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_SEQUENTIAL), y0)
     assert np.array_equal(yd, yo) and abs(ced - oce1) < 1e-11 * oce1  # the parity mode: the oracle's run, bit for bit
     lo = _edge_len(indptr, nbr, yo)
-    for mode in (A.AE_CE_EVENT, A.AE_CE_AUTO):
-        y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=mode), y0)
-        assert abs(ce0 - oce0) < 2e-6 * oce0   # (the embedded scales of a mode that is not the bit-exact one: mean summed as an f64 tree, an f32 ulp off the reference's)
-        assert np.isfinite(y).all()
-        assert abs(ce1 - oce1) < 0.03 * oce1, (mode, ce1, oce1)
-        lg = _edge_len(indptr, nbr, y)
-        for q in (0.25, 0.5, 0.75, 0.95):
-            assert abs(np.quantile(lg, q) - np.quantile(lo, q)) < 0.05 * np.quantile(lo, q), (mode, q)
+    seeds = (4242, 12121, 20000, 27879)
+    names, floors = ["ce", "q25", "q50", "q75", "q95"], [0.01, 0.03, 0.01, 0.03, 0.03]
+
+    def runs(mode):
+        out = []
+        for sd in seeds:
+            y, ce0, ce1 = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=mode, seed=sd), y0)
+            if mode != A.AE_CE_SEQUENTIAL:
+                assert abs(ce0 - oce0) < 2e-6 * oce0   # (the embedded scales of a mode that is not the bit-exact one: mean summed as an f64 tree, an f32 ulp off the reference's)
+            assert np.isfinite(y).all()
+            out.append([ce1] + [float(np.quantile(_edge_len(indptr, nbr, y), q)) for q in (0.25, 0.5, 0.75, 0.95)])
+        return out
+
+    exact = runs(A.AE_CE_SEQUENTIAL)
+    for mode, what in ((A.AE_CE_EVENT, "event-ordered / exact, 20 k nodes"), (A.AE_CE_AUTO, "default (ordered dataflow) / exact, 20 k nodes")):
+        assert_means_close(runs(mode), exact, names, floors, what)
     # rounds mode: a throughput mode outside the envelope (documented) -- only sanity here
     yr, _, cer = A.entropy_optimize(g, npar, A.EmbedderParams(nb_grad_batch=6, ce_mode=A.AE_CE_HOGWILD), y0)
     assert np.isfinite(yr).all() and abs(cer - oce1) < 0.25 * oce1
@@ -790,6 +798,60 @@ def test_gpu_dense_direct_svd_column_counts(A, oracle, m, ncols, rank):
     s_ref = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:rank]
     assert _relmax(r.s, s_ref) < 2e-4
     assert np.linalg.norm((r.u * r.s) @ r.vt - a) / np.linalg.norm(a) < 1e-4
+
+
+def _mixture_rows(m, n, seed):
+    """rows of configs[4]'s kind: components of 50 000 points, means N(0, 10^2), sigma 1 -- a spectrum with a clear head"""
+    rng = np.random.default_rng(seed)
+    ncomp = max(2, m // 50_000)
+    means = rng.normal(size=(ncomp, n)) * 10.0
+    lab = np.arange(m) % ncomp
+    return (means[lab] + rng.standard_normal((m, n), dtype=np.float32)).astype(np.float32)
+
+
+def test_gpu_dense_direct_svd_c5_columns_vs_oracle(A, oracle):
+    """The dense range finder at configs[4]'s column count (svdapprox.rs:285-333, 721-799 on a 200 000 x 128 block of the data matrix;
+    the tall panel's QR is deferred to the small side, svd.hip: TallFactor): singular values against the oracle's LAPACK path (same
+    Omega stream, same algorithm), U orthonormal, A^T U = V S."""
+    a = _mixture_rows(200_000, 128, 4)
+    r = A.SvdApprox(A.MatRepr.from_array2(a)).direct_svd(A.RangeRank(20, 5))
+    so, uo, vto = oracle.direct_svd(a, 20, 5)
+    assert _relmax(r.s[:4], so[:4]) < 1e-4   # the four centres
+    assert _relmax(r.s, so) < 3e-4           # the sketch's view of the flat noise floor: two f32 summation orders apart
+    assert np.max(np.abs(r.u.T.astype(np.float64) @ r.u - np.eye(20))) < 1e-4
+    assert np.max(np.abs(r.vt.astype(np.float64) @ r.vt.T - np.eye(20))) < 1e-4
+    # the leading triplets agree with the oracle's up to the sign of a column (the tail of a rank-20 sketch of a 128-column matrix
+    # with a flat noise floor is not unique to 1e-4: compare where the spectrum has gaps)
+    lead = 4
+    for j in range(lead):
+        assert abs(abs(float(r.u[:, j] @ uo[:, j])) - 1.0) < 1e-3, j
+    resid = np.linalg.norm(a.T.astype(np.float64) @ r.u - r.vt.T * r.s) / np.linalg.norm(r.s)
+    assert resid < 1e-4, resid
+    # the explicit Q of subspace_iteration (the same deferred path, with the one Y <- Y R^-1 at its end) spans the same range
+    q = A.subspace_iteration(A.MatRepr.from_array2(a), 20, 5)
+    assert np.max(np.abs(q.T.astype(np.float64) @ q - np.eye(20))) < 1e-4
+    assert np.linalg.norm(q @ (q.T @ r.u[:, :lead]) - r.u[:, :lead]) < 1e-3
+
+
+def test_gpu_dense_direct_svd_c5_shard_size_properties(A):
+    """... and at a rank's share of configs[4] (6.25 M x 128, 3.2 GB): size-independent properties -- U orthonormal, sigma = the norms of
+    A^T u, sigma_0 the spectral norm of the centre structure (>= the largest column-block norm / sqrt(m) bound), descending spectrum."""
+    m, n = 6_250_000, 128
+    a = _mixture_rows(m, n, 4)
+    r = A.SvdApprox(A.MatRepr.from_array2(a)).direct_svd(A.RangeRank(20, 5), want_vt=False)
+    assert np.all(np.diff(r.s) <= 1e-6 * r.s[0]) and r.s[-1] > 0
+    g = np.zeros((20, 20))
+    atu = np.zeros((n, 20))
+    for b in range(0, m, 500_000):   # (blocked f64 accumulation on the host)
+        ub = r.u[b:b + 500_000].astype(np.float64)
+        g += ub.T @ ub
+        atu += a[b:b + 500_000].astype(np.float64).T @ ub
+    assert np.max(np.abs(g - np.eye(20))) < 2e-4, np.max(np.abs(g - np.eye(20)))
+    assert _relmax(np.linalg.norm(atu, axis=0), r.s) < 2e-4
+    # Rayleigh bound: no unit vector gives more than sigma_0; the all-ones direction of the row space gives a lower bound
+    ones = np.ones(n) / np.sqrt(n)
+    lower = np.sqrt(sum(float(np.sum((a[b:b + 500_000].astype(np.float64) @ ones) ** 2)) for b in range(0, m, 500_000)))
+    assert r.s[0] >= lower * (1 - 1e-4)
 
 
 def test_gpu_svd_sparse_vs_oracle(A, oracle):
