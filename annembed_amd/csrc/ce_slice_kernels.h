@@ -147,7 +147,7 @@ __device__ __forceinline__ void coop_land(const f4 (&pc)[NF / 4], float* stage) 
     wave_lds_sync();
 }
 template <int NF>
-__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride = NF) {
+__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride = NF, bool nt = false) {
     constexpr int G = NF / 4, RS = NF + 4;
     const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
     const uint32_t word = idx | (want ? 0x80000000u : 0u);
@@ -155,8 +155,12 @@ __device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t id
 #pragma unroll
     for (int t = 0; t < G; t++) {
         const uint32_t wt = group_bcast<G>(word, t);
-        if (wt & 0x80000000u)
-            *reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u) = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
+        if (wt & 0x80000000u) {
+            f4* dst = reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u);
+            const f4 v = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
+            if (nt) __builtin_nontemporal_store(v, dst);   // (A/B, AE_SL_DBG bit 128: the row leaves the caches as it is written instead of at the kernel's end)
+            else *dst = v;
+        }
     }
     wave_lds_sync();
 }
@@ -257,7 +261,7 @@ struct RowFetch {  // a coordinate row on its way to its lane
     }
 };
 template <int DIM>
-__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride) {
+__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride, bool nt = false) {
     if constexpr (kCoopRow<DIM>) {
         float* p = stage + (threadIdx.x & 63) * (DIM + 4);
 #pragma unroll
@@ -265,7 +269,7 @@ __device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, 
             f4 v; v.x = in[4 * q]; v.y = in[4 * q + 1]; v.z = in[4 * q + 2]; v.w = in[4 * q + 3];
             *reinterpret_cast<f4*>(p + 4 * q) = v;
         }
-        coop_store<DIM>(y, node, want, stage, stride);
+        coop_store<DIM>(y, node, want, stage, stride, nt);
     } else {
         if (want) store_row<DIM>(y + (uint64_t)node * stride, 0u, in);
     }
@@ -367,11 +371,12 @@ struct TileFetch {
     static constexpr int Q = DIM % 4 == 0 ? DIM / 4 : DIM;  // pieces per row
     f4 pc[T::kPieces];
     uint32_t node[T::kPieces];
-    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n) {
+    // rows: the tile's first `rows` rows are distinct draws, the others repeat them (A/B, AE_SL_DBG bit 256: a tile of 128 rows for 256 samples)
+    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n, uint32_t rows = (uint32_t)TileShape<DIM>::kRows) {
         const uint32_t pool_at = hub ? __umulhi(pcg_hash(wkey), hub_pool_n - (uint32_t)T::kRows) : 0u;
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
-            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = x / Q;
+            const uint32_t x = (uint32_t)z * 256u + threadIdx.x, r = (x / Q) & (rows - 1u);
             if (hub) {
                 node[z] = hub_pool[pool_at + r];   // a run of the batch's pool: kRows independent draws of the alias table, one coalesced read
             } else {
@@ -404,11 +409,11 @@ struct TileFetch {
 // the alias look-ups overlap.  Returns the number accepted (5 unless the graph is tiny).
 template <int DIM, int KMAX, bool TILE>
 __device__ __forceinline__ uint32_t draw_negatives(const CeDev& c, bool hub, const uint32_t* s_tnode, uint32_t nb, uint32_t i,
-                                                   const uint32_t (&nbr_reg)[KMAX], uint32_t (&out)[5]) {
+                                                   const uint32_t (&nbr_reg)[KMAX], uint32_t (&out)[5], uint32_t tile_rows = (uint32_t)TileShape<DIM>::kRows) {
     using T = TileShape<DIM>;
     uint32_t got = 0;
     // the units a sample may use once: windows of T::kL = 16 rows; with hubness weighting single rows (every tile row is a draw of its own)
-    const uint32_t wshift = hub ? 0u : 4u, units = hub ? (uint32_t)T::kRows : (uint32_t)T::kW;
+    const uint32_t wshift = hub ? 0u : 4u, units = hub ? tile_rows : tile_rows / (uint32_t)T::kL;
     static_assert(T::kL == 16 && (T::kW & (T::kW - 1)) == 0 && (T::kRows & (T::kRows - 1)) == 0, "draw_negatives: windows of 16 rows, power-of-two counts");
 #pragma unroll
     for (int g = 0; g < 5; g++) out[g] = TILE ? 0u : i;
@@ -654,7 +659,8 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
             if (p + 1 < a.end) nx = a.ev[p + 1];
         }
         TileFetch<DIM> ft;
-        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
+        const uint32_t tile_rows = (a.dbg & 256) ? (uint32_t)TileShape<DIM>::kRows / 2u : (uint32_t)TileShape<DIM>::kRows;
+        if constexpr (TILE && FIRST) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n, tile_rows);
         const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
         const bool half = act0 && ev_half(e.j);   // (multi-GPU) the source is another shard's: attraction on the target's row only
         // chains: this event has the previous one's target / the next one has this one's
@@ -703,7 +709,7 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         SplitSample<DIM, F64, TILE> sm;
         uint32_t neg[5], got = 0;
         if (cmp && !half) {
-            got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
+            got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg, tile_rows);
             if (a.dbg & 4) { got = 0; for (int g = 0; g < 5; g++) neg[g] = TILE ? 0u : i; }
             sm.fetch(c, sh.tile, neg);
         }
@@ -730,7 +736,7 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
             if (cmp && runpos == t && !(a.dbg & 1)) {
                 for (uint32_t q = 0; q + 1u < rep; q++) {   // earlier repetitions of the edge: whole samples, one after the other
                     uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
-                    const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng);
+                    const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + q)), i, nbr_reg, ng, tile_rows);
                     run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
                 }
                 sm.attract(c, yi, yj, w, scale_f, a.step);
@@ -746,8 +752,8 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         // and announced where the chain goes on in the next chunk
         const bool store_j = act0 && last_in_seg && !hand_over;
         if (!(a.dbg & 2)) {
-            row_store<DIM>(c.y, j, store_j, stage, yj, c.ystride);  // :1239
-            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride);      // :1301
+            row_store<DIM>(c.y, j, store_j, stage, yj, c.ystride, (a.dbg & 128) != 0);  // :1239
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride, (a.dbg & 128) != 0);      // :1301
         } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
             row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride);
         }

@@ -550,6 +550,8 @@ def compact_line(full):
                            "frac_whole_batch": round(dm["roofline"]["frac_whole_batch"], 4)}
     if brief:
         out["scale_shapes"] = brief
+    if full.get("end_to_end"):
+        out["end_to_end"] = {k: v for k, v in full["end_to_end"].items() if k != "note"}
     for k in ("per_rank_batch_ms_max", "faithful", "samples_per_s", "ce_before", "ce_after", "details"):
         if k in full:
             out[k] = _short(full[k], 120)
@@ -959,11 +961,21 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
         y0 = A.set_data_box(np.random.default_rng(1).normal(size=(n, d)).astype(np.float32), 10.0)   # (a component-wise kNN graph is disconnected: no diffusion-map start)
     else:
         y0 = A.set_data_box(A.DiffusionMaps(A.DiffusionParams(d, 5.0, 12)).embed_from_kgraph(kg), 10.0)  # replicated
+    # what every rank REPEATS (replicated by a measured decision): edge weights, the handle (per-node records of the whole
+    # graph, alias tables), the edge colouring (at attach: ce_slice_prepare); timed so that the line can say what share of a sharded
+    # embedding they are
+    L.check(L.load().ae_synchronize())
+    t_rep = time.perf_counter()
     node_params = A.to_proba_edges(kg, 1.0, 1.0)
+    L.check(L.load().ae_synchronize())
+    node_params_s = time.perf_counter() - t_rep
     nb_batch = max(25, args.warmup + args.steps + 1)
     params = A.EmbedderParams(asked_dim=d, nb_grad_batch=nb_batch, nb_sampling_by_edge=10, grad_step=1.0, scale_rho=1.0, beta=1.0,
                               ce_mode=A.AE_CE_AUTO if faithful else A.AE_CE_HOGWILD, hubness_weighting=hub is not None)
+    t_rep = time.perf_counter()
     eo = A.EntropyOptim(kg, node_params, params, y0, node_lo=lo, node_hi=hi, hub_counts=hub)
+    L.check(L.load().ae_synchronize())
+    create_s = time.perf_counter() - t_rep
     nb_sample = params.nb_sampling_by_edge * eo.get_nb_edges()
     library_comm = args.backend == "nccl"
     comm = sharded = None
@@ -972,7 +984,10 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
     if library_comm:
         try:
             comm = LibraryComm(rank, world)
+            t_rep = time.perf_counter()
             comm.attach(eo, args.exchanges)
+            L.check(L.load().ae_synchronize())
+            create_s += time.perf_counter() - t_rep   # (the time-sliced mode prepares here: colouring + static records of the whole graph)
         except Exception as e:  # e.g. librccl.so.1 not loadable from the library: agree on the fallback below
             comm, comm_error = None, repr(e)[:300]
         ok = torch.tensor([1 if comm is not None else 0], device="cuda")
@@ -1038,6 +1053,12 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
             run["sliced"] = {"classes": cl, "overflow_mass_fraction": ovf, "slices_per_batch": slices, "max_in_degree": eo.slice_hub_info()[0]}
         roof = roofline_of(run, k, d)
         roof["note"] = "per GPU: bytes of this rank's samples / the slowest rank's batch time, collectives included"
+        ms_b = elapsed / args.steps * 1e3
+        rep_s = (part_info or {}).get("seconds", 0.0) + node_params_s + create_s
+        end_to_end = {"partition_s": (part_info or {}).get("seconds"), "node_params_s": node_params_s, "prepare_s": create_s, "replicated_s": rep_s, "ms_per_batch": ms_b,
+                      "batches": 40, "replicated_share_of_a_40_batch_embedding": rep_s / (rep_s + 40 * ms_b * 1e-3),
+                      "note": "every rank repeats partition, edge weights and the handle's preparation (colouring + records of the whole graph); the dmap initialisation of "
+                              "embed() is replicated too (configs[3]: 0.1 s, configs[4]: 1.1 s; svd_init_c4 in the --gpus 1 line)"}
         exch = args.exchanges if library_comm else 1
         out = {
             "metric": "embedded_points_per_sec_ce_epoch",
@@ -1061,6 +1082,7 @@ def multi_gpu(args, A, L, dist, torch, rank, world, fence):
                              else "torch/gloo (validation)")},
             "roofline": roof,
             "per_rank_batch_ms_max": kernel_ms_max,
+            "end_to_end": end_to_end,
             "faithful": "statistically (the time-sliced mode on node ranges: tests/test_gpu_configs.py::test_sharded_sliced_*, DESIGN 5)" if resolved == 5 else False,
             "multi_gpu_note": ("every rank runs the time-sliced mode on its own node range: its events on current rows, the other ranks' rows (negatives, the far ends of the "
                                "few cross-shard edges) as of the last all-gather; measured on one GPU with 2 and 8 processes: the result does not depend on the exchanges "

@@ -1,6 +1,11 @@
-"""the two launch forms of the time-sliced class path (merged slices / one launch per class) against the exact mode on the stiff
-k = 6 blobs graph of tests/test_gpu_configs.py::test_k6_blobs_without_hubness_40_batches, many seeds a side.
-usage: python tools/run_blobs_forms.py [n_seeds]"""
+"""The launch forms of the time-sliced class path (merged slices / one launch per class / the optimistic passes) against the exact mode on the
+stiff k = 6 blobs graph of tests/test_gpu_configs.py::test_k6_blobs_without_hubness_40_batches, many seeds a side -- and, round 6, the A/B
+variants that look for the merged form's bias (+0.7 % CE, -1.5 % median edge at 48 seeds, round 5):
+  late      merged, the negatives' rows read after the lane's dependencies are met, past the caches (AE_SL_DBG bit 64)
+  ov_every  merged, the thin overflow class in EVERY slice (not every 8th)
+  base11    merged with the base palette (11 classes instead of 15)
+  pc15      one launch per class with the wide palette (15 classes)
+usage: python tools/run_blobs_forms.py [n_seeds] [variants: comma list of exact,per_class,merged,optimistic,late,ov_every,base11,pc15]"""
 import os
 import sys
 
@@ -13,12 +18,24 @@ import annembed_amd as A  # noqa: E402
 import test_gpu_configs as T  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["exact", "per_class", "merged", "optimistic"]
 n = 60000
 g = A.KGraph.bruteforce_l2(T._blobs(n), 6)
 indptr, nbr, _ = g.get_neighbours()
 npar = A.to_proba_edges(g, 0.75, 1.0)
 y0 = (np.random.default_rng(5).random(size=(n, 2)).astype(np.float32) - 0.5)
 seeds = [1000 + 7919 * s for s in range(n_seeds)]
+K = {"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1"}
+VARIANTS = {
+    "exact": (A.AE_CE_SEQUENTIAL, {}),
+    "per_class": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1")),
+    "merged": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1")),
+    "optimistic": (A.AE_CE_SLICED, {}),
+    "late": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_DBG="64")),
+    "ov_every": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_OV_EVERY_SLICE="1")),
+    "base11": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_BASE_CLASSES="1")),
+    "pc15": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15")),
+}
 
 
 def rows(mode, knobs):
@@ -34,14 +51,19 @@ def rows(mode, knobs):
             os.environ.pop(k, None)
 
 
-res = {"exact": rows(A.AE_CE_SEQUENTIAL, {})}
-res["per class"] = rows(A.AE_CE_SLICED, {"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_MERGE": "1"})
-res["merged"] = rows(A.AE_CE_SLICED, {"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1", "AE_SL_MERGE": "1"})
-res["optimistic"] = rows(A.AE_CE_SLICED, {})
-b = res["exact"]
-for name, a in res.items():
+def ratio(a, b):
     se = np.sqrt(a.var(0, ddof=1) / len(a) + b.var(0, ddof=1) / len(b)) / b.mean(0)
-    print("%-12s / exact: ce, q25, q50, q75 = %s  2 SE %s  (%d seeds a side)" % (name, np.round(a.mean(0) / b.mean(0), 4), np.round(2 * se, 4), len(a)), flush=True)
-a, b = res["merged"], res["per class"]
-se = np.sqrt(a.var(0, ddof=1) / len(a) + b.var(0, ddof=1) / len(b)) / b.mean(0)
-print("merged / per class: %s  2 SE %s" % (np.round(a.mean(0) / b.mean(0), 4), np.round(2 * se, 4)))
+    return np.round(a.mean(0) / b.mean(0), 4), np.round(2 * se, 4)
+
+
+res = {}
+for name in which:
+    res[name] = rows(*VARIANTS[name])
+    if "exact" in res:
+        r, se = ratio(res[name], res["exact"])
+        print("%-10s / exact: ce, q25, q50, q75 = %s  2 SE %s  (%d seeds a side)" % (name, r, se, n_seeds), flush=True)
+if "per_class" in res:
+    for name in which:
+        if name not in ("exact", "per_class"):
+            r, se = ratio(res[name], res["per_class"])
+            print("%-10s / per_class: %s  2 SE %s" % (name, r, se), flush=True)
