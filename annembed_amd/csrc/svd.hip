@@ -1027,9 +1027,13 @@ float ndarray_sum_f32(const float* d_x, uint64_t n) {
 
 // l % 4 == 0, l <= 32: eight lanes per edge, each gathering one float4 of the X row (8 edges x 80 bytes per wave
 // instruction for l = 20 instead of 2 edges), partial rows summed across the 8 edge slots by three xor-shuffle steps.
+constexpr uint32_t kWideLd = 32;   // floats per row of a panel's gather copy (128 bytes)
+// ldx: floats from row to row of the GATHERED operand x (l, or 32: rows of 128 bytes on 128-byte boundaries -- a gathered row is then ONE
+// line where an 80-byte row at an 80-byte stride straddles two in 62 % of the cases; the product is bound by the number of lines it asks
+// the memory system for, tools/ubench_rowgather.hip)
 __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ ind,
                                                             const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ y,
-                                                            uint32_t l) {
+                                                            uint32_t l, uint32_t ldx) {
     const int lane = threadIdx.x & 63;
     const int sl = lane >> 3, q = lane & 7;
     const bool active = (uint32_t)(4 * q) < l;
@@ -1044,8 +1048,8 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
             const bool ina = ea < e1, inc = ec < e1;
             const float va = val[ina ? ea : e0], vc = val[inc ? ec : e0];
             const uint64_t ca = ind[ina ? ea : e0], cc = ind[inc ? ec : e0];
-            const float4 xa = *reinterpret_cast<const float4*>(x + ca * l + qo);
-            const float4 xc = *reinterpret_cast<const float4*>(x + cc * l + qo);
+            const float4 xa = *reinterpret_cast<const float4*>(x + ca * ldx + qo);
+            const float4 xc = *reinterpret_cast<const float4*>(x + cc * ldx + qo);
             const float wa = (ina && active) ? va : 0.f, wc = (inc && active) ? vc : 0.f;
             a0 = fmaf(wa, xa.x, a0); a1 = fmaf(wa, xa.y, a1); a2 = fmaf(wa, xa.z, a2); a3 = fmaf(wa, xa.w, a3);
             a0 = fmaf(wc, xc.x, a0); a1 = fmaf(wc, xc.y, a1); a2 = fmaf(wc, xc.z, a2); a3 = fmaf(wc, xc.w, a3);
@@ -1058,13 +1062,19 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
     }
 }
 
-static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l) {
+// may this product gather from a 128-byte-strided copy of its operand?  (the vec4 kernel's shapes; a panel beyond what the caches hold)
+static bool spmm_wide_ok(const ae_matrepr& a, uint32_t l) {
+    return a.is_csr && l % 4 == 0 && l < kWideLd && (uint64_t)std::max(a.nrows, a.ncols) * kWideLd * 4ull > (256ull << 20) && !debug_knob("AE_SPMM_NO_WIDE") &&
+           !debug_knob("AE_SPMM_SCALAR");
+}
+static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l, uint32_t ldx = 0) {
     const unsigned grid = grid_cap(a.nrows * 64, 256);
     if (l % 4 == 0 && l <= 32 && !debug_knob("AE_SPMM_SCALAR")) {
-        hipLaunchKernelGGL(spmm_csr_vec4_kernel, dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
+        hipLaunchKernelGGL(spmm_csr_vec4_kernel, dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l, ldx ? ldx : l);
         check_launch("spmm_csr_vec4");
         return;
     }
+    if (ldx && ldx != l) fail(AE_ERR_INVALID_ARG, "internal: strided gather operand outside the vec4 product");
     if (l <= 16)
         hipLaunchKernelGGL((spmm_csr_kernel<16>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l);
     else if (l <= 32)
@@ -1198,7 +1208,10 @@ __global__ void __launch_bounds__(256) gram_mfma_f64_kernel(const float* __restr
         for (int b = 0; b < TB; b++) acc[a][b] = d4_t{0., 0., 0., 0.};
     const uint64_t nsteps = (rows + 3) / 4;
     const uint64_t sstride = gridDim.x * 4ull;
-    constexpr int U = 4;  // steps whose loads are issued together (clamped addresses, masked values: no branches)
+    // steps whose loads are issued together (clamped addresses, masked values: no branches).  Round 6: 8 for panels of <= 32 columns and
+    // a grid of up to 2048 workgroups -- at 11 M rows the kernel ran at 1.6 TB/s with 4 MB of loads in flight (512 workgroups x 4 waves
+    // x 2 KB); HBM wants ~16 MB
+    constexpr int U = TB <= 2 ? 8 : 4;
     for (uint64_t s0 = blockIdx.x * 4ull + (uint64_t)__builtin_amdgcn_readfirstlane(wave); s0 < nsteps; s0 += U * sstride) {
         float raw[U][TB];
 #pragma unroll
@@ -1243,7 +1256,7 @@ __global__ void __launch_bounds__(256) gram_mfma_f64_kernel(const float* __restr
 
 static void launch_gram_mfma(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
     const uint64_t nsteps = (rows + 3) / 4;
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nsteps + 63) / 64, 512));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nsteps + 63) / 64, debug_knob("AE_GRAM_GRID") ? atoi(debug_knob("AE_GRAM_GRID")) : 2048));
     const int tb = (int)((l + 15) / 16);
     switch (tb) {
         case 1: hipLaunchKernelGGL((gram_mfma_f64_kernel<1>), dim3(grid), dim3(256), 0, stream(), d_y, rows, l, d_g); break;
@@ -1300,8 +1313,10 @@ __device__ __forceinline__ bool chol_wave_registers(const double* R_in /*LDS, l 
     return ok;
 }
 
+// y_wide (may be null): the orthonormalised rows once more, kWideLd floats apart -- the gather copy the next sparse product reads (spmm)
 __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ g,
-                                                         double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero, uint32_t rp) {
+                                                         double rel_tol, int* __restrict__ flag, double* __restrict__ g_zero, uint32_t rp,
+                                                         float* __restrict__ y_wide = nullptr) {
     extern __shared__ double smem[];         // R[l*l] | rinv[l] | tile[rp rows * (l + 1)] (f64, one row per thread, rp <= 256)
     double* R = smem;
     double* rinv = smem + (size_t)l * l;
@@ -1408,7 +1423,11 @@ __global__ void __launch_bounds__(256) chol_apply_kernel(float* __restrict__ y, 
             }
         }
         __syncthreads();
-        for (uint32_t idx = tid; idx < nr * l; idx += 256) y[r0 * l + idx] = (float)tile[(idx / l) * (l + 1) + idx % l];
+        for (uint32_t idx = tid; idx < nr * l; idx += 256) {
+            const float v = (float)tile[(idx / l) * (l + 1) + idx % l];
+            y[r0 * l + idx] = v;
+            if (y_wide) y_wide[(r0 + idx / l) * kWideLd + idx % l] = v;
+        }
     }
 }
 
@@ -1512,7 +1531,9 @@ struct FastOrth {
 };
 static FastOrth& fast_orth() { static FastOrth f; f.init(); return f; }
 
-void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) {
+static void orthonormalize_panel_fast_wide(float* d_y, uint64_t rows, uint32_t l, float* d_y_wide);
+void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) { orthonormalize_panel_fast_wide(d_y, rows, l, nullptr); }
+static void orthonormalize_panel_fast_wide(float* d_y, uint64_t rows, uint32_t l, float* d_y_wide) {
     FastOrth& f = fast_orth();
     double* g = f.g[f.k & 1].p;
     double* gz = f.g[(f.k + 1) & 1].p;
@@ -1523,7 +1544,7 @@ void orthonormalize_panel_fast(float* d_y, uint64_t rows, uint32_t l) {
     const uint64_t ntiles = (rows + rp - 1) / rp;
     const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 1024));
     const size_t smem = sizeof(double) * ((size_t)l * l + l + rp * (size_t)(l + 1));
-    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), smem, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz, rp);
+    hipLaunchKernelGGL(chol_apply_kernel, dim3(nblocks), dim3(256), smem, stream(), d_y, rows, l, (const double*)g, 1e-10, f.flag.p, gz, rp, d_y_wide);
     check_launch("chol_apply");
 }
 // true when a Cholesky pivot failed since the last call (synchronises the stream)
@@ -1584,10 +1605,15 @@ void orthonormalize_panel(float* d_y, uint64_t rows, uint32_t l, double* d_work)
 struct TallFactor {
     bool deferred = false;   // q holds Y, not Q
     const double* g = nullptr;
+    DevBuf<float> q_wide;    // (sparse matrices with panels beyond the caches) Q once more, rows 128 bytes apart: what the next sparse product gathers
 };
 static size_t small_panel_lds(uint64_t n, uint32_t l) { return sizeof(double) * (2 * (size_t)l * l + l) + sizeof(float) * (size_t)n * (l | 1u); }
+// (from 4 M panel entries on: below, the chol_apply over the tall panel it saves -- 23 us at 60 000 x 20 -- costs less than the
+// single-workgroup launch that replaces it -- measured at 60 000 x 784: 1.12 ms per direct_svd explicit, 1.27 ms deferred; at
+// 6.25 M x 128: 12.5 -> 10.4 ms)
 static bool dense_deferred_ok(const ae_matrepr& a, uint32_t l) {
-    return !a.is_csr && a.nrows >= a.ncols && l <= 32 && small_panel_lds(a.ncols, l) <= 150 * 1024 && !debug_knob("AE_SVD_NO_DEFER");
+    return !a.is_csr && a.nrows >= a.ncols && (uint64_t)a.nrows * l >= 4000000ull && l <= 32 && small_panel_lds(a.ncols, l) <= 150 * 1024 &&
+           !debug_knob("AE_SVD_NO_DEFER");
 }
 static void launch_small_panel_qr(float* z, uint64_t n, uint32_t l, const double* g_tall, int* flag, double* g_zero, bool apply_only) {
     const size_t lds = small_panel_lds(n, l);
@@ -1612,7 +1638,7 @@ static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t
     yn.alloc_pooled(n * l);
     work.alloc_pooled(3ull * l * l + l);
     q.alloc_pooled(m * l);
-    if (tf) *tf = TallFactor();
+    if (tf) { tf->deferred = false; tf->g = nullptr; tf->q_wide.release(); }
     if (!no_defer && dense_deferred_ok(a, l)) {
         FastOrth& f = fast_orth();
         f.g[0].zero(); f.g[1].zero();
@@ -1643,21 +1669,39 @@ static uint32_t subspace_iteration_device(ae_matrepr& a, uint64_t rank, uint64_t
     // do_qr (Householder, :998-1013) is replaced by CholeskyQR on an f64 Gram.  First optimistically (two launches per
     // QR, no host round trip); if any panel was rank deficient (sticky device flag) the whole iteration is redone
     // with the eigen route, which turns the dependent directions into zero columns.
+    // Sparse matrices whose panels do not fit the caches: every orthonormalised panel is also written with its rows 128 bytes apart, and
+    // the next product gathers from that copy (one line per gathered row instead of 1.6: spmm_csr_vec4_kernel)
+    const bool wide = spmm_wide_ok(a, l);
+    DevBuf<float> q_wide, yn_wide;
+    if (wide) { q_wide.alloc_pooled(m * kWideLd); yn_wide.alloc_pooled(n * kWideLd); }
     for (int robust = 0; robust < 2; robust++) {
-        auto qr = [&](float* y, uint64_t rows) {
+        const bool w = wide && !robust;
+        auto qr = [&](float* y, uint64_t rows, float* yw) {
             if (robust) orthonormalize_panel(y, rows, l, work.p);
-            else orthonormalize_panel_fast(y, rows, l);
+            else orthonormalize_panel_fast_wide(y, rows, l, w ? yw : nullptr);
+        };
+        auto mul = [&](const float* x, const float* xw, float* y) {       // y = A x
+            if (w) spmm(a, xw, y, l, kWideLd); else mat_mul_panel(a, x, y, l);
+        };
+        auto tmul = [&](const float* x, const float* xw, float* y) {      // y = A^T x
+            if (!w) { mat_t_mul_panel(a, x, y, l); return; }
+            if (a.symmetric) { spmm(a, xw, y, l, kWideLd); return; }
+            build_transpose(a);
+            spmm(*a.transpose, xw, y, l, kWideLd);
         };
         gaussian_fill_device(omega.p, n * l, kDefaultSeed, kTagOmega);  // RandomGaussianMatrix::new, :69-76, :299/:363
         mat_mul_panel(a, omega.p, q.p, l);                              // :300 / :366
-        qr(q.p, m);                                                     // :307 / :374
+        qr(q.p, m, q_wide.p);                                           // :307 / :374
         for (uint64_t j = 1; j < nbiter; j++) {                         // :308 / :375
-            mat_t_mul_panel(a, q.p, yn.p, l);                           // :311 / :379
-            qr(yn.p, n);                                                // :313-319 / :381-387
-            mat_mul_panel(a, yn.p, q.p, l);                             // :321 / :390
-            qr(q.p, m);                                                 // :323-329 / :392-398
+            tmul(q.p, q_wide.p, yn.p);                                  // :311 / :379
+            qr(yn.p, n, yn_wide.p);                                     // :313-319 / :381-387
+            mul(yn.p, yn_wide.p, q.p);                                  // :321 / :390
+            qr(q.p, m, q_wide.p);                                       // :323-329 / :392-398
         }
-        if (robust || !orthonormalize_fast_failed()) break;
+        if (robust || !orthonormalize_fast_failed()) {
+            if (w && tf) tf->q_wide = std::move(q_wide);
+            break;
+        }
     }
     sync();
     return l;
@@ -1723,7 +1767,7 @@ static void direct_svd_device(ae_matrepr& a, uint64_t rank, uint64_t nbiter, boo
     DevBuf<float> q;
     TallFactor tf;
     uint32_t l = subspace_iteration_device(a, rank, nbiter, q, &tf);
-    if (direct_svd_from_q(a, q, l, want_vt, out, tf.deferred ? &tf : nullptr)) return;
+    if (direct_svd_from_q(a, q, l, want_vt, out, &tf)) return;
     // the last tall panel's Gram did not factorise (rank deficient): the explicit route
     l = subspace_iteration_device(a, rank, nbiter, q, nullptr, true);
     direct_svd_from_q(a, q, l, want_vt, out);
@@ -1749,8 +1793,10 @@ static bool chol_upper_host(const double* g, uint32_t l, std::vector<double>& R)
 }
 // the part of direct_svd after the range approximation Q (m x l), :737-799.  tf: q holds the un-normalised tall panel Y and tf->g its
 // Gram (Q = Y R^-1); returns false if that Gram does not factorise (nothing computed: the caller takes the explicit route)
-static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out, const TallFactor* tf) {
+static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool want_vt, SvdOut& out, const TallFactor* tf_in) {
     const uint64_t m = a.nrows, n = a.ncols;
+    const TallFactor* tf = (tf_in && tf_in->deferred) ? tf_in : nullptr;
+    const float* q_wide = (tf_in && tf_in->q_wide.n) ? tf_in->q_wide.p : nullptr;
     std::vector<double> hgt, hR;
     if (tf) {
         hgt.resize((size_t)l * l);
@@ -1761,7 +1807,12 @@ static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
     // B = Q^T A (l x n), kept transposed: Bt = A^T Q (n x l)                       :737-743
     DevBuf<float> bt;
     bt.alloc_pooled(n * l);
-    mat_t_mul_panel(a, q.p, bt.p, l);
+    if (q_wide) {   // (the gather copy of Q: spmm_wide_ok)
+        if (a.symmetric) spmm(a, q_wide, bt.p, l, kWideLd);
+        else { build_transpose(a); spmm(*a.transpose, q_wide, bt.p, l, kWideLd); }
+    } else {
+        mat_t_mul_panel(a, q.p, bt.p, l);
+    }
     if (tf) {   // ... = (A^T Y) R^-1, on the small side
         FastOrth& f = fast_orth();
         launch_small_panel_qr(bt.p, n, l, tf->g, f.flag.p, nullptr, true);

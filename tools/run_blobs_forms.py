@@ -35,6 +35,14 @@ VARIANTS = {
     "ov_every": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_OV_EVERY_SLICE="1")),
     "base11": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_BASE_CLASSES="1")),
     "pc15": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15")),
+    "pc11": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="11")),
+    "pc13": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="13")),
+    "pc19": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="19")),
+    "pc15_ov": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15", AE_SL_OV_EVERY_SLICE="1")),
+    "pc15_nolines": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15", AE_SL_NO_LINES="1")),
+    "pc11_nolines": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NO_LINES="1")),
+    "ordered": (A.AE_CE_ORDERED, {}),
+    "event": (A.AE_CE_EVENT, {}),
 }
 
 
