@@ -23,6 +23,7 @@ struct CeDev {
     const float* hub_odds;       // non-null = hubness-weighted negative sampling (NodeSampler, embedder.rs:915-930)
     const uint32_t* hub_alias;
     const uint2* hub_tab;        // the same alias table, one 8-byte entry per node {odds bits, alias}: one random access per draw
+    const float* yneg;           // (experiment, AE_SL_NEG_SNAPSHOT: tools/run_blobs_forms.py) where the time-sliced mode reads its NEGATIVES' rows if not in y: a snapshot of y some slices old
     uint32_t ystride;            // floats from one node's row of `y` to the next: dim, or more where the time-sliced mode keeps a node's dependency words behind its row (ce_slice_kernels.h)
 };
 
@@ -135,6 +136,7 @@ struct ae_entropy_optim {
     // batch (a uniform random relabelling: what runs of consecutive rows hold has nothing to do with the caller's labels)
     DevBuf<uint32_t> sl_perm;
     DevBuf<float> sl_y;
+    DevBuf<float> sl_neg_snap;                  // (experiment AE_SL_NEG_SNAPSHOT) the copy of the coordinates the negatives are read from
     uint32_t sl_y_lines = 0;                    // floats per node line whose static part (embedded scale, neighbour ids) sl_y currently holds; 0: none
     DevBuf<uint2> sl_hub_tab;                   // the NodeSampler's alias table in internal numbering
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)

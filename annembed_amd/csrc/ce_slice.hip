@@ -1151,6 +1151,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         AE_HIP(hipEventCreateWithFlags(&dbg_ev, hipEventDisableTiming));
         for (int pc = 0; pc < 8; pc++) AE_HIP(hipStreamCreateWithFlags(&dbg_streams[pc], hipStreamNonBlocking));
     }
+    // EXPERIMENT (AE_SL_NEG_SNAPSHOT = k, one launch per class only): the negatives' rows come from a copy of the coordinates taken every k
+    // slices -- what a form whose negatives are a slice old (merged slices: drawn and fetched at the launch's start) does to the statistics
+    const int neg_snapshot = (!merged && debug_knob("AE_SL_NEG_SNAPSHOT")) ? std::max(1, atoi(debug_knob("AE_SL_NEG_SNAPSHOT"))) : 0;
+    if (neg_snapshot && o->sl_neg_snap.n < n * ystride) o->sl_neg_snap.alloc(n * ystride);
     bool premarked = false;   // the slice about to run had its words filled by the slice before it
     uint32_t step_seq_base = 0;
     auto slice_args = [&](uint32_t s) {
@@ -1240,6 +1244,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         }
         for (uint32_t s = 0; s < n_slices; s++) {
             const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
+            if (neg_snapshot && s % (uint32_t)neg_snapshot == 0u) {   // (experiment: the negatives of the next `neg_snapshot` slices are read from the rows as they are NOW)
+                AE_HIP(hipMemcpyAsync(o->sl_neg_snap.p, cdev.y, sizeof(float) * n * ystride, hipMemcpyDeviceToDevice, stream()));
+                da.c.yneg = a.c.yneg = o->sl_neg_snap.p;
+            }
             if (merged) {
                 // every class of the slice in ONE launch, the order between events kept node by node (sl_slice_kernel).  Its dependency words
                 // were filled by the slice before it, from inside its kernel (a wave that is through enters the next slice's events: the

@@ -384,11 +384,12 @@ struct TileFetch {
                 node[z] -= node[z] >= (uint32_t)c.n ? (uint32_t)c.n : 0u;
             }
         }
+        const float* yb = c.yneg ? c.yneg : c.y;
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
             const uint32_t x = (uint32_t)z * 256u + threadIdx.x, q = x % Q;
-            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(c.y + (uint64_t)node[z] * c.ystride + 4u * q);
-            else pc[z].x = c.y[(uint64_t)node[z] * c.ystride + q];
+            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(yb + (uint64_t)node[z] * c.ystride + 4u * q);
+            else pc[z].x = yb[(uint64_t)node[z] * c.ystride + q];
         }
     }
     __device__ __forceinline__ void land(float* s_tile, uint32_t* s_tnode) {
@@ -530,7 +531,7 @@ struct SplitSample {
                 for (int t2 = 0; t2 < DIM; t2++) row[t2] = s_tile[x * DIM + t2];
             }
         } else {
-            load_row<DIM>(c.y + (uint64_t)x * c.ystride, 0u, row);
+            load_row<DIM>((c.yneg ? c.yneg : c.y) + (uint64_t)x * c.ystride, 0u, row);
         }
     }
     __device__ __forceinline__ void fetch(const CeDev& c, const float* s_tile, const uint32_t (&neg)[5]) {

@@ -231,7 +231,12 @@ __global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(c
     extern __shared__ __attribute__((aligned(16))) float sXs[];  // [n / 4][l][4] (KS = 2: at least 4 x 64 x 16 floats, the partial sums' exchange)
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, ks = tid >> 8;
     const int i = lane & 31, h = lane >> 5;
-    const uint64_t row = blockIdx.x * 128ull + (uint64_t)w * 32u + (uint64_t)i;
+    // Round 6: a workgroup walks over row blocks blockIdx.x, + gridDim.x, ... (KS = 1; the launcher caps the grid): the panel is staged
+    // ONCE per workgroup -- at 128 columns a block of 128 rows is 64 KB of A against 10 KB of panel and a barrier, and a wave lived for
+    // four trips: 0.52 of HBM on a 6.25 M x 128 matrix.
+    const uint64_t nblk = (m + 127) / 128;
+    uint64_t blk = blockIdx.x;
+    uint64_t row = blk * 128ull + (uint64_t)w * 32u + (uint64_t)i;
     // this wave's k range: [k_lo, k_hi), multiples of 8
     const uint64_t k_mid = KS == 2 ? (n / 16) * 8 : n;
     const uint64_t k_lo = ks ? k_mid : 0, k_hi = ks ? n : k_mid;
@@ -245,9 +250,12 @@ __global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(c
     if (full) issue(buf0, k_lo);  // the first trip's loads do not wait for the panel
     const int nrem = (int)((k_hi - k_lo - full * 8 * U) / 8);  // float4 loads of the remainder (< U): issued now, used last
     float4 rem[U > 1 ? U - 1 : 1];
+    auto issue_rem = [&]() {
 #pragma unroll
-    for (int u = 0; u < U - 1; u++)  // (u >= nrem: never used -- loaded from the start of the wave's k range, inside the row: with nrem == 0 the remainder's base is one past the row, for the last row of A past the allocation)
-        rem[u] = *reinterpret_cast<const float4*>(pa + (u < nrem ? k_lo + full * 8 * U + 8 * u : k_lo));
+        for (int u = 0; u < U - 1; u++)  // (u >= nrem: never used -- loaded from the start of the wave's k range, inside the row: with nrem == 0 the remainder's base is one past the row, for the last row of A past the allocation)
+            rem[u] = *reinterpret_cast<const float4*>(pa + (u < nrem ? k_lo + full * 8 * U + 8 * u : k_lo));
+    };
+    issue_rem();
     {
         constexpr int XL = 4096 / (256 * KS);  // at most 64 KB = 4096 float4: XL per thread
         const uint64_t nl = n * l;
@@ -273,8 +281,6 @@ __global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(c
     const bool jin = (uint32_t)i < l;                 // (the B operand's lane index j = lane % 32)
     const float* pb = sXs + ((uint64_t)h * l + (jin ? i : 0)) * 4;   // + (k / 4) * l * 4 for the trip's k
     f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.f;
     auto contract = [&](const float4 (&buf)[U], uint64_t k) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -285,57 +291,71 @@ __global__ void __launch_bounds__(256 * KS) dense_mul_panel_mfma_stream_kernel(c
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[u].w, b.w, acc, 0, 0, 0);
         }
     };
-    uint64_t k0 = k_lo, t = 0;
-    for (; t + 2 < full; t += 2, k0 += 16 * U) {  // trips t and t + 1, and a trip t + 2 exists: every issue is unconditional
-        issue(buf1, k0 + 8 * U);
-        __builtin_amdgcn_sched_barrier(0);
-        contract(buf0, k0);
-        issue(buf0, k0 + 16 * U);
-        __builtin_amdgcn_sched_barrier(0);
-        contract(buf1, k0 + 8 * U);
-    }
-    if (t + 2 == full) {
-        issue(buf1, k0 + 8 * U);
-        __builtin_amdgcn_sched_barrier(0);
-        contract(buf0, k0);
-        contract(buf1, k0 + 8 * U);
-        k0 += 16 * U;
-    } else if (t + 1 == full) {  // its data sit in buf0
-        contract(buf0, k0);
-        k0 += 8 * U;
-    }
+    for (;;) {   // one row block per turn (KS = 2: exactly one turn, the launcher gives every block its workgroup)
 #pragma unroll
-    for (int u = 0; u < U - 1; u++) {  // remainder (loaded at the start)
-        if (u < nrem) {
-            const float4 b = *reinterpret_cast<const float4*>(pb + (k0 + 8 * u) * l);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].w, b.w, acc, 0, 0, 0);
+        for (int q = 0; q < 16; q++) acc[q] = 0.f;
+        uint64_t k0 = k_lo, t = 0;
+        for (; t + 2 < full; t += 2, k0 += 16 * U) {  // trips t and t + 1, and a trip t + 2 exists: every issue is unconditional
+            issue(buf1, k0 + 8 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            contract(buf0, k0);
+            issue(buf0, k0 + 16 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            contract(buf1, k0 + 8 * U);
         }
-    }
-    if constexpr (KS == 2) {  // upper half -> LDS -> lower half adds (low + high: one fixed order)
-        __syncthreads();      // every wave is done with the panel
-        float* ex = sXs + ((uint64_t)w * 64 + lane) * 16;
-        if (ks) {
+        if (t + 2 == full) {
+            issue(buf1, k0 + 8 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            contract(buf0, k0);
+            contract(buf1, k0 + 8 * U);
+            k0 += 16 * U;
+        } else if (t + 1 == full) {  // its data sit in buf0
+            contract(buf0, k0);
+            k0 += 8 * U;
+        }
 #pragma unroll
-            for (int q = 0; q < 16; q += 4) *reinterpret_cast<float4*>(ex + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+        for (int u = 0; u < U - 1; u++) {  // remainder (loaded at the start)
+            if (u < nrem) {
+                const float4 b = *reinterpret_cast<const float4*>(pb + (k0 + 8 * u) * l);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rem[u].w, b.w, acc, 0, 0, 0);
+            }
         }
-        __syncthreads();
-        if (ks) return;
+        const uint64_t rb = blk * 128ull + (uint64_t)w * 32u;   // this turn's rows
+        if constexpr (KS == 1) {   // the next block's first loads travel while this block's results are stored
+            blk += gridDim.x;
+            if (blk < nblk) {
+                row = blk * 128ull + (uint64_t)w * 32u + (uint64_t)i;
+                pa = a + (row < m ? row : 0) * n + 4 * h;
+                if (full) issue(buf0, k_lo);
+                issue_rem();
+            }
+        }
+        if constexpr (KS == 2) {  // upper half -> LDS -> lower half adds (low + high: one fixed order)
+            __syncthreads();      // every wave is done with the panel
+            float* ex = sXs + ((uint64_t)w * 64 + lane) * 16;
+            if (ks) {
 #pragma unroll
-        for (int q = 0; q < 16; q += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(ex + q);
-            acc[q] += v.x; acc[q + 1] += v.y; acc[q + 2] += v.z; acc[q + 3] += v.w;
-        }
-    }
-    if (jin) {
-        const uint64_t rb = blockIdx.x * 128ull + (uint64_t)w * 32u;
+                for (int q = 0; q < 16; q += 4) *reinterpret_cast<float4*>(ex + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+            }
+            __syncthreads();
+            if (ks) return;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint64_t r = rb + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            if (r < m) y[r * l + i] = acc[q];
+            for (int q = 0; q < 16; q += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(ex + q);
+                acc[q] += v.x; acc[q + 1] += v.y; acc[q + 2] += v.z; acc[q + 3] += v.w;
+            }
         }
+        if (jin) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint64_t r = rb + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (r < m) y[r * l + i] = acc[q];
+            }
+        }
+        if (KS == 2 || blk >= nblk) break;
     }
 }
 
@@ -513,6 +533,61 @@ __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t
 }
 
 constexpr int kGramTile = 64;
+
+// out = y M for panels of <= 32 columns (round 6): 256 rows per workgroup and trip -- all of a trip's loads issued before the first LDS
+// store (as chol_apply_kernel), the rows transposed through LDS so that loads and stores stay coalesced, one thread per row with the
+// row in f64 registers and M read by LDS broadcast.  The 64-row form below ran at 1.0 TB/s on a 6.25 M x 20 panel (two barriers per 5 KB).
+__global__ void __launch_bounds__(256) apply_panel_rows_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ mat,
+                                                               uint32_t lout, float* __restrict__ out) {
+    extern __shared__ double smem_ap[];   // M[l * lout] | tile[256 x (w + 1)] f64, w = max(l, lout)
+    double* sm = smem_ap;
+    const uint32_t w = l > lout ? l : lout;
+    double* tile = smem_ap + (size_t)l * lout;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t idx = tid; idx < l * lout; idx += 256) sm[idx] = mat[idx];
+    const uint64_t ntiles = (rows + 255) / 256;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t r0 = t * 256;
+        const uint32_t nr = (uint32_t)(rows - r0 < 256 ? rows - r0 : 256);
+        const uint32_t tot = nr * l;
+        float tmp[32];
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+            const uint32_t idx = tid + (uint32_t)it * 256u;
+            tmp[it] = y[r0 * l + (idx < tot ? idx : 0u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // (the previous trip's stores out of `tile` are done; M is staged)
+#pragma unroll
+        for (int it = 0; it < 32; it++) {
+            const uint32_t idx = tid + (uint32_t)it * 256u;
+            if (idx < tot) tile[(idx / l) * (w + 1) + idx % l] = (double)tmp[it];
+        }
+        __syncthreads();
+        if (tid < nr) {
+            double* x = tile + (size_t)tid * (w + 1);
+            double xr[32], o[32];
+#pragma unroll
+            for (int c = 0; c < 32; c++) xr[c] = (uint32_t)c < l ? x[c] : 0.;
+#pragma unroll
+            for (int c2 = 0; c2 < 32; c2++) {
+                if ((uint32_t)c2 < lout) {  // uniform
+                    double a0 = 0., a1 = 0.;
+#pragma unroll
+                    for (int c = 0; c < 32; c++) {
+                        if ((uint32_t)c < l) { if (c & 1) a1 += xr[c] * sm[c * lout + c2]; else a0 += xr[c] * sm[c * lout + c2]; }
+                    }
+                    o[c2] = a0 + a1;
+                }
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 32; c2++)
+                if ((uint32_t)c2 < lout) x[c2] = o[c2];
+        }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nr * lout; idx += 256) out[r0 * lout + idx] = (float)tile[(idx / lout) * (w + 1) + idx % lout];
+    }
+}
 
 // out tile = y tile * M ; each workgroup owns kGramTile rows, staged through LDS so that in-place is safe
 __global__ void __launch_bounds__(256) apply_panel_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,
@@ -1095,10 +1170,16 @@ void mat_mul_panel(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l
             const size_t lds = std::max<size_t>(x_bytes, 4 * 64 * 16 * sizeof(float));
             // (U = 2 / 3 / 4 / 6 / 8 loads per trip: 37.4 / 37.4 / 36.2 / 36.4 / 36.7 us; the contraction split over two waves per row group,
             // 16 waves per CU: 39 us)
-            if (debug_knob("AE_SVD_KSPLIT"))
+            if (debug_knob("AE_SVD_KSPLIT")) {
                 hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, 2>), dim3(g2), dim3(512), lds, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
-            else
-                hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, 1>), dim3(g2), dim3(256), lds, stream(), a.values.p, a.nrows, a.ncols, d_x, d_y, l);
+            } else {
+                // (a workgroup walks over row blocks once there are more blocks than the device holds workgroups: the panel is staged once)
+                int per_cu = 2;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dense_mul_panel_mfma_stream_kernel<4, 1>, 256, lds);
+                const unsigned cap = debug_knob("AE_SVD_STREAM_GRID") ? (unsigned)atoi(debug_knob("AE_SVD_STREAM_GRID")) : 256u * (unsigned)std::max(1, per_cu);
+                hipLaunchKernelGGL((dense_mul_panel_mfma_stream_kernel<4, 1>), dim3(std::min(g2, std::max(1u, cap))), dim3(256), lds, stream(), a.values.p, a.nrows, a.ncols,
+                                   d_x, d_y, l);
+            }
             check_launch("dense_mul_panel_mfma_stream");
             return;
         }
@@ -1562,6 +1643,15 @@ void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
 }
 void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out) {
     if (d_out == d_y && lout > l) fail(AE_ERR_INVALID_ARG, "in-place apply needs lout <= l");
+    if (l <= 32 && lout <= 32 && rows >= 4096 && !debug_knob("AE_APPLY_OLD")) {   // (in place is safe: a trip reads its rows before it writes them)
+        const uint32_t w = std::max(l, lout);
+        const size_t smem = sizeof(double) * ((size_t)l * lout + 256 * (size_t)(w + 1));
+        const uint64_t nt = (rows + 255) / 256;
+        hipLaunchKernelGGL(apply_panel_rows_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, 1024))), dim3(256), smem, stream(), d_y, rows, l, d_m,
+                           lout, d_out);
+        check_launch("apply_panel_rows");
+        return;
+    }
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
     const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 8192));
     hipLaunchKernelGGL(apply_panel_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, d_m, lout, d_out);

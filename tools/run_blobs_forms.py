@@ -41,6 +41,9 @@ VARIANTS = {
     "pc15_ov": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15", AE_SL_OV_EVERY_SLICE="1")),
     "pc15_nolines": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CLASS_CAP="15", AE_SL_NO_LINES="1")),
     "pc11_nolines": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NO_LINES="1")),
+    "pc_snap1": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="1")),
+    "pc_snap4": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="4")),
+    "pc_snap16": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="16")),
     "ordered": (A.AE_CE_ORDERED, {}),
     "event": (A.AE_CE_EVENT, {}),
 }

@@ -69,7 +69,9 @@ cases = {"sequential": (A.AE_CE_SEQUENTIAL, {}), "sliced, no tile": (A.AE_CE_SLI
          "lambda 1 repeats left": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_NO_TILE": "1", "AE_SL_NO_FIT": "1", "AE_SL_LAMBDA": "1", "AE_SL_NO_SPREAD": "1"}),
          "thick 0.75": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1", "AE_SL_LAMBDA": "0.75"}),
          "thick 1.0": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1", "AE_SL_LAMBDA": "1.0"}),
-         "sliced classes, tile forced": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1"})}
+         "sliced classes, tile forced": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1"}),
+         # round 6: a tile of 128 rows for a workgroup's 256 samples (half a request per event instead of one)
+         "tile 128 rows, forced": (A.AE_CE_SLICED, {"AE_SL_FORCE_CLASSES": "1", "AE_SL_TILE_MIN": "1", "AE_SL_DBG": "256"})}
 only = os.environ.get("CASES")
 res = {}
 for name, (mode, knobs) in cases.items():
