@@ -371,7 +371,7 @@ struct TileFetch {
     static constexpr int Q = DIM % 4 == 0 ? DIM / 4 : DIM;  // pieces per row
     f4 pc[T::kPieces];
     uint32_t node[T::kPieces];
-    // rows: the tile's first `rows` rows are distinct draws, the others repeat them (A/B, AE_SL_DBG bit 256: a tile of 128 rows for 256 samples)
+    // rows: the tile's first `rows` rows are distinct draws, the others repeat them (the step kernel's hub tile: 128 draws for 256 samples)
     __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n, uint32_t rows = (uint32_t)TileShape<DIM>::kRows) {
         const uint32_t pool_at = hub ? __umulhi(pcg_hash(wkey), hub_pool_n - (uint32_t)T::kRows) : 0u;
 #pragma unroll
@@ -660,7 +660,11 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
             if (p + 1 < a.end) nx = a.ev[p + 1];
         }
         TileFetch<DIM> ft;
-        const uint32_t tile_rows = (a.dbg & 256) ? (uint32_t)TileShape<DIM>::kRows / 2u : (uint32_t)TileShape<DIM>::kRows;
+        // Hubness-weighted tiles take 128 draws of the pool for the workgroup's 256 samples (round 6: half a request per event instead of
+        // one; configs[3]'s graph 145 -> 139.5 ms per batch; ten seeds a side on 1 M Higgs-shaped points, 8 columns, tile forced: CE 0.9939
+        // against 0.9938 with 256 draws, median edge 1.010 +- 0.004 against 1.006 +- 0.003 -- profiles/r06/r6_tile128_bias.txt).  Window
+        // tiles keep their 16 windows (a sample takes no window twice: 8 would leave little choice).  AE_SL_DBG bit 256: 256 draws (A/B).
+        const uint32_t tile_rows = (hub && !(a.dbg & 256) && TileShape<DIM>::kRows == 256) ? 128u : (uint32_t)TileShape<DIM>::kRows;
         if constexpr (TILE && FIRST) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n, tile_rows);
         const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;   // (an idle lane addresses row 0: the lane-group stores carry `want` in the index's top bit)
         const bool half = act0 && ev_half(e.j);   // (multi-GPU) the source is another shard's: attraction on the target's row only

@@ -534,61 +534,8 @@ __global__ void reduce_chunks_kernel(const float* __restrict__ partial, uint64_t
 
 constexpr int kGramTile = 64;
 
-// out = y M for panels of <= 32 columns (round 6): 256 rows per workgroup and trip -- all of a trip's loads issued before the first LDS
-// store (as chol_apply_kernel), the rows transposed through LDS so that loads and stores stay coalesced, one thread per row with the
-// row in f64 registers and M read by LDS broadcast.  The 64-row form below ran at 1.0 TB/s on a 6.25 M x 20 panel (two barriers per 5 KB).
-__global__ void __launch_bounds__(256) apply_panel_rows_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l, const double* __restrict__ mat,
-                                                               uint32_t lout, float* __restrict__ out) {
-    extern __shared__ double smem_ap[];   // M[l * lout] | tile[256 x (w + 1)] f64, w = max(l, lout)
-    double* sm = smem_ap;
-    const uint32_t w = l > lout ? l : lout;
-    double* tile = smem_ap + (size_t)l * lout;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t idx = tid; idx < l * lout; idx += 256) sm[idx] = mat[idx];
-    const uint64_t ntiles = (rows + 255) / 256;
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint64_t r0 = t * 256;
-        const uint32_t nr = (uint32_t)(rows - r0 < 256 ? rows - r0 : 256);
-        const uint32_t tot = nr * l;
-        float tmp[32];
-#pragma unroll
-        for (int it = 0; it < 32; it++) {
-            const uint32_t idx = tid + (uint32_t)it * 256u;
-            tmp[it] = y[r0 * l + (idx < tot ? idx : 0u)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();   // (the previous trip's stores out of `tile` are done; M is staged)
-#pragma unroll
-        for (int it = 0; it < 32; it++) {
-            const uint32_t idx = tid + (uint32_t)it * 256u;
-            if (idx < tot) tile[(idx / l) * (w + 1) + idx % l] = (double)tmp[it];
-        }
-        __syncthreads();
-        if (tid < nr) {
-            double* x = tile + (size_t)tid * (w + 1);
-            double xr[32], o[32];
-#pragma unroll
-            for (int c = 0; c < 32; c++) xr[c] = (uint32_t)c < l ? x[c] : 0.;
-#pragma unroll
-            for (int c2 = 0; c2 < 32; c2++) {
-                if ((uint32_t)c2 < lout) {  // uniform
-                    double a0 = 0., a1 = 0.;
-#pragma unroll
-                    for (int c = 0; c < 32; c++) {
-                        if ((uint32_t)c < l) { if (c & 1) a1 += xr[c] * sm[c * lout + c2]; else a0 += xr[c] * sm[c * lout + c2]; }
-                    }
-                    o[c2] = a0 + a1;
-                }
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < 32; c2++)
-                if ((uint32_t)c2 < lout) x[c2] = o[c2];
-        }
-        __syncthreads();
-        for (uint32_t idx = tid; idx < nr * lout; idx += 256) out[r0 * lout + idx] = (float)tile[(idx / lout) * (w + 1) + idx % lout];
-    }
-}
-
+// (A row-per-thread form of the kernel below -- 256 rows per trip, the row in f64 registers, as chol_apply_kernel -- was measured in round 6
+// and is not kept: 1.30 ms against 1.01 ms on a 6.25 M x 20 panel.)
 // out tile = y tile * M ; each workgroup owns kGramTile rows, staged through LDS so that in-place is safe
 __global__ void __launch_bounds__(256) apply_panel_kernel(const float* __restrict__ y, uint64_t rows, uint32_t l,
                                                           const double* __restrict__ mat, uint32_t lout, float* __restrict__ out) {
@@ -1138,8 +1085,11 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
 }
 
 // may this product gather from a 128-byte-strided copy of its operand?  (the vec4 kernel's shapes; a panel beyond what the caches hold)
+// MEASURED, NOT ENABLED (round 6; AE_SPMM_WIDE under AE_DEBUG_KNOBS to repeat it): on the laplacian of an 11 M-node graph the product went
+// from 3.21 to 3.09 ms with the aligned copy, and chol_apply from 0.84 to 1.19 ms for writing it: 46.6 -> 47.7 ms per do_svd.  The
+// product is not bound by the lines it gathers alone (a wave per row: three dependent hops -- row pointers, indices, panel rows).
 static bool spmm_wide_ok(const ae_matrepr& a, uint32_t l) {
-    return a.is_csr && l % 4 == 0 && l < kWideLd && (uint64_t)std::max(a.nrows, a.ncols) * kWideLd * 4ull > (256ull << 20) && !debug_knob("AE_SPMM_NO_WIDE") &&
+    return debug_knob("AE_SPMM_WIDE") && a.is_csr && l % 4 == 0 && l < kWideLd && (uint64_t)std::max(a.nrows, a.ncols) * kWideLd * 4ull > (256ull << 20) &&
            !debug_knob("AE_SPMM_SCALAR");
 }
 static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l, uint32_t ldx = 0) {
@@ -1643,15 +1593,6 @@ void gram_panel(const float* d_y, uint64_t rows, uint32_t l, double* d_g) {
 }
 void apply_panel(const float* d_y, uint64_t rows, uint32_t l, const double* d_m, uint32_t lout, float* d_out) {
     if (d_out == d_y && lout > l) fail(AE_ERR_INVALID_ARG, "in-place apply needs lout <= l");
-    if (l <= 32 && lout <= 32 && rows >= 4096 && !debug_knob("AE_APPLY_OLD")) {   // (in place is safe: a trip reads its rows before it writes them)
-        const uint32_t w = std::max(l, lout);
-        const size_t smem = sizeof(double) * ((size_t)l * lout + 256 * (size_t)(w + 1));
-        const uint64_t nt = (rows + 255) / 256;
-        hipLaunchKernelGGL(apply_panel_rows_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, 1024))), dim3(256), smem, stream(), d_y, rows, l, d_m,
-                           lout, d_out);
-        check_launch("apply_panel_rows");
-        return;
-    }
     const uint64_t ntiles = (rows + kGramTile - 1) / kGramTile;
     const unsigned nblocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, 8192));
     hipLaunchKernelGGL(apply_panel_kernel, dim3(nblocks), dim3(256), 0, stream(), d_y, rows, l, d_m, lout, d_out);

@@ -137,12 +137,17 @@ enum {
        beyond (measured cross-over: ~29 M samples per batch on an exact kNN graph with hubs -- its under-filled time slices run as one
        launch each --, ~30 M on a lattice of uniform in-degree); both statistically faithful (as the reference's own threaded loop is
        not reproducible sample by sample either) -- the bit-exact replay of the reference's sequential loop is AE_CE_SEQUENTIAL,
-       by name.  How faithful, measured (48 seeds a side on the stiffest graph of the suite -- 60 k points in 64 blobs, k = 6, 2-D,
-       40 batches; ratios to AE_CE_SEQUENTIAL's means, 2 SE = 0.005 / 0.009): AE_CE_ORDERED final cross entropy 1.000-1.007, median edge
-       length 0.987-1.003; AE_CE_SLICED with one launch per class 0.998 / 1.003; AE_CE_SLICED where its slices run MERGED or through the
-       optimistic passes (what AE_CE_AUTO runs from 2^25 samples per batch on up to a few 10^8, and on the ranks of a sharded run from
-       4 ranks on): cross entropy +0.7 %, median edge -1.5 % (-2.7 % on a 400 k-node graph of that kind at 8 seeds) -- a RESOLVED bias of
-       these two forms on stiff 2-D graphs, not visible at 8 columns (profiles/r05/r5_fidelity_means.txt).  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
+       by name.  How faithful, measured (32-48 seeds a side on the stiffest graph of the suite -- 60 k points in 64 blobs, k = 6, 2-D,
+       40 batches; ratios to AE_CE_SEQUENTIAL's means, 2 SE = 0.7 % on the final cross entropy, 1.2 % on the median edge length;
+       profiles/r06/r6_blobs_forms.txt): AE_CE_ORDERED 1.002 / 0.994, AE_CE_EVENT 1.003 / 0.995, AE_CE_SLICED with one launch per class
+       0.997-1.002 / 0.992-1.006 whatever its palette -- all inside the standard error.  AE_CE_SLICED where its slices run MERGED (what
+       AE_CE_AUTO runs from 2^25 samples per batch up to a few 10^8, and on the ranks of a sharded run from 4 ranks on) or through the
+       optimistic passes: cross entropy +0.9 ... +1.1 %, median edge -1.6 ... -2.2 % -- a RESOLVED bias of these forms on stiff 2-D graphs
+       (not visible at 8 columns).  Its cause, isolated in round 6: the AGE of the negatives' rows.  A merged launch reads a slice's negatives
+       as the slice found them (half an event per node stale on average); with one launch per class they are a step old.  One launch per
+       class with its negatives read from a copy of the coordinates refreshed every 1 / 4 / 16 slices reproduces sign and size: cross
+       entropy 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820.  Thinner slices shrink it in proportion
+       (lambda 1/4: half), at twice the launches.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
        column adds +0 to every distance and never moves).  A sharded node range (several GPUs) runs AE_CE_SLICED whatever the
        batch size (see there; refused with AE_ERR_INVALID_ARG when more than 10 % of the range's edge mass crosses shards: the
        approximate AE_CE_HOGWILD still shards, by name).  ae_entropy_optim_get_ce_mode reports the choice. */
@@ -161,8 +166,9 @@ enum {
        communicator is attached).
        Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
        parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
-       standard error on graphs of 8 columns; on stiff 2-column graphs the merged-slice and optimistic forms sit at CE +0.7 %, median
-       edge -1.5 % against the exact mode at 48 seeds, one launch per class at -0.2 % / +0.3 %: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
+       standard error on graphs of 8 columns; on stiff 2-column graphs the merged-slice and optimistic forms sit at CE +1 %, median
+       edge -2 % against the exact mode at 32 seeds -- their negatives are a slice old --, one launch per class inside the standard
+       error: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
        sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
        the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
        exchange. */

@@ -91,8 +91,14 @@ def test_k6_blobs_without_hubness_40_batches(A):
     profiles/r05/r5_fidelity_means.txt): a small bias of that sign is real (a kept repeat of an edge runs a pass later, not back to back),
     floors 2 % / 5 % / 3 % / 5 %, said here.  The class path (forced: the cost model runs 60 k nodes optimistically) read CE +1.7 %, quartiles
     -2.5 ... -3 % over four seeds, +0.4 ... +0.8 % / -1 ... -2 % over sixteen (both launch forms; optimistic path +1.1 % / -1.4 ... -2.8 %;
-    r5_fidelity_means.txt): floors 1.5 % / 4 % / 2 % / 4 %, said here.  A four-seed mean of the median edge scatters by ~2 % on this graph
-    (the runs of these modes are not repeatable seed by seed: the overflow class is scheduled by races): EIGHT seeds for the class path."""
+    r5_fidelity_means.txt).  Round 6 resolved the forms with 32 seeds a side (profiles/r06/r6_blobs_forms.txt): ONE LAUNCH PER CLASS is the
+    exact mode's within a standard error whatever the palette (11 / 13 / 15 / 19 classes: CE 0.997-1.002, median edge 0.992-1.006; 2 SE 0.7 % /
+    1.2 %) -- floors 1 % / 3 % / 1 % / 3 %; MERGED SLICES carry a bias of CE +1.1 %, quartiles -2 ... -2.5 % (three 32-seed runs: CE 1.009-1.011,
+    median edge 0.978-0.981) -- floors 1.5 % / 3.5 % / 3 % / 3 % = what is claimed, and the same against one launch per class.  Its cause is
+    the AGE of the negatives' rows: a merged launch reads them as the slice found them; one launch per class with the negatives read from a
+    snapshot taken every 1 / 4 / 16 slices reproduces the sign and a dose-response (CE 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820).
+    A four-seed mean of the median edge scatters by ~2 % on this graph (the runs of these modes are not repeatable seed by seed: the overflow
+    class is scheduled by races): EIGHT seeds for the class path."""
     n = 60000
     g = A.KGraph.bruteforce_l2(_blobs(n), 6)
     indptr, nbr, _ = g.get_neighbours()
@@ -143,10 +149,12 @@ def test_k6_blobs_without_hubness_40_batches(A):
                     os.environ.pop(k2, None)
                 else:
                     os.environ[k2] = v2
+    floors = {"one launch per class": (0.01, 0.03, 0.01, 0.03), "merged slices": (0.015, 0.035, 0.03, 0.03)}   # (the claims of the docstring)
     for form, got in forced.items():
-        assert_means_close(got, exact, METRIC_NAMES, (0.015, 0.04, 0.02, 0.04), "k6 blobs, time-sliced, class path forced, " + form)   # (round 4, single runs: CE 1.012, quartiles 0.96-1.00)
-    # same events in the same order on every node: the two forms differ only in WHEN a finished row becomes visible to the negatives
-    assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, (0.01, 0.03, 0.01, 0.03), "k6 blobs, merged slices against one launch per class")
+        assert_means_close(got, exact, METRIC_NAMES, floors[form], "k6 blobs, time-sliced, class path forced, " + form)
+    # same events in the same order on every node: the two forms differ only in WHEN a finished row becomes visible to the negatives -- and
+    # that is what the merged form's bias is made of (the snapshot experiment of the docstring)
+    assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, floors["merged slices"], "k6 blobs, merged slices against one launch per class")
 
 
 @pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])

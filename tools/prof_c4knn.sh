@@ -3,8 +3,8 @@
 # configs[3]'s own graph (tools/run_scale_shapes.py c4_knn); counters in their own passes (FETCH_SIZE, WRITE_SIZE), as the guide prescribes
 set -u
 TAG=$1; SHAPE=${2:-c4_knn}
-export NEEDLE="sl_direct_kernel<8, 16, true, true>"
-case $SHAPE in c5*) export NEEDLE="sl_direct_kernel<16, 32, true, true>";; esac
+export NEEDLE="sl_direct_kernel<8, 16, true, true, 16>"   # (round 6: the node-line instantiation; <8, 16, true, true, 0> under AE_SL_NO_LINES)
+case $SHAPE in c5*) export NEEDLE="sl_direct_kernel<16, 32, true, true, 32>";; esac
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
