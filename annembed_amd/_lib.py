@@ -140,6 +140,7 @@ SIGNATURES = {
     "ae_entropy_optim_comm_bytes": [_vp, _P(_u64)],
     "ae_entropy_optim_slice_info": [_vp, _P(C.c_uint32), _P(C.c_double), _P(C.c_uint32), _P(C.c_uint32)],
     "ae_entropy_optim_slice_hub_info": [_vp, _P(C.c_uint32), _P(_f64)],
+    "ae_entropy_optim_slice_form": [_vp, _P(C.c_uint32)],
     "ae_entropy_optim_ce": [_vp, _P(_f64)],
     "ae_entropy_optim_gradient_iteration": [_vp, _u64, _f64, _u64],
     "ae_entropy_optim_gradient_iteration_lockstep": [_vp, C.c_uint32, _vp, _f64, _u64, C.c_uint32],

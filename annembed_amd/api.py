@@ -382,6 +382,13 @@ class EntropyOptim(_Handle):
         check(L.load().ae_entropy_optim_slice_hub_info(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def slice_form(self):
+        """AE_CE_SLICED: the launch form of the last batch -- 0 none yet, 1 one launch per class, 2 the same on node lines, 3 merged slices,
+        4 optimistic passes only (ae_entropy_optim_slice_form: how old the negatives' rows are)"""
+        v = C.c_uint32()
+        check(L.load().ae_entropy_optim_slice_form(self._h, C.byref(v)))
+        return v.value
+
     def ce_compute_threaded(self):
         v = C.c_double()
         check(L.load().ae_entropy_optim_ce(self._h, C.byref(v)))

@@ -1153,6 +1153,14 @@ int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim* o, uint32_t* max
     });
 }
 
+int32_t ae_entropy_optim_slice_form(const ae_entropy_optim* o, uint32_t* form) {
+    return guard([&] {
+        if (!o || !form) fail(AE_ERR_INVALID_ARG, "null argument");
+        if (o->params.ce_mode != AE_CE_SLICED) fail(AE_ERR_STATE, "the handle does not run AE_CE_SLICED");
+        *form = o->sl_last_form;
+    });
+}
+
 int32_t ae_entropy_optim_ce(ae_entropy_optim* o, double* ce) {
     return guard([&] {
         require_device();

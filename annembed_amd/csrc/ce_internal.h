@@ -137,6 +137,7 @@ struct ae_entropy_optim {
     DevBuf<uint32_t> sl_perm;
     DevBuf<float> sl_y;
     DevBuf<float> sl_neg_snap;                  // (experiment AE_SL_NEG_SNAPSHOT) the copy of the coordinates the negatives are read from
+    uint32_t sl_last_form = 0;                  // AE_SLICE_*: the launch form of the last batch (ae_entropy_optim_slice_form)
     uint32_t sl_y_lines = 0;                    // floats per node line whose static part (embedded scale, neighbour ids) sl_y currently holds; 0: none
     DevBuf<uint2> sl_hub_tab;                   // the NodeSampler's alias table in internal numbering
     uint32_t sl_max_in_degree = 0;              // largest in-degree of the graph (the longest chains)

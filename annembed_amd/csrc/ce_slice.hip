@@ -1013,6 +1013,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // embedded scale and neighbour ids behind its row, the step kernel fetches a source's line as ONE request (ce_slice_kernels.h: LineRec)
     const uint32_t line = (classes && !merged) ? sl_node_line(o) : 0u;
     const bool strided = words_in_rows || line != 0u;   // the internal copy's rows are further apart than the caller's
+    o->sl_last_form = !classes ? AE_SLICE_OPTIMISTIC : (merged ? AE_SLICE_MERGED : (line ? AE_SLICE_PER_CLASS_LINES : AE_SLICE_PER_CLASS));
     const uint32_t ystride = words_in_rows ? (o->dev.dim <= 4 ? 8u : 16u) : (line ? line : (uint32_t)o->dev.dim);
     // (floats from the start of a node's line: rows of 8 columns sit in the middle of their line, a set of words on either side --
     // ce_slice_kernels.h: LineFetch --; shorter rows at its start, the two sets behind them)

@@ -452,6 +452,13 @@ int32_t ae_entropy_optim_slice_info(const ae_entropy_optim *o, uint32_t *classes
    max_in_degree: the largest in-degree of the graph (the reference's hubness count, src/fromhnsw/hubness.rs:39-76);
    busiest_row_events_per_step: the expected length of the longest chain of a step (0 when everything runs optimistically). */
 int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim *o, uint32_t *max_in_degree, double *busiest_row_events_per_step);
+/* AE_CE_SLICED: the launch form of the handle's LAST batch (0 before the first) -- it decides how old the negatives' rows are, i.e. which
+   of the fidelity figures under AE_CE_AUTO applies: AE_SLICE_PER_CLASS (one launch per class and slice: negatives a step old; inside the
+   exact mode's standard error), AE_SLICE_PER_CLASS_LINES (the same on node lines: a source's row, scale and neighbour ids as one request),
+   AE_SLICE_MERGED (every class of a slice in one launch: negatives a slice old -- the resolved bias on stiff 2-D graphs),
+   AE_SLICE_OPTIMISTIC (no classes: every event through the optimistic passes; the same bias).  AE_ERR_STATE for another mode. */
+enum { AE_SLICE_NONE = 0, AE_SLICE_PER_CLASS = 1, AE_SLICE_PER_CLASS_LINES = 2, AE_SLICE_MERGED = 3, AE_SLICE_OPTIMISTIC = 4 };
+int32_t ae_entropy_optim_slice_form(const ae_entropy_optim *o, uint32_t *form);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);
 /* gradient_iteration_threaded(nb_sample, grad_step) (embedder.rs:1311-1315).  `iter` keys the RNG
