@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
 // whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
 // mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
+constexpr uint32_t kClsBits = 7;   // step keys of a batch with one launch per class: (slice << kClsBits) | class (<= 64 classes + the overflow class)
 // probability mass that arrives at every node (its out-edges carry 1): with it, the rate of the events that touch a node
 __global__ void __launch_bounds__(256) sl_in_mass_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, float* __restrict__ in_mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
@@ -225,6 +226,14 @@ __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, Edge
         if (m_gen != 0.) atomicAdd(&mass[0], m_gen);
         if (m_cross != 0.) atomicAdd(&mass[1], m_cross);
     }
+}
+// the class of the edge at every position of the target-grouped order: 0 overflow, 1 + class, 255 an edge this shard does not generate
+__global__ void __launch_bounds__(256) sl_class_key_kernel(uint64_t nnz, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sorted_group_key,
+                                                           const uint8_t* __restrict__ color, uint32_t* __restrict__ ckey) {
+    const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
+    if (x >= nnz) return;
+    const uint8_t c = color[perm[x]];
+    ckey[x] = sorted_group_key[x] == kDropKey ? 255u : (c == kOverflowColor || c == kNoColor ? 0u : 1u + (uint32_t)c);
 }
 __global__ void __launch_bounds__(256) sl_count_below_kernel(uint64_t nnz, const uint32_t* __restrict__ keys, uint32_t bound, unsigned long long* __restrict__ out) {
     unsigned long long c = 0;
@@ -329,9 +338,11 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     }
     for (uint32_t r = 0; r < k; r++) {
         uint32_t s = sorted ? SL(r) : __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
-        const uint32_t pos = cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes;
         if (cl >= classes && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
-        keys[o + r] = s * (classes + 1u) + pos;
+        // class_pos null: one launch per class -- the key is (slice << kClsBits) | class, sorted on its slice bits alone (the edges come in
+        // class order); else merged slices: slice * (classes + 1) + the class's POSITION in the slice's order
+        const uint32_t cls = cl < classes ? (uint32_t)cl : classes;
+        keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
         vals[o + r] = evv;
     }
 #undef SL
@@ -531,15 +542,15 @@ __global__ void __launch_bounds__(256) sl_chain_unlink_kernel(SliceArgs a, uint3
 // in/out form asks for a full copy of keys and values as temporary storage -- 7.6 GB at the C4 shape -- and its size follows the
 // batch's event count: whenever a batch set a new record the stream-ordered pool had to get a fresh block from the driver, 1.5-2 s,
 // a few times per run.  Found in round 3 as C4-shape batches of 300-900 ms among batches of 121 ms.)
-bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned end_bit) {
+bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned begin_bit, unsigned end_bit) {
     static_assert(sizeof(Event) == 12, "events are sorted as 12-byte values");
     rocprim::double_buffer<uint32_t> dk(keys_a, keys_b);
     rocprim::double_buffer<Event> dv(vals_a, vals_b);
     size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, 0, end_bit, stream()) != hipSuccess)
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, begin_bit, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
     if (o->sl_sort_tmp.n < tmp_bytes + 1) o->sl_sort_tmp.alloc(2 * tmp_bytes + 4096);  // (kept with the handle: no allocation in the batch)
-    if (rocprim::radix_sort_pairs(o->sl_sort_tmp.p, tmp_bytes, dk, dv, count, 0, end_bit, stream()) != hipSuccess)
+    if (rocprim::radix_sort_pairs(o->sl_sort_tmp.p, tmp_bytes, dk, dv, count, begin_bit, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs failed");
     return dk.current() == keys_b;
 }
@@ -622,11 +633,23 @@ static void slice_color_edges(ae_entropy_optim* o) {
         DevBuf<uint32_t> key_out, perm;
         key_out.alloc_pooled(nnz); perm.alloc_pooled(nnz);
         sort_pairs_u32_u32(group_key.p, key_out.p, ident.p, perm.p, nnz, 32);
-        // edges of this shard = keys below kDropKey (sorted: a binary search on the device would do; the count comes with the masses)
+        // ... then CLASS-MAJOR (round 6; a stable pass on 8 bits: inside a class the targets stay in hashed order): the events of a time slice
+        // then leave the generator already in class order, and a batch with one launch per class sorts its events by SLICE alone -- one
+        // radix pass instead of two (ce_slice_gradient_iteration)
+        {
+            DevBuf<uint32_t> ckey, perm_in;
+            ckey.alloc_pooled(nnz); perm_in.alloc_pooled(nnz);
+            hipLaunchKernelGGL(sl_class_key_kernel, dim3(grid), dim3(256), 0, stream(), nnz, (const uint32_t*)perm.p, (const uint32_t*)key_out.p,
+                               (const uint8_t*)o->sl_color.p, ckey.p);
+            AE_HIP(hipMemcpyAsync(perm_in.p, perm.p, sizeof(uint32_t) * nnz, hipMemcpyDeviceToDevice, stream()));
+            sort_pairs_u32_u32(ckey.p, key_out.p, perm_in.p, perm.p, nnz, 8);   // (key_out: the sorted class keys from here on)
+            sync();
+        }
+        // edges of this shard = class keys below 255 (sorted: a binary search on the device would do; the count comes with the masses)
         DevBuf<unsigned long long> cnt;
         cnt.alloc_pooled(1);
         cnt.zero();
-        hipLaunchKernelGGL(sl_count_below_kernel, dim3(grid_cap(nnz, 256, 2048)), dim3(256), 0, stream(), nnz, (const uint32_t*)key_out.p, kDropKey, cnt.p);
+        hipLaunchKernelGGL(sl_count_below_kernel, dim3(grid_cap(nnz, 256, 2048)), dim3(256), 0, stream(), nnz, (const uint32_t*)key_out.p, 255u, cnt.p);
         unsigned long long n_gen = 0;
         cnt.download(&n_gen, 1);
         o->sl_gen_edges = n_gen;
@@ -952,7 +975,22 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     const bool f64 = o->params.ce_precision != AE_PRECISION_F32;
     const uint32_t classes = o->sl_classes;
     const bool has_overflow = o->sl_ov_frac > 0.;
-    const uint64_t n_keys = (uint64_t)n_slices * (classes + 1u);
+    // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
+    // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
+    // Full steps stay one launch per class: they are bound by requests, and the dependency words would only add to them.
+    // (a sharded run: decided from what every rank shares -- the rank-agreed share of a segment and overflow fraction, as the slice
+    // count above -- because the form decides which label space the in-batch exchanges move: ranks on different sides of the
+    // threshold would read each other's rows in the wrong numbering)
+    const double step_events = classes ? seg_rank * (1.0 - ov_sched) / ((double)n_slices * (double)classes) : 0.;
+    const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
+                        (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
+    // The events' sort keys.  Merged slices: slice * (classes + 1) + the POSITION of the event's class in the slice's order (the launch
+    // walks the classes in that order).  One launch per class (round 6): (slice << kClsBits) | class -- the edges are generated in
+    // class order (slice_color_edges), so a stable sort on the SLICE bits alone leaves the events sorted by (slice, class): one radix
+    // pass of 8 bits for up to 256 slices where the composite key took two; the host walks a slice's classes in the drawn order.
+    const bool slice_keys = !merged && !debug_knob("AE_SL_COMPOSITE_KEYS");
+    const uint32_t kstride = slice_keys ? (1u << kClsBits) : classes + 1u;   // step pointers per slice
+    const uint64_t n_keys = (uint64_t)n_slices * kstride;
     if (n_keys >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: too many steps in a batch");
     o->rounds = segments * n_slices;
     const uint64_t ev_cap = (uint64_t)(seg_local + 8.0 * std::sqrt(seg_local) + 1024.0);
@@ -996,15 +1034,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (o->sl_class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) o->sl_class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
     unsigned kbits = 1;
     while (kbits < 32 && (n_keys >> kbits)) kbits++;
-    // Under-filled steps (a rank's share of a sharded batch, graphs of ~10^6 nodes): the classes of a slice in ONE launch, ordered node
-    // by node (sl_slice_kernel) -- a step of few events is a chain of latencies whatever it holds, and a slice is k + 5 of them.
-    // Full steps stay one launch per class: they are bound by requests, and the dependency words would only add to them.
-    // (a sharded run: decided from what every rank shares -- the rank-agreed share of a segment and overflow fraction, as the slice
-    // count above -- because the form decides which label space the in-batch exchanges move: ranks on different sides of the
-    // threshold would read each other's rows in the wrong numbering)
-    const double step_events = classes ? seg_rank * (1.0 - ov_sched) / ((double)n_slices * (double)classes) : 0.;
-    const bool merged = classes && classes <= kDepBits && !debug_knob("AE_SL_NO_MERGE") &&
-                        (debug_knob("AE_SL_MERGE") || step_events < kMergeBelow * sl_resident_events(o));
+    const unsigned kbegin = slice_keys ? kClsBits : 0u;   // (the class bits are in order already)
     // Rows of <= 8 columns keep the two sets of dependency words BEHIND the node's row in the batch's internal copy (rows 32 / 64
     // bytes apart instead of 8 ... 32): a word comes with the line of the row the event reads anyway and is wiped into the line it
     // writes anyway -- four of a merged event's six extra requests.
@@ -1212,10 +1242,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
-                           (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices), ov_every, o->sl_keys0.p, ev0);
+                           slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
+                           ov_every, o->sl_keys0.p, ev0);
         if (prof) sync();
         const double t_fill = wall();
-        const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbits);
+        const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
         const uint32_t* sorted_keys = in_second ? o->sl_keys1.p : o->sl_keys0.p;
         Event* sorted_ev = in_second ? ev1 : ev0;
         if (prof) sync();
@@ -1244,7 +1275,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             for (int pc = 0; pc < chains_dbg; pc++) AE_HIP(hipStreamWaitEvent(dbg_streams[pc], dbg_ev, 0));
         }
         for (uint32_t s = 0; s < n_slices; s++) {
-            const uint32_t* sp = hptr.data() + (size_t)s * (classes + 1u);
+            const uint32_t* sp = hptr.data() + (size_t)s * kstride;   // merged: by class POSITION; one launch per class: by class (sp[classes]: the overflow class)
+            const uint8_t* order = class_pos.data() + (size_t)s * std::max(1u, classes);   // (one launch per class) the slice's class order: a fresh uniform permutation
             if (neg_snapshot && s % (uint32_t)neg_snapshot == 0u) {   // (experiment: the negatives of the next `neg_snapshot` slices are read from the rows as they are NOW)
                 AE_HIP(hipMemcpyAsync(o->sl_neg_snap.p, cdev.y, sizeof(float) * n * ystride, hipMemcpyDeviceToDevice, stream()));
                 da.c.yneg = a.c.yneg = o->sl_neg_snap.p;
@@ -1268,7 +1300,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             } else if (chains_dbg > 1) {
                 // TIMING EXPERIMENT (AE_SL_CHAINS_DBG = P, wrong results): every step cut into P launches on P streams that are never joined
                 // inside the batch -- what P desynchronised chains of steps would cost if the graph fell into P independent parts
-                for (uint32_t q = 0; q < classes; q++) {
+                for (uint32_t qq = 0; qq < classes; qq++) {
+                    const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
                     if (sp[q + 1] == sp[q]) continue;
                     const uint32_t b0 = sp[q], cnt = sp[q + 1] - sp[q];
                     da.step_seq = step_seq++;
@@ -1284,7 +1317,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                     }
                 }
             } else
-            for (uint32_t q = 0; q < classes; q++) {  // the slice's matchings, in this slice's order
+            for (uint32_t qq = 0; qq < classes; qq++) {  // the slice's matchings, in this slice's order
+                const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
                 if (sp[q + 1] == sp[q]) continue;
                 da.begin = sp[q];
                 da.end = sp[q + 1];
