@@ -1874,9 +1874,26 @@ static bool direct_svd_from_q(ae_matrepr& a, DevBuf<float>& q, uint32_t l, bool 
                 for (uint32_t k = (uint32_t)i + 1; k < l; k++) v -= hR[(size_t)i * l + k] * mm[(size_t)k * l + c];
                 mm[(size_t)i * l + c] = v / hR[(size_t)i * l + i];
             }
-        AE_HIP(hipMemcpyAsync(ub, mm.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, stream()));
-        apply_panel(q.p, m, l, ub, l, out.u.p);
-        sync();   // (mm leaves scope)
+        if (l % 4 == 0 && !debug_knob("AE_SVD_APPLY_F64")) {
+            // U = Y M through the matrix-core product (Y as an m x l dense matrix, M as its l x l panel, f32 as the reference's own
+            // `q.dot(&u_b)`, svdapprox.rs:781): the f64 row-by-row kernel ran at 1 TB/s on a 6.25 M x 20 panel (1.0 ms of a 9.8 ms direct_svd)
+            std::vector<float> mf((size_t)l * l);
+            for (size_t idx = 0; idx < mf.size(); idx++) mf[idx] = (float)mm[idx];
+            DevBuf<float> dmf;
+            dmf.alloc_pooled((size_t)l * l);
+            dmf.upload(mf.data(), mf.size());
+            ae_matrepr view;   // (borrows q's storage: released from the view before it dies)
+            view.is_csr = false;
+            view.nrows = m; view.ncols = l; view.nnz = m * l;
+            view.values.p = q.p; view.values.n = m * l;
+            try { mat_mul_panel(view, dmf.p, out.u.p, l); } catch (...) { view.values.p = nullptr; view.values.n = 0; throw; }
+            view.values.p = nullptr; view.values.n = 0;
+            sync();   // (mf, dmf leave scope)
+        } else {
+            AE_HIP(hipMemcpyAsync(ub, mm.data(), sizeof(double) * l * l, hipMemcpyHostToDevice, stream()));
+            apply_panel(q.p, m, l, ub, l, out.u.p);
+            sync();   // (mm leaves scope)
+        }
     } else {
         apply_panel(q.p, m, l, ub, l, out.u.p);
     }

@@ -22,8 +22,8 @@ from annembed_amd import _lib as L  # noqa: E402
 if shape == "c3":
     gr = bench.exact_knn_graph(A, bench.higgs_shaped_points(1_650_000), 6, "Higgs-shaped points")
     n, k, d, hubw = 1_650_000, 6, 2, True
-elif shape == "c5":
-    gr = bench.config_graphs(A, "c5")
+elif shape in ("c5", "c5full"):
+    gr = bench.config_graphs(A, "c5_full" if shape == "c5full" else "c5")
     n, k, d, hubw = gr["n"], gr["k"], 16, False
 else:
     gr = bench.config_graphs(A, "c4")
@@ -52,6 +52,8 @@ for v in variants.split(";"):
         print("AB", json.dumps({"variant": name, "knobs": env, "ms_per_batch": [round(t * 1e3, 1) for t in ts[1:]], "mean_ms": round(float(np.mean(ts[1:])) * 1e3, 2),
                                 "ce_after": eo.ce_compute_threaded(), "classes": cl, "overflow": ov, "slices": slices}), flush=True)
         del eo
+    except A.AnnembedError as e:
+        print("AB", json.dumps({"variant": name, "knobs": env, "error": str(e)[:300]}), flush=True)
     finally:
         for kk in env:
             os.environ.pop(kk, None)
