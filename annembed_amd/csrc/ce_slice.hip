@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
 // whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
 // mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
-constexpr uint32_t kClsBits = 7;   // step keys of a batch with one launch per class: (slice << kClsBits) | class (<= 64 classes + the overflow class)
+constexpr uint32_t kClsBits = 7;   // step keys of a batch with one launch per class: (slice << kClsBits) | (0: the overflow class, 1 + c: class c <= 63)
 // probability mass that arrives at every node (its out-edges carry 1): with it, the rate of the events that touch a node
 __global__ void __launch_bounds__(256) sl_in_mass_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, float* __restrict__ in_mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
@@ -341,7 +341,9 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
         if (cl >= classes && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
         // class_pos null: one launch per class -- the key is (slice << kClsBits) | class, sorted on its slice bits alone (the edges come in
         // class order); else merged slices: slice * (classes + 1) + the class's POSITION in the slice's order
-        const uint32_t cls = cl < classes ? (uint32_t)cl : classes;
+        // (the overflow class is 0 there, class c is 1 + c: the ORDER the edges are generated in -- the sort on the slice bits is stable, the
+        // class bits must already ascend inside a slice)
+        const uint32_t cls = cl < classes ? 1u + (uint32_t)cl : 0u;
         keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
         vals[o + r] = evv;
     }
@@ -1275,7 +1277,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             for (int pc = 0; pc < chains_dbg; pc++) AE_HIP(hipStreamWaitEvent(dbg_streams[pc], dbg_ev, 0));
         }
         for (uint32_t s = 0; s < n_slices; s++) {
-            const uint32_t* sp = hptr.data() + (size_t)s * kstride;   // merged: by class POSITION; one launch per class: by class (sp[classes]: the overflow class)
+            // step pointers of the slice.  Merged: sp[q] = the class at POSITION q, sp[classes] the overflow class.  One launch per class:
+            // the overflow class FIRST (key 0: the order its edges are generated in), class c at sp[1 + c]
+            const uint32_t* sp = hptr.data() + (size_t)s * kstride;
+            const uint32_t* spc = slice_keys ? sp + 1 : sp;                       // spc[c] .. spc[c + 1]: class c (one launch per class) / position c (merged)
+            const uint32_t ov0 = slice_keys ? sp[0] : sp[classes], ov1 = slice_keys ? sp[1] : sp[classes + 1u];   // the overflow class's events
             const uint8_t* order = class_pos.data() + (size_t)s * std::max(1u, classes);   // (one launch per class) the slice's class order: a fresh uniform permutation
             if (neg_snapshot && s % (uint32_t)neg_snapshot == 0u) {   // (experiment: the negatives of the next `neg_snapshot` slices are read from the rows as they are NOW)
                 AE_HIP(hipMemcpyAsync(o->sl_neg_snap.p, cdev.y, sizeof(float) * n * ystride, hipMemcpyDeviceToDevice, stream()));
@@ -1302,8 +1308,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 // inside the batch -- what P desynchronised chains of steps would cost if the graph fell into P independent parts
                 for (uint32_t qq = 0; qq < classes; qq++) {
                     const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
-                    if (sp[q + 1] == sp[q]) continue;
-                    const uint32_t b0 = sp[q], cnt = sp[q + 1] - sp[q];
+                    if (spc[q + 1] == spc[q]) continue;
+                    const uint32_t b0 = spc[q], cnt = spc[q + 1] - spc[q];
                     da.step_seq = step_seq++;
                     for (int pc = 0; pc < chains_dbg; pc++) {
                         da.begin = b0 + (uint32_t)(((uint64_t)cnt * pc / chains_dbg) & ~63ull);
@@ -1319,9 +1325,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             } else
             for (uint32_t qq = 0; qq < classes; qq++) {  // the slice's matchings, in this slice's order
                 const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
-                if (sp[q + 1] == sp[q]) continue;
-                da.begin = sp[q];
-                da.end = sp[q + 1];
+                if (spc[q + 1] == spc[q]) continue;
+                da.begin = spc[q];
+                da.end = spc[q + 1];
                 const uint32_t cnt = da.end - da.begin;
                 // events per thread: one, unless the step is several times what the device holds at once (then the tile is amortised)
                 da.ept = ept_force ? ept_force : std::min(4u, std::max(1u, cnt / (256u * 3072u)));
@@ -1331,8 +1337,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 else AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
             }
             if (!has_overflow || (ov_every > 1u && s != std::min(n_slices - 1u, s - s % ov_every + ov_every / 2u))) { exchange_after(s); continue; }
-            a.f0 = sp[classes];
-            a.f1 = sp[classes + 1u];
+            a.f0 = ov0;
+            a.f1 = ov1;
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
             a.owner_mark = 0;
             hipLaunchKernelGGL(sl_mark_kernel, dim3(grid_full, kSub), dim3(256), 0, stream(), a);

@@ -49,7 +49,8 @@ for v in variants.split(";"):
             L.check(L.load().ae_synchronize())
             ts.append(time.perf_counter() - t0)
         cl, ov, _, slices = eo.slice_info()
-        print("AB", json.dumps({"variant": name, "knobs": env, "ms_per_batch": [round(t * 1e3, 1) for t in ts[1:]], "mean_ms": round(float(np.mean(ts[1:])) * 1e3, 2),
+        drawn = eo.samples_drawn()[0]
+        print("AB", json.dumps({"variant": name, "events_vs_expected_in_sigma": round((drawn - (steps + 1) * S) / np.sqrt((steps + 1) * S), 2), "knobs": env, "ms_per_batch": [round(t * 1e3, 1) for t in ts[1:]], "mean_ms": round(float(np.mean(ts[1:])) * 1e3, 2),
                                 "ce_after": eo.ce_compute_threaded(), "classes": cl, "overflow": ov, "slices": slices}), flush=True)
         del eo
     except A.AnnembedError as e:
