@@ -157,6 +157,50 @@ def test_k6_blobs_without_hubness_40_batches(A):
     assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, floors["merged slices"], "k6 blobs, merged slices against one launch per class")
 
 
+@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 3)])
+def test_class_path_runs_every_event_once_in_every_layout(A, knobs, form):
+    """One launch per class in its round-6 layouts -- node lines, the events sorted by their slice bits alone (the edges come in class order: the
+    overflow class FIRST, key 0) -- and in the layouts they replaced (composite (slice, class position) keys, dense rows + static records),
+    and merged slices: on a graph with hubs and a real overflow class (200 k Higgs-shaped points, 8 columns, k = 6, the class path forced)
+    every event of the batch's Poisson totals runs exactly once (the executed count within 6 sigma of nb_sample: a step pointer one class off
+    would drop or double 1/15 of a slice), `ae_entropy_optim_slice_form` names the form, and the layouts end at the same cross entropy (2 %:
+    one run against one run of a mode scheduled by races)."""
+    n = 200000
+    g = A.KGraph.bruteforce_l2(_blobs(n), 6)
+    npar = A.to_proba_edges(g, 1.0, 1.0)
+    y0 = A.set_data_box(np.random.default_rng(3).normal(size=(n, 8)).astype(np.float32), 10.0)
+    hub = g.hubness()
+
+    def run(extra):
+        env = dict({"AE_DEBUG_KNOBS": "1", "AE_SL_FORCE_CLASSES": "1"}, **extra)
+        if "AE_SL_MERGE" not in env:
+            env["AE_SL_NO_MERGE"] = "1"
+        saved = {k2: os.environ.get(k2) for k2 in env}
+        os.environ.update(env)
+        try:
+            eo = A.EntropyOptim(g, npar, A.EmbedderParams(asked_dim=8, nb_grad_batch=10, ce_mode=A.AE_CE_SLICED, grad_step=1.0, hubness_weighting=True), y0, hub_counts=hub)
+            S = 10 * eo.get_nb_edges()
+            for it in (1, 2, 3):
+                eo.gradient_iteration_threaded(S, 1.0 - it / 10, it)
+            drawn, _ = eo.samples_drawn()
+            classes, ov, _, _ = eo.slice_info()
+            return drawn, 3 * S, classes, ov, eo.slice_form(), eo.ce_compute_threaded(), eo.get_embedded()
+        finally:
+            for k2, v2 in saved.items():
+                if v2 is None:
+                    os.environ.pop(k2, None)
+                else:
+                    os.environ[k2] = v2
+    drawn, want, classes, ov, got_form, ce, y = run(knobs)
+    assert classes >= 11 and 0.0 < ov < 0.05, (classes, ov)
+    assert got_form == form, (got_form, form)
+    assert np.isfinite(y).all()
+    assert abs(drawn - want) < 6 * np.sqrt(want), (drawn, want, (drawn - want) / np.sqrt(want))
+    if knobs:
+        _, _, _, _, _, ce0, _ = run({})
+        assert abs(ce - ce0) < 0.02 * ce0, (ce, ce0)
+
+
 @pytest.mark.parametrize("k,nb_batch", [(6, 30), (12, 25)])
 def test_c1_c2_full_schedule_from_dmap_init(A, k, nb_batch):
     """configs[0] / configs[1] shapes -- 60 000 x 784 MNIST-shaped points, k = 6 / 30 batches (examples/mnist_digits.rs:92-109)
