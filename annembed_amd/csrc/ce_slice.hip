@@ -303,6 +303,10 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 // a time: key from the stage, the record from its lane by a shuffle, both stored coalesced.  A wave whose stretch does not fit the stage
 // (heavy edges) writes directly, as before (`staged` 0: A/B).
 constexpr uint32_t kFillStage = 1024;   // events a wave stages
+// (Round 6: the same kernel with its writes through a wave-private LDS stage -- every thread drops its keys at its run's place, the wave
+// then stores the stretch 64 places at a time, the records fetched from their lanes by shuffles: fully coalesced stores -- was built and
+// measured: 134.2 against 134.2 ms per configs[3] batch.  The kernel is not bound by how its stores coalesce; commit "event fill through a
+// wave-private LDS stage" holds the code.)
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
