@@ -296,33 +296,23 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 // 1/4: 0.995 / 0.991, 1/2: 1.008 / 0.967, 1: 1.051 / 0.949 -- clipped attractions are violent (a pair moves to 2 % of its distance),
 // so how two of them on one edge are spaced matters although < 3 % of the events are repeats.  `spread` 2 (the default): a repeat
 // stays with probability p_stay and moves on otherwise.
-// Round 6: the writes go through a wave-private LDS stage.  A thread's events are a run of ~10 consecutive array places, so a wave's 64 runs are
-// one contiguous stretch of ~640 events; written thread by thread every store instruction scatters 64 small pieces over that stretch (the
-// kernel ran at 1.15 TB/s of writes: 9.2 ms of a 133 ms configs[3] batch).  Now every thread drops its KEYS into the stage at its run's place
-// together with its lane number (the values of an edge's events are all the same record), and the wave then walks the stretch 64 places at
-// a time: key from the stage, the record from its lane by a shuffle, both stored coalesced.  A wave whose stretch does not fit the stage
-// (heavy edges) writes directly, as before (`staged` 0: A/B).
-constexpr uint32_t kFillStage = 1024;   // events a wave stages
 // (Round 6: the same kernel with its writes through a wave-private LDS stage -- every thread drops its keys at its run's place, the wave
 // then stores the stretch 64 places at a time, the records fetched from their lanes by shuffles: fully coalesced stores -- was built and
-// measured: 134.2 against 134.2 ms per configs[3] batch.  The kernel is not bound by how its stores coalesce; commit "event fill through a
-// wave-private LDS stage" holds the code.)
+// measured: 134.2 against 134.2 ms per configs[3] batch.  The kernel is not bound by how its stores coalesce; commit d82df92 holds the code.)
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
-                                                      uint32_t ov_every, uint32_t* __restrict__ keys, Event* __restrict__ vals, int staged) {
+                                                      uint32_t ov_every, uint32_t* __restrict__ keys, Event* __restrict__ vals) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    const bool valid = e < n_gen;
-    const uint32_t k = valid ? cnt[e] : 0u, o = valid ? offs[e] : 0u;
+    if (e >= n_gen) return;
+    const uint32_t k = cnt[e], o = offs[e];
+    if (!k) return;
     const uint32_t tk = pcg_hash(round_hash_key(key, c.seed) ^ kTagSlTime);
-    const uint8_t cl = valid ? color[e] : (uint8_t)0;
-    EdgeRec er{0u, 0.f, 0u, 0u};
-    if (valid) er = erec[e];
+    const uint8_t cl = color[e];
+    const EdgeRec er = erec[e];
     const Event evv{er.im, er.j | (er.flags & kHalfEvent), er.w};
     constexpr uint32_t kSortMax = 24;
     __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge (dynamic indexing: LDS, not scratch)
-    __shared__ uint32_t s_stage_key[4 * kFillStage];
-    __shared__ uint8_t s_stage_lane[4 * kFillStage];
     uint32_t* sl = s_sl + threadIdx.x;
 #define SL(r) sl[(r) * 256u]
     const bool sorted = spread && k > 1 && k <= kSortMax && k <= n_slices;
@@ -349,13 +339,6 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
             for (uint32_t r = k - 1; r > 0 && SL(r - 1) > SL(r); r--) SL(r - 1) = SL(r);
         }
     }
-    // the wave's stretch of the event arrays: [base, end) (the edges of a wave are consecutive, so are their runs)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t base = (valid && k) ? o : 0xFFFFFFFFu, end = (valid && k) ? o + k : 0u;
-    for (int off = 32; off > 0; off >>= 1) { base = min(base, (uint32_t)__shfl_xor((int)base, off)); end = max(end, (uint32_t)__shfl_xor((int)end, off)); }
-    const bool stage = staged && end > base && end - base <= kFillStage;   // (uniform over the wave)
-    uint32_t* st_key = s_stage_key + wv * kFillStage;
-    uint8_t* st_lane = s_stage_lane + wv * kFillStage;
     for (uint32_t r = 0; r < k; r++) {
         uint32_t s = sorted ? SL(r) : __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
         if (cl >= classes && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
@@ -364,35 +347,10 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
         // (the overflow class is 0 there, class c is 1 + c: the ORDER the edges are generated in -- the sort on the slice bits is stable, the
         // class bits must already ascend inside a slice)
         const uint32_t cls = cl < classes ? 1u + (uint32_t)cl : 0u;
-        const uint32_t kv = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
-        if (stage) {
-            st_key[o - base + r] = kv;
-            st_lane[o - base + r] = (uint8_t)lane;
-        } else {
-            keys[o + r] = kv;
-            vals[o + r] = evv;
-        }
+        keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
+        vals[o + r] = evv;
     }
 #undef SL
-    if (stage) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (a wave's LDS operations execute in program order)
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t tot = end - base;
-        for (uint32_t p0 = 0; p0 < tot; p0 += 64u) {   // (uniform trip count: every lane takes part in the shuffles)
-            const uint32_t p = p0 + (uint32_t)lane;
-            const bool in = p < tot;
-            const uint32_t kv = in ? st_key[p] : 0u;
-            const int src = in ? (int)st_lane[p] : lane;
-            Event ev;
-            ev.im = (uint32_t)__shfl((int)evv.im, src);
-            ev.j = (uint32_t)__shfl((int)evv.j, src);
-            ev.w = __shfl(evv.w, src);
-            if (in) {
-                keys[base + p] = kv;
-                vals[base + p] = ev;
-            }
-        }
-    }
 }
 // (hubness weighting) the batch's pool of i.i.d. draws of the NodeSampler (embedder.rs:927-930), ce_slice_kernels.h: TileFetch
 __global__ void __launch_bounds__(256) sl_hub_pool_kernel(CeDev c, uint32_t key, uint32_t count, uint32_t* __restrict__ pool) {
@@ -1290,7 +1248,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
                            slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
-                           ov_every, o->sl_keys0.p, ev0, debug_knob("AE_SL_FILL_DIRECT") ? 0 : 1);
+                           ov_every, o->sl_keys0.p, ev0);
         if (prof) sync();
         const double t_fill = wall();
         const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
