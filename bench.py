@@ -554,8 +554,9 @@ def compact_line(full):
         out["parity_mode"] = {"ce_mode": "AE_CE_SEQUENTIAL (bit-exact vs the oracle)", "ms_per_step": pm["ms_per_step"], "points_per_s": pm["points_per_s"],
                               "frac": pm["roofline"]["frac"]}
     for k in ("svd_init", "svd_init_c4", "svd_dense", "svd_dense_c5", "svd_dense_c5_full"):
-        if full.get(k):
-            out[k] = {kk: vv for kk, vv in full[k].items() if not isinstance(vv, (dict, list)) and not (isinstance(vv, str) and len(vv) > 80)}
+        if full.get(k):   # (scalars only, five significant digits, without the constants: the details line has everything)
+            out[k] = {kk: (float("%.5g" % vv) if isinstance(vv, float) else vv) for kk, vv in full[k].items()
+                      if not isinstance(vv, (dict, list)) and not (isinstance(vv, str) and len(vv) > 80) and kk not in ("mfma_f32_peak_tflops", "upload_s", "sigma19")}
     shapes = full.get("scale_shapes") or {}
     brief = {}
     for name, sh in shapes.items():
@@ -565,10 +566,13 @@ def compact_line(full):
             brief[name] = {"ms": round(dm["ms_per_step"], 2), "points_per_s": round(dm["points_per_s"]), "frac": round(dm["roofline"]["frac"], 4),
                            "frac_whole_batch": round(dm["roofline"]["frac_whole_batch"], 4)}
             if form:   # (merged / optimistic: the published bias on stiff 2-D graphs applies)
-                brief[name]["form"] = {"one launch per class": "per_class", "one launch per class, node lines": "per_class_lines", "merged slices": "merged (biased: see faithful)",
-                                       "optimistic passes": "optimistic (biased: see faithful)"}.get(form, form)
+                brief[name]["form"] = {"one launch per class": "per_class", "one launch per class, node lines": "lines", "merged slices": "merged*",
+                                       "optimistic passes": "optimistic*"}.get(form, form)
     if brief:
         out["scale_shapes"] = brief
+        if any(str(v.get("form", "")).endswith("*") for v in brief.values()):
+            out["form_note"] = "*: negatives a slice old: CE +1 %, median edge -2 % on stiff 2-D graphs (DESIGN 4.3b)"
+
     if full.get("end_to_end"):
         out["end_to_end"] = {k: v for k, v in full["end_to_end"].items() if k != "note"}
     for k in ("per_rank_batch_ms_max", "faithful", "samples_per_s", "ce_before", "ce_after", "details"):
