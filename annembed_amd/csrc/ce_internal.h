@@ -137,15 +137,6 @@ struct ae_entropy_optim {
     DevBuf<uint32_t> sl_perm;
     DevBuf<float> sl_y;
     DevBuf<float> sl_neg_snap;                  // (experiment AE_SL_NEG_SNAPSHOT) the copy of the coordinates the negatives are read from
-    // TWO CHAINS of steps side by side (round 6; one device, one launch per class): the nodes in two parts with next to no edge mass between
-    // them (partition.hip), part 0 = internal numbers [0, sl_chain_n0); the steps of the two parts run on two streams, joined at the slice
-    // boundaries; the few edges between the parts run with the overflow class.  ce_slice.hip.
-    DevBuf<uint32_t> sl_chain_part_perm;        // position of every node (caller's label) in the partition's order: part = position >= sl_chain_n0
-    uint64_t sl_chain_n0 = 0;                   // 0: no partition
-    double sl_chain_cross = 0.;                 // share of the edge mass between the parts
-    bool sl_chains = false;                     // the edges were cut for two chains (the class path, full steps)
-    hipStream_t sl_chain_stream = nullptr;
-    hipEvent_t sl_chain_ev[2] = {nullptr, nullptr};
     uint32_t sl_last_form = 0;                  // AE_SLICE_*: the launch form of the last batch (ae_entropy_optim_slice_form)
     uint32_t sl_y_lines = 0;                    // floats per node line whose static part (embedded scale, neighbour ids) sl_y currently holds; 0: none
     DevBuf<uint2> sl_hub_tab;                   // the NodeSampler's alias table in internal numbering
@@ -173,8 +164,6 @@ struct ae_entropy_optim {
         for (hipEvent_t e : {df_ahead.start, df_ahead.ran, df_ahead.prepared}) if (e) (void)hipEventDestroy(e);
         for (auto& e : df_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-        if (sl_chain_stream) { (void)hipStreamSynchronize(sl_chain_stream); (void)hipStreamDestroy(sl_chain_stream); }
-        for (hipEvent_t e : sl_chain_ev) if (e) (void)hipEventDestroy(e);
     }
 };
 

@@ -176,10 +176,7 @@ __global__ void __launch_bounds__(256) sl_class_mass_kernel(uint64_t nnz, const 
 // whose target it owns while the source is another shard's; every other edge gets the key kDropKey (sorted to the end and cut off).
 // mass: [0] the edges this shard generates, [1] its cross-shard edges (one end here, one elsewhere).
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
-// step keys of a batch with one launch per class: (slice << kClsBits) | (class key << 1) | part, class key 0: the overflow class, 1 + c: class c <= 63;
-// part: which of the two chains the edge belongs to (0 without chains, and for the overflow class)
-constexpr uint32_t kClsBits = 8;
-__host__ __device__ __forceinline__ uint32_t step_key_low(uint32_t cls_key, uint32_t part) { return (cls_key << 1) | part; }
+constexpr uint32_t kClsBits = 7;   // step keys of a batch with one launch per class: (slice << kClsBits) | (0: the overflow class, 1 + c: class c <= 63)
 // probability mass that arrives at every node (its out-edges carry 1): with it, the rate of the events that touch a node
 __global__ void __launch_bounds__(256) sl_in_mass_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, float* __restrict__ in_mass) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
@@ -231,31 +228,12 @@ __global__ void __launch_bounds__(256) sl_color_finish_kernel(uint64_t nnz, Edge
     }
 }
 // the class of the edge at every position of the target-grouped order: 0 overflow, 1 + class, 255 an edge this shard does not generate
-// (part_perm / n0: the two chains' partition, or null / 0: the part of a class edge = the part of its target = the part of its source)
 __global__ void __launch_bounds__(256) sl_class_key_kernel(uint64_t nnz, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sorted_group_key,
-                                                           const uint8_t* __restrict__ color, const EdgeRec* __restrict__ erec,
-                                                           const uint32_t* __restrict__ part_perm, uint64_t n0, uint32_t* __restrict__ ckey) {
+                                                           const uint8_t* __restrict__ color, uint32_t* __restrict__ ckey) {
     const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
     if (x >= nnz) return;
-    const uint32_t e = perm[x];
-    const uint8_t c = color[e];
-    const uint32_t cls_key = c == kOverflowColor || c == kNoColor ? 0u : 1u + (uint32_t)c;
-    const uint32_t part = (n0 && cls_key && part_perm[erec[e].j] >= n0) ? 1u : 0u;
-    ckey[x] = sorted_group_key[x] == kDropKey ? 255u : step_key_low(cls_key, part);
-}
-// two chains: an edge between the parts runs with the overflow class (after the slice's steps, both chains joined)
-__global__ void __launch_bounds__(256) sl_cross_overflow_kernel(uint64_t nnz, const EdgeRec* __restrict__ erec, const uint32_t* __restrict__ part_perm, uint64_t n0,
-                                                                uint8_t* __restrict__ color) {
-    const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    if (e >= nnz) return;
-    const EdgeRec r = erec[e];
-    if ((part_perm[r.im >> 5] >= n0) != (part_perm[r.j] >= n0)) color[e] = kOverflowColor;
-}
-// internal numbering with two chains: the part of the node at every place of the random order
-__global__ void __launch_bounds__(256) sl_perm_part_kernel(uint64_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ part_perm, uint64_t n0,
-                                                           uint32_t* __restrict__ block) {
-    const uint64_t x = blockIdx.x * 256ull + threadIdx.x;
-    if (x < n) block[x] = part_perm[order[x]] >= n0 ? 1u : 0u;
+    const uint8_t c = color[perm[x]];
+    ckey[x] = sorted_group_key[x] == kDropKey ? 255u : (c == kOverflowColor || c == kNoColor ? 0u : 1u + (uint32_t)c);
 }
 __global__ void __launch_bounds__(256) sl_count_below_kernel(uint64_t nnz, const uint32_t* __restrict__ keys, uint32_t bound, unsigned long long* __restrict__ out) {
     unsigned long long c = 0;
@@ -324,7 +302,7 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
-                                                      uint32_t ov_every, uint32_t chain_n0, uint32_t* __restrict__ keys, Event* __restrict__ vals) {
+                                                      uint32_t ov_every, uint32_t* __restrict__ keys, Event* __restrict__ vals) {
     const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
     if (e >= n_gen) return;
     const uint32_t k = cnt[e], o = offs[e];
@@ -368,10 +346,8 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
         // class order); else merged slices: slice * (classes + 1) + the class's POSITION in the slice's order
         // (the overflow class is 0 there, class c is 1 + c: the ORDER the edges are generated in -- the sort on the slice bits is stable, the
         // class bits must already ascend inside a slice)
-        // (chain_n0: two chains -- the internal numbers below it are part 0; a class edge lies inside one part)
         const uint32_t cls = cl < classes ? 1u + (uint32_t)cl : 0u;
-        const uint32_t part = (chain_n0 && cls && ev_node(er.j) >= chain_n0) ? 1u : 0u;
-        keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | step_key_low(cls, part);
+        keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
         vals[o + r] = evv;
     }
 #undef SL
@@ -618,7 +594,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
     o->sl_gen_edges = nnz;
     o->sl_gen_mass = (double)n;
     o->sl_cross_frac = 0.;
-    o->sl_chains = false;
     o->sl_erec_gen.release();
     o->sl_color_gen.release();
     const unsigned grid = blocks_for(nnz, 256), ngrid = blocks_for(n, 256);
@@ -670,8 +645,7 @@ static void slice_color_edges(ae_entropy_optim* o) {
             DevBuf<uint32_t> ckey, perm_in;
             ckey.alloc_pooled(nnz); perm_in.alloc_pooled(nnz);
             hipLaunchKernelGGL(sl_class_key_kernel, dim3(grid), dim3(256), 0, stream(), nnz, (const uint32_t*)perm.p, (const uint32_t*)key_out.p,
-                               (const uint8_t*)o->sl_color.p, (const EdgeRec*)erec, (const uint32_t*)(o->sl_chains ? o->sl_chain_part_perm.p : nullptr),
-                               o->sl_chains ? o->sl_chain_n0 : 0ull, ckey.p);
+                               (const uint8_t*)o->sl_color.p, ckey.p);
             AE_HIP(hipMemcpyAsync(perm_in.p, perm.p, sizeof(uint32_t) * nnz, hipMemcpyDeviceToDevice, stream()));
             sort_pairs_u32_u32(ckey.p, key_out.p, perm_in.p, perm.p, nnz, 8);   // (key_out: the sorted class keys from here on)
             sync();
@@ -797,14 +771,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
     }
     hipLaunchKernelGGL(sl_color_giveup_kernel, dim3(grid), dim3(256), 0, stream(), nnz, o->sl_color.p);
     check_launch("sl_color");
-    // Two chains (ce_slice_prepare found a partition; full steps only: merged slices overlap their classes already): the few edges between
-    // the parts leave their classes for the overflow class
-    o->sl_chains = o->sl_chain_n0 != 0 && !merged_regime;
-    if (o->sl_chains) {
-        hipLaunchKernelGGL(sl_cross_overflow_kernel, dim3(grid), dim3(256), 0, stream(), nnz, (const EdgeRec*)erec, (const uint32_t*)o->sl_chain_part_perm.p,
-                           o->sl_chain_n0, o->sl_color.p);
-        check_launch("sl_cross_overflow");
-    }
     DevBuf<double> mass;
     mass.alloc_pooled(kMaxClasses + 1);
     mass.zero();
@@ -839,28 +805,6 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     // (a sharded range: once the communicator is attached and every rank's range is known -- entropy_optim_attach_comm prepares again --
     // the same relabelling on every rank, inside every rank's range: a rank's rows stay one contiguous run, the exchanges stay in place)
     const bool ranges_known = !whole_range && o->comm && o->comm_ranges.size() >= 4;
-    // TWO CHAINS (round 6).  A full step leaves ~12 of its ~33 us to latencies that overlap with nothing; two chains of steps on
-    // two streams overlap them (timed before it was built, every step cut in two: configs[3]'s graph 145 -> 134 ms, a configs[4] shard 260 ->
-    // 234; four chains lose: 174 / 379).  What makes it legal is a graph property: the nodes in two parts with next to no edge mass between
-    // them (the library's own partitioner: connected components packed whole, what must be cut bisected along the graph-smoothed current
-    // coordinates) -- events inside different parts share no node, so their steps need no order between them; the few edges between the
-    // parts run with the overflow class, both chains joined.  Only where the steps are full (slice_color_edges decides) and the cut is thin.
-    o->sl_chain_n0 = 0;
-    o->sl_chain_part_perm.release();
-    if (whole_range && !o->comm && !debug_knob("AE_SL_NO_CHAINS") && !debug_knob("AE_SL_LABEL_ORDER") && (g->n >= (2ull << 20) || debug_knob("AE_SL_CHAINS"))) {
-        try {
-            Partition part;
-            partition_nodes_device(g, o->np->proba.p, o->dev.y, (uint32_t)o->dev.dim, (uint32_t)o->dev.dim, 2u, part);
-            partition_cross_mass_device(g, o->np->proba.p, part);
-            if (part.ranges.size() == 4 && part.cross_mass <= 0.02 && part.imbalance <= 0.05) {
-                o->sl_chain_part_perm = std::move(part.perm);
-                o->sl_chain_n0 = part.ranges[1];
-                o->sl_chain_cross = part.cross_mass;
-            }
-        } catch (const Error&) {
-            // (a graph the partitioner refuses: one chain)
-        }
-    }
     if ((whole_range || ranges_known) && !debug_knob("AE_SL_LABEL_ORDER")) {
         DevBuf<uint32_t> keys, keys_out, ident, order;
         keys.alloc_pooled(g->n); keys_out.alloc_pooled(g->n); ident.alloc_pooled(g->n); order.alloc_pooled(g->n);
@@ -878,13 +822,6 @@ void ce_slice_prepare(ae_entropy_optim* o) {
             while ((1u << bits) < world) bits++;
             sort_pairs_u32_u32(keys.p, keys_out.p, order.p, ident.p, g->n, bits);
             sync();   // (d_ranges is read by the kernel above)
-            std::swap(order.p, ident.p);
-        }
-        if (o->sl_chain_n0) {   // two chains: part 0 first -- a stable 1-bit sort: the random order survives inside either part
-            hipLaunchKernelGGL(sl_perm_part_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)order.p,
-                               (const uint32_t*)o->sl_chain_part_perm.p, o->sl_chain_n0, keys.p);
-            sort_pairs_u32_u32(keys.p, keys_out.p, order.p, ident.p, g->n, 1);
-            sync();
             std::swap(order.p, ident.p);
         }
         o->sl_perm.alloc(g->n);
@@ -1058,15 +995,6 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     // pass of 8 bits for up to 256 slices where the composite key took two; the host walks a slice's classes in the drawn order.
     const bool slice_keys = !merged && !debug_knob("AE_SL_COMPOSITE_KEYS");
     const uint32_t kstride = slice_keys ? (1u << kClsBits) : classes + 1u;   // step pointers per slice
-    // two chains of steps side by side (ce_slice_prepare / slice_color_edges cut the graph for them)
-    const bool chains = o->sl_chains && slice_keys && classes && o->sl_perm.n && !debug_knob("AE_SL_CHAINS_DBG") && !debug_knob("AE_SL_NEG_SNAPSHOT") &&
-                        !debug_knob("AE_SL_ONE_CHAIN");
-    const uint32_t chain_join_every = debug_knob("AE_SL_CHAIN_JOIN") ? (uint32_t)std::max(1, atoi(debug_knob("AE_SL_CHAIN_JOIN"))) : 1u;
-    if (chains) o->sl_last_form = AE_SLICE_TWO_CHAINS;
-    if (chains && !o->sl_chain_stream) {
-        AE_HIP(hipStreamCreateWithFlags(&o->sl_chain_stream, hipStreamNonBlocking));
-        for (hipEvent_t& e : o->sl_chain_ev) AE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     const uint64_t n_keys = (uint64_t)n_slices * kstride;
     if (n_keys >= (1ull << 31)) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: too many steps in a batch");
     o->rounds = segments * n_slices;
@@ -1286,22 +1214,6 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         }
         return ra;
     };
-    // two chains: fork = the second stream starts behind what the library's stream has enqueued; join = the library's stream waits for it
-    bool chain_forked = false;
-    auto chain_fork = [&] {
-        AE_HIP(hipEventRecord(o->sl_chain_ev[0], stream()));
-        AE_HIP(hipStreamWaitEvent(o->sl_chain_stream, o->sl_chain_ev[0], 0));
-        chain_forked = true;
-    };
-    auto chain_join = [&] {
-        AE_HIP(hipEventRecord(o->sl_chain_ev[1], o->sl_chain_stream));
-        AE_HIP(hipStreamWaitEvent(stream(), o->sl_chain_ev[1], 0));
-        chain_forked = false;
-    };
-    struct ChainGuard {   // (a batch that fails half way leaves nothing running on the second stream)
-        ae_entropy_optim* o; const bool& forked;
-        ~ChainGuard() { if (forked && o->sl_chain_stream) (void)hipStreamSynchronize(o->sl_chain_stream); }
-    } chain_guard{o, chain_forked};
     for (uint32_t sg = 0; sg < segments; sg++) {
         const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
@@ -1336,7 +1248,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
                            slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
-                           ov_every, chains ? (uint32_t)o->sl_chain_n0 : 0u, o->sl_keys0.p, ev0);
+                           ov_every, o->sl_keys0.p, ev0);
         if (prof) sync();
         const double t_fill = wall();
         const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
@@ -1371,15 +1283,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             // step pointers of the slice.  Merged: sp[q] = the class at POSITION q, sp[classes] the overflow class.  One launch per class:
             // the overflow class FIRST (key 0: the order its edges are generated in), class c at sp[1 + c]
             const uint32_t* sp = hptr.data() + (size_t)s * kstride;
-            // (one launch per class) the events of class c, part p: sp[low] .. sp[low + 1], low = step_key_low(1 + c, p); merged: position c: sp[c] .. sp[c + 1]
-            auto class_range = [&](uint32_t c, uint32_t part, uint32_t& b, uint32_t& e) {
-                const uint32_t low = slice_keys ? step_key_low(1u + c, part) : c;
-                b = sp[low];
-                e = (slice_keys && !chains) ? sp[low + 2u] : sp[low + 1u];   // (without chains the odd keys are empty: the class ends where the next one starts)
-            };
+            const uint32_t* spc = slice_keys ? sp + 1 : sp;                       // spc[c] .. spc[c + 1]: class c (one launch per class) / position c (merged)
             const uint32_t ov0 = slice_keys ? sp[0] : sp[classes], ov1 = slice_keys ? sp[1] : sp[classes + 1u];   // the overflow class's events
             const uint8_t* order = class_pos.data() + (size_t)s * std::max(1u, classes);   // (one launch per class) the slice's class order: a fresh uniform permutation
-            if (chains && !chain_forked) chain_fork();
             if (neg_snapshot && s % (uint32_t)neg_snapshot == 0u) {   // (experiment: the negatives of the next `neg_snapshot` slices are read from the rows as they are NOW)
                 AE_HIP(hipMemcpyAsync(o->sl_neg_snap.p, cdev.y, sizeof(float) * n * ystride, hipMemcpyDeviceToDevice, stream()));
                 da.c.yneg = a.c.yneg = o->sl_neg_snap.p;
@@ -1405,10 +1311,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 // inside the batch -- what P desynchronised chains of steps would cost if the graph fell into P independent parts
                 for (uint32_t qq = 0; qq < classes; qq++) {
                     const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
-                    uint32_t b0, e0;
-                    class_range(q, 0u, b0, e0);
-                    if (e0 == b0) continue;
-                    const uint32_t cnt = e0 - b0;
+                    if (spc[q + 1] == spc[q]) continue;
+                    const uint32_t b0 = spc[q], cnt = spc[q + 1] - spc[q];
                     da.step_seq = step_seq++;
                     for (int pc = 0; pc < chains_dbg; pc++) {
                         da.begin = b0 + (uint32_t)(((uint64_t)cnt * pc / chains_dbg) & ~63ull);
@@ -1422,12 +1326,11 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                     }
                 }
             } else
-            for (uint32_t qq = 0; qq < classes; qq++)   // the slice's matchings, in this slice's order
-            for (uint32_t part = 0; part < (chains ? 2u : 1u); part++) {   // ... either chain's share on its own stream
+            for (uint32_t qq = 0; qq < classes; qq++) {  // the slice's matchings, in this slice's order
                 const uint32_t q = slice_keys ? (uint32_t)order[qq] : qq;
-                class_range(q, part, da.begin, da.end);
-                if (da.end == da.begin) continue;
-                StreamScope on_chain(part ? o->sl_chain_stream : stream());
+                if (spc[q + 1] == spc[q]) continue;
+                da.begin = spc[q];
+                da.end = spc[q + 1];
                 const uint32_t cnt = da.end - da.begin;
                 // events per thread: one, unless the step is several times what the device holds at once (then the tile is amortised)
                 da.ept = ept_force ? ept_force : std::min(4u, std::max(1u, cnt / (256u * 3072u)));
@@ -1436,11 +1339,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 if (line) launch_step_line((uint32_t)o->dev.dim, da, line, f64, da.tile != 0, nullptr);
                 else AE_DISPATCH_DIM(o->dev.dim, launch_direct, da, o->sl_srec_floats, f64);
             }
-            const bool ov_now = has_overflow && !(ov_every > 1u && s != std::min(n_slices - 1u, s - s % ov_every + ov_every / 2u));
-            // the chains meet at the slice's end (every chain_join_every-th: between two meetings a chain reads the other part's rows -- negatives
-            // only -- as the other chain has them, up to that many slices ahead or behind), always before the overflow class and the segment's end
-            if (chain_forked && (ov_now || (s + 1u) % chain_join_every == 0u || s + 1u == n_slices)) chain_join();
-            if (!ov_now) { exchange_after(s); continue; }
+            if (!has_overflow || (ov_every > 1u && s != std::min(n_slices - 1u, s - s % ov_every + ov_every / 2u))) { exchange_after(s); continue; }
             a.f0 = ov0;
             a.f1 = ov1;
             a.src_list = cur; a.dst_list = (cur + 1) % 3; a.zero_list = (cur + 2) % 3;
@@ -1562,8 +1461,6 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     }
     owe.armed = false;
     if (own_copy) move_rows(0, n, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // back to the caller's labels and row stride
-    if (prof && chains) fprintf(stderr, "CESLICE two chains: part 0 = %llu of %llu nodes, %.4f of the edge mass between the parts, joined every %u slice(s)\n",
-                                (unsigned long long)o->sl_chain_n0, (unsigned long long)n, o->sl_chain_cross, chain_join_every);
     if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
                       t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");

@@ -456,10 +456,8 @@ int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim *o, uint32_t *max
    of the fidelity figures under AE_CE_AUTO applies: AE_SLICE_PER_CLASS (one launch per class and slice: negatives a step old; inside the
    exact mode's standard error), AE_SLICE_PER_CLASS_LINES (the same on node lines: a source's row, scale and neighbour ids as one request),
    AE_SLICE_MERGED (every class of a slice in one launch: negatives a slice old -- the resolved bias on stiff 2-D graphs),
-   AE_SLICE_OPTIMISTIC (no classes: every event through the optimistic passes; the same bias), AE_SLICE_TWO_CHAINS (one launch per class
-   with the nodes in two parts that share next to no edge mass, their steps side by side on two streams, joined at every slice's end:
-   negatives from the node's own part a step old, from the other part at most a slice).  AE_ERR_STATE for another mode. */
-enum { AE_SLICE_NONE = 0, AE_SLICE_PER_CLASS = 1, AE_SLICE_PER_CLASS_LINES = 2, AE_SLICE_MERGED = 3, AE_SLICE_OPTIMISTIC = 4, AE_SLICE_TWO_CHAINS = 5 };
+   AE_SLICE_OPTIMISTIC (no classes: every event through the optimistic passes; the same bias).  AE_ERR_STATE for another mode. */
+enum { AE_SLICE_NONE = 0, AE_SLICE_PER_CLASS = 1, AE_SLICE_PER_CLASS_LINES = 2, AE_SLICE_MERGED = 3, AE_SLICE_OPTIMISTIC = 4 };
 int32_t ae_entropy_optim_slice_form(const ae_entropy_optim *o, uint32_t *form);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);

@@ -157,19 +157,16 @@ def test_k6_blobs_without_hubness_40_batches(A):
     assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, floors["merged slices"], "k6 blobs, merged slices against one launch per class")
 
 
-@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 3), ({"AE_SL_CHAINS": "1"}, 5),
-                                        ({"AE_SL_CHAINS": "1", "AE_SL_CHAIN_JOIN": "8"}, 5)])
+@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 3)])
 def test_class_path_runs_every_event_once_in_every_layout(A, knobs, form):
     """One launch per class in its round-6 layouts -- node lines, the events sorted by their slice bits alone (the edges come in class order: the
     overflow class FIRST, key 0) -- and in the layouts they replaced (composite (slice, class position) keys, dense rows + static records),
     and merged slices: on a graph with hubs and a real overflow class (200 k Higgs-shaped points, 8 columns, k = 6, the class path forced)
-    -- and with the nodes in TWO CHAINS (two parts with next to no edge mass between them, their steps on two streams, the cross edges with the
-    overflow class; forced here: by itself the library takes it from 2 M nodes on) --
     every event of the batch's Poisson totals runs exactly once (the executed count within 6 sigma of nb_sample: a step pointer one class off
     would drop or double 1/15 of a slice), `ae_entropy_optim_slice_form` names the form, and the layouts end at the same cross entropy (5 %:
     one run against one run, three batches from a random start, the slices' class orders drawn differently: measured 2.1 % apart)."""
     n = 200000
-    g = A.KGraph.bruteforce_l2(_blobs(n), 6)   # (64 blobs: the graph falls into components, which the two chains' partition packs whole)
+    g = A.KGraph.bruteforce_l2(_blobs(n), 6)
     npar = A.to_proba_edges(g, 1.0, 1.0)
     y0 = A.set_data_box(np.random.default_rng(3).normal(size=(n, 8)).astype(np.float32), 10.0)
     hub = g.hubness()

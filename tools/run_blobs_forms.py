@@ -44,8 +44,6 @@ VARIANTS = {
     "pc_snap1": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="1")),
     "pc_snap4": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="4")),
     "pc_snap16": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="16")),
-    "pc_chains": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CHAINS="1")),
-    "pc_chains_join8": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_CHAINS="1", AE_SL_CHAIN_JOIN="8")),
     "ordered": (A.AE_CE_ORDERED, {}),
     "event": (A.AE_CE_EVENT, {}),
 }
@@ -56,10 +54,8 @@ def rows(mode, knobs):
     try:
         out = []
         for sd in seeds:
-            y, ce, eo = T._run_ce(A, g, npar, y0, 40, mode, seed=sd)
+            y, ce, _ = T._run_ce(A, g, npar, y0, 40, mode, seed=sd)
             out.append(T._metrics(indptr, nbr, y, ce))
-        if mode == A.AE_CE_SLICED:
-            print("  (launch form of the last batch: %d)" % eo.slice_form(), flush=True)
         return np.array(out)
     finally:
         for k in knobs:
