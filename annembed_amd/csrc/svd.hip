@@ -1062,29 +1062,65 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
     const uint32_t qo = active ? 4u * (uint32_t)q : 0u;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t row = wave; row < m; row += nwaves) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        const uint64_t e0 = indptr[row], e1 = indptr[row + 1];
-        for (uint64_t eb = e0; eb < e1; eb += 16) {  // two edges per lane in flight (clamped, masked: no branches)
-            const uint64_t ea = eb + sl, ec = eb + 8 + sl;
-            const bool ina = ea < e1, inc = ec < e1;
-            const float va = val[ina ? ea : e0], vc = val[inc ? ec : e0];
-            const uint64_t ca = ind[ina ? ea : e0], cc = ind[inc ? ec : e0];
-            const float4 xa = *reinterpret_cast<const float4*>(x + ca * ldx + qo);
-            const float4 xc = *reinterpret_cast<const float4*>(x + cc * ldx + qo);
-            const float wa = (ina && active) ? va : 0.f, wc = (inc && active) ? vc : 0.f;
-            a0 = fmaf(wa, xa.x, a0); a1 = fmaf(wa, xa.y, a1); a2 = fmaf(wa, xa.z, a2); a3 = fmaf(wa, xa.w, a3);
-            a0 = fmaf(wc, xc.x, a0); a1 = fmaf(wc, xc.y, a1); a2 = fmaf(wc, xc.z, a2); a3 = fmaf(wc, xc.w, a3);
+    // Round 6: U rows in flight per wave.  A row is three DEPENDENT hops (row pointers -> indices / values -> panel rows) and a wave took them one
+    // row at a time: at 11 M rows of ~14 entries the product ran at the pace of its latencies (3.1 ms; its gathers alone would take ~2).  Now the
+    // hops of U rows travel together: all row pointers, then all first trips' indices, then all gathers; rows of more than 16 entries finish in
+    // a tail loop of their own.
+    constexpr int U = 4;
+    for (uint64_t row0 = wave; row0 < m; row0 += (uint64_t)U * nwaves) {
+        uint64_t e0[U], e1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t r = row0 + (uint64_t)u * nwaves;
+            const uint64_t rc = r < m ? r : row0;
+            e0[u] = indptr[rc];
+            e1[u] = r < m ? indptr[rc + 1] : e0[u];   // (a row beyond the matrix: no entries)
+        }
+        float va[U], vc[U];
+        uint64_t ca[U], cc[U];
+        bool ina[U], inc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // the first trip of every row: two edges per lane slot (clamped, masked: no branches)
+            const uint64_t ea = e0[u] + sl, ec = e0[u] + 8 + sl;
+            ina[u] = ea < e1[u]; inc[u] = ec < e1[u];
+            va[u] = val[ina[u] ? ea : e0[u]]; vc[u] = val[inc[u] ? ec : e0[u]];
+            ca[u] = ind[ina[u] ? ea : e0[u]]; cc[u] = ind[inc[u] ? ec : e0[u]];
+        }
+        float4 xa[U], xc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            xa[u] = *reinterpret_cast<const float4*>(x + ca[u] * ldx + qo);
+            xc[u] = *reinterpret_cast<const float4*>(x + cc[u] * ldx + qo);
         }
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+        for (int u = 0; u < U; u++) {
+            const uint64_t row = row0 + (uint64_t)u * nwaves;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            {
+                const float wa = (ina[u] && active) ? va[u] : 0.f, wc = (inc[u] && active) ? vc[u] : 0.f;
+                a0 = fmaf(wa, xa[u].x, a0); a1 = fmaf(wa, xa[u].y, a1); a2 = fmaf(wa, xa[u].z, a2); a3 = fmaf(wa, xa[u].w, a3);
+                a0 = fmaf(wc, xc[u].x, a0); a1 = fmaf(wc, xc[u].y, a1); a2 = fmaf(wc, xc[u].z, a2); a3 = fmaf(wc, xc[u].w, a3);
+            }
+            for (uint64_t eb = e0[u] + 16; eb < e1[u]; eb += 16) {  // (rows of more than 16 entries: the trips in the same order as before)
+                const uint64_t ea = eb + sl, ec = eb + 8 + sl;
+                const bool in_a = ea < e1[u], in_c = ec < e1[u];
+                const float v_a = val[in_a ? ea : e0[u]], v_c = val[in_c ? ec : e0[u]];
+                const uint64_t c_a = ind[in_a ? ea : e0[u]], c_c = ind[in_c ? ec : e0[u]];
+                const float4 x_a = *reinterpret_cast<const float4*>(x + c_a * ldx + qo);
+                const float4 x_c = *reinterpret_cast<const float4*>(x + c_c * ldx + qo);
+                const float wa = (in_a && active) ? v_a : 0.f, wc = (in_c && active) ? v_c : 0.f;
+                a0 = fmaf(wa, x_a.x, a0); a1 = fmaf(wa, x_a.y, a1); a2 = fmaf(wa, x_a.z, a2); a3 = fmaf(wa, x_a.w, a3);
+                a0 = fmaf(wc, x_c.x, a0); a1 = fmaf(wc, x_c.y, a1); a2 = fmaf(wc, x_c.z, a2); a3 = fmaf(wc, x_c.w, a3);
+            }
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+            }
+            if (row < m && sl == 0 && active) *reinterpret_cast<float4*>(y + row * l + qo) = make_float4(a0, a1, a2, a3);
         }
-        if (sl == 0 && active) *reinterpret_cast<float4*>(y + row * l + qo) = make_float4(a0, a1, a2, a3);
     }
 }
 
-// may this product gather from a 128-byte-strided copy of its operand?  (the vec4 kernel's shapes; a panel beyond what the caches hold)
 // MEASURED, NOT ENABLED (round 6; AE_SPMM_WIDE under AE_DEBUG_KNOBS to repeat it): on the laplacian of an 11 M-node graph the product went
 // from 3.21 to 3.09 ms with the aligned copy, and chol_apply from 0.84 to 1.19 ms for writing it: 46.6 -> 47.7 ms per do_svd.  The
 // product is not bound by the lines it gathers alone (a wave per row: three dependent hops -- row pointers, indices, panel rows).
