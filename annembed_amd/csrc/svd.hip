@@ -1053,6 +1053,7 @@ constexpr uint32_t kWideLd = 32;   // floats per row of a panel's gather copy (1
 // ldx: floats from row to row of the GATHERED operand x (l, or 32: rows of 128 bytes on 128-byte boundaries -- a gathered row is then ONE
 // line where an 80-byte row at an 80-byte stride straddles two in 62 % of the cases; the product is bound by the number of lines it asks
 // the memory system for, tools/ubench_rowgather.hip)
+template <int U>
 __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const uint64_t* __restrict__ indptr, const uint32_t* __restrict__ ind,
                                                             const float* __restrict__ val, const float* __restrict__ x, float* __restrict__ y,
                                                             uint32_t l, uint32_t ldx) {
@@ -1065,8 +1066,8 @@ __global__ void __launch_bounds__(256) spmm_csr_vec4_kernel(uint64_t m, const ui
     // Round 6: U rows in flight per wave.  A row is three DEPENDENT hops (row pointers -> indices / values -> panel rows) and a wave took them one
     // row at a time: at 11 M rows of ~14 entries the product ran at the pace of its latencies (3.1 ms; its gathers alone would take ~2).  Now the
     // hops of U rows travel together: all row pointers, then all first trips' indices, then all gathers; rows of more than 16 entries finish in
-    // a tail loop of their own.
-    constexpr int U = 4;
+    // a tail loop of their own.  (11 M-node laplacian: 46.6 -> 44.7 ms per do_svd with U = 4; at 60 000 rows there are fewer rows than waves and
+    // U = 4 costs 0.77 -> 0.84 ms: the launcher takes U = 1 below 2^20 rows.)
     for (uint64_t row0 = wave; row0 < m; row0 += (uint64_t)U * nwaves) {
         uint64_t e0[U], e1[U];
 #pragma unroll
@@ -1131,7 +1132,10 @@ static bool spmm_wide_ok(const ae_matrepr& a, uint32_t l) {
 static void spmm(const ae_matrepr& a, const float* d_x, float* d_y, uint32_t l, uint32_t ldx = 0) {
     const unsigned grid = grid_cap(a.nrows * 64, 256);
     if (l % 4 == 0 && l <= 32 && !debug_knob("AE_SPMM_SCALAR")) {
-        hipLaunchKernelGGL(spmm_csr_vec4_kernel, dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l, ldx ? ldx : l);
+        if (a.nrows >= (1ull << 20))
+            hipLaunchKernelGGL((spmm_csr_vec4_kernel<4>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l, ldx ? ldx : l);
+        else
+            hipLaunchKernelGGL((spmm_csr_vec4_kernel<1>), dim3(grid), dim3(256), 0, stream(), a.nrows, a.indptr.p, a.indices.p, a.values.p, d_x, d_y, l, ldx ? ldx : l);
         check_launch("spmm_csr_vec4");
         return;
     }
