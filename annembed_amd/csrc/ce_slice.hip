@@ -801,6 +801,7 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     // end (two row moves: ~1 % of a batch); everything between the two -- records, events, pending lists -- speaks internal numbers.
     // A sharded range keeps the caller's labels: its ranks own label ranges and exchange rows in place.
     o->sl_perm.release();
+    o->sl_y_lines = 0;   // (the node lines' static part names the neighbours by their internal numbers: a new numbering, a new fill)
     const bool whole_range = o->dev.node_lo == 0 && o->dev.node_hi == g->n;
     // (a sharded range: once the communicator is attached and every rank's range is known -- entropy_optim_attach_comm prepares again --
     // the same relabelling on every rank, inside every rank's range: a rank's rows stay one contiguous run, the exchanges stay in place)
