@@ -805,7 +805,20 @@ void ce_slice_prepare(ae_entropy_optim* o) {
     const bool whole_range = o->dev.node_lo == 0 && o->dev.node_hi == g->n;
     // (a sharded range: once the communicator is attached and every rank's range is known -- entropy_optim_attach_comm prepares again --
     // the same relabelling on every rank, inside every rank's range: a rank's rows stay one contiguous run, the exchanges stay in place)
-    const bool ranges_known = !whole_range && o->comm && o->comm_ranges.size() >= 4;
+    // (measurement only, AE_SL_ASSUME_WORLD = W under AE_DEBUG_KNOBS: a range WITHOUT a communicator prepares as rank r of W equal ranges would
+    // with one -- relabelled inside the ranges, hence tile and node lines -- so that a rank's share can be timed alone on one GPU:
+    // tools/run_shard_time.py)
+    std::vector<uint64_t> assumed_ranges;
+    if (!whole_range && !o->comm && debug_knob("AE_SL_ASSUME_WORLD")) {
+        const uint64_t w = (uint64_t)std::max(2, atoi(debug_knob("AE_SL_ASSUME_WORLD"))), base = g->n / w, rem = g->n % w;
+        for (uint64_t r = 0; r < w; r++) {
+            const uint64_t lo = r * base + std::min(r, rem);
+            assumed_ranges.push_back(lo);
+            assumed_ranges.push_back(lo + base + (r < rem ? 1 : 0));
+        }
+    }
+    const std::vector<uint64_t>& rank_ranges = assumed_ranges.empty() ? o->comm_ranges : assumed_ranges;
+    const bool ranges_known = !whole_range && (o->comm || !assumed_ranges.empty()) && rank_ranges.size() >= 4;
     if ((whole_range || ranges_known) && !debug_knob("AE_SL_LABEL_ORDER")) {
         DevBuf<uint32_t> keys, keys_out, ident, order;
         keys.alloc_pooled(g->n); keys_out.alloc_pooled(g->n); ident.alloc_pooled(g->n); order.alloc_pooled(g->n);
@@ -813,10 +826,10 @@ void ce_slice_prepare(ae_entropy_optim* o) {
                            pcg_hash((uint32_t)o->dev.seed ^ 0x51ED270Bu), keys.p, ident.p);
         sort_pairs_u32_u32(keys.p, keys_out.p, ident.p, order.p, g->n, 32);
         if (ranges_known) {   // stable sort by owner: the random order survives inside every range
-            const uint32_t world = (uint32_t)(o->comm_ranges.size() / 2);
+            const uint32_t world = (uint32_t)(rank_ranges.size() / 2);
             DevBuf<uint64_t> d_ranges;
-            d_ranges.alloc_pooled(o->comm_ranges.size());
-            d_ranges.upload(o->comm_ranges.data(), o->comm_ranges.size());
+            d_ranges.alloc_pooled(rank_ranges.size());
+            d_ranges.upload(rank_ranges.data(), rank_ranges.size());
             hipLaunchKernelGGL(sl_perm_block_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), (uint64_t)g->n, (const uint32_t*)order.p,
                                (const uint64_t*)d_ranges.p, world, keys.p);
             unsigned bits = 1;
