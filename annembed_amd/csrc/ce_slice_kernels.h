@@ -147,7 +147,7 @@ __device__ __forceinline__ void coop_land(const f4 (&pc)[NF / 4], float* stage) 
     wave_lds_sync();
 }
 template <int NF>
-__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride = NF, bool nt = false) {
+__device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t idx, bool want, const float* stage, uint32_t stride = NF, int nt = 0) {
     constexpr int G = NF / 4, RS = NF + 4;
     const int lane = threadIdx.x & 63, sub = lane & (G - 1), gb = lane & ~(G - 1);
     const uint32_t word = idx | (want ? 0x80000000u : 0u);
@@ -158,7 +158,10 @@ __device__ __forceinline__ void coop_store(float* __restrict__ base, uint32_t id
         if (wt & 0x80000000u) {
             f4* dst = reinterpret_cast<f4*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * stride + (uint32_t)sub * 4u);
             const f4 v = *reinterpret_cast<const f4*>(stage + (gb + t) * RS + sub * 4);
-            if (nt) __builtin_nontemporal_store(v, dst);   // (A/B, AE_SL_DBG bit 128: the row leaves the caches as it is written instead of at the kernel's end)
+            // (A/B, AE_SL_DBG bit 128: a non-temporal store; bit 512: a write-through store (sc0 sc1) -- the row leaves the caches as it is written
+            // instead of in the burst at the kernel's end)
+            if (nt == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
+            else if (nt == 1) __builtin_nontemporal_store(v, dst);
             else *dst = v;
         }
     }
@@ -261,7 +264,7 @@ struct RowFetch {  // a coordinate row on its way to its lane
     }
 };
 template <int DIM>
-__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride, bool nt = false) {
+__device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride, int nt = 0) {
     if constexpr (kCoopRow<DIM>) {
         float* p = stage + (threadIdx.x & 63) * (DIM + 4);
 #pragma unroll
@@ -757,8 +760,9 @@ __device__ __forceinline__ void sl_step_body(const DirectArgs& a, uint32_t block
         // and announced where the chain goes on in the next chunk
         const bool store_j = act0 && last_in_seg && !hand_over;
         if (!(a.dbg & 2)) {
-            row_store<DIM>(c.y, j, store_j, stage, yj, c.ystride, (a.dbg & 128) != 0);  // :1239
-            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride, (a.dbg & 128) != 0);      // :1301
+            const int st_mode = (a.dbg & 512) ? 2 : ((a.dbg & 128) ? 1 : 0);
+            row_store<DIM>(c.y, j, store_j, stage, yj, c.ystride, st_mode);  // :1239
+            row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride, st_mode);      // :1301
         } else if (yi[0] == 1.2345e-30f && yj[0] == 3.4e-30f) {
             row_store<DIM>(c.y, i, cmp && !half, stage, yi, c.ystride);
         }
