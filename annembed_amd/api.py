@@ -383,8 +383,9 @@ class EntropyOptim(_Handle):
         return a.value, b.value
 
     def slice_form(self):
-        """AE_CE_SLICED: the launch form of the last batch -- 0 none yet, 1 one launch per class, 2 the same on node lines, 3 merged slices,
-        4 optimistic passes only (ae_entropy_optim_slice_form: how old the negatives' rows are)"""
+        """AE_CE_SLICED: the launch form of the last batch -- 0 none yet, 1 one launch per class, 2 the same on node lines, 3 merged slices without
+        the class window (debug knob), 4 optimistic passes only, 5 merged slices with the class window -- what merged slices run as
+        (ae_entropy_optim_slice_form: how old the negatives' rows are)"""
         v = C.c_uint32()
         check(L.load().ae_entropy_optim_slice_form(self._h, C.byref(v)))
         return v.value

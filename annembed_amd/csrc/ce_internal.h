@@ -136,6 +136,7 @@ struct ae_entropy_optim {
     // batch (a uniform random relabelling: what runs of consecutive rows hold has nothing to do with the caller's labels)
     DevBuf<uint32_t> sl_perm;
     DevBuf<float> sl_y;
+    DevBuf<uint32_t> sl_class_done;             // merged slices, the class window: per slice and class position, the workgroups that are through (zeroed per segment)
     DevBuf<float> sl_neg_snap;                  // (experiment AE_SL_NEG_SNAPSHOT) the copy of the coordinates the negatives are read from
     uint32_t sl_last_form = 0;                  // AE_SLICE_*: the launch form of the last batch (ae_entropy_optim_slice_form)
     uint32_t sl_y_lines = 0;                    // floats per node line whose static part (embedded scale, neighbour ids) sl_y currently holds; 0: none

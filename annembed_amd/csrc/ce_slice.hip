@@ -1207,8 +1207,19 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     if (neg_snapshot && o->sl_neg_snap.n < n * ystride) o->sl_neg_snap.alloc(n * ystride);
     bool premarked = false;   // the slice about to run had its words filled by the slice before it
     uint32_t step_seq_base = 0;
+    // THE CLASS WINDOW of the merged launches (SliceRunArgs::window): half the palette.  A merged launch without it runs every class of a
+    // slice at once, so an event reads its negatives' rows as up to a whole slice of its predecessors has NOT yet moved them -- the form's
+    // bias of round 5 (stiff 2-D blobs, 256 seeds a side against one launch per class: CE +0.34 +- 0.23 %, median edge -0.69 +- 0.43 %).
+    // Window 8 of 15 classes: +0.12 +- 0.22 % / -0.18 +- 0.43 %; 6: +0.03 / -0.17; 4 and 2: nothing at 64 seeds.  What it costs is the
+    // concurrency it takes away: configs[2]'s large graph 29.4 ms per batch without, 32.2 with 8, 40.8 with 6, 54.6 with 4 (one launch
+    // per class: 50.8).  profiles/r06/r6_blobs_window*.txt, r6_c3_window_ab2.jsonl.  AE_SL_WINDOW (debug knob): another width, 0 = none.
+    const uint32_t window = !merged ? 0u : (debug_knob("AE_SL_WINDOW") ? (uint32_t)std::max(0, atoi(debug_knob("AE_SL_WINDOW"))) : (classes + 1u) / 2u);
+    if (window && o->sl_class_done.n < (uint64_t)n_slices * classes) o->sl_class_done.alloc((uint64_t)n_slices * classes);
+    if (merged && window) o->sl_last_form = AE_SLICE_MERGED_WINDOW;
     auto slice_args = [&](uint32_t s) {
         SliceRunArgs ra;
+        ra.window = window;
+        ra.class_done = window ? o->sl_class_done.p + (size_t)s * classes : nullptr;
         ra.d = da;
         ra.d.ept = 1;
         ra.sptr = o->sl_sptr.p + (size_t)s * (classes + 1u);
@@ -1288,6 +1299,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (merged) {
             step_seq_base = step_seq;
             step_seq += n_slices * classes;
+            if (window) o->sl_class_done.zero();
         }
         if (chains_dbg > 1) {   // fork: the side streams start behind the event generation
             AE_HIP(hipEventRecord(dbg_ev, stream()));
@@ -1486,6 +1498,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         if (h[1024] & 2ull) fail(AE_ERR_STATE, "AE_CE_SLICED: a hub chain waited for the previous chunk beyond the poll budget (is another process using this GPU?)");
         if (h[1024] & (unsigned long long)kErrDepPoll)
             fail(AE_ERR_STATE, "AE_CE_SLICED: an event of a merged slice waited for an earlier class on one of its nodes beyond the poll budget (is another process using this GPU?)");
+        if (h[1024] & (unsigned long long)kErrWindowPoll)
+            fail(AE_ERR_STATE, "AE_CE_SLICED: a workgroup of a merged slice waited for the classes before its window beyond the poll budget (is another process using this GPU?)");
         fail(AE_ERR_STATE, "AE_CE_SLICED: pending list overflow");
     }
     // samples executed, into the common counter

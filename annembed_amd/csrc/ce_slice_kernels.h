@@ -211,8 +211,12 @@ struct LineFetch {
         wave_lds_sync();
     }
 };
+// a store that leaves the caches as it is written (sc0 sc1): the other XCDs' agent-scope loads see it without waiting for the launch's end
+__device__ __forceinline__ void store_through(f4* dst, const f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory"); }
+using f2v = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void store_through(f2v* dst, const f2v v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory"); }
 template <int DIM>
-__device__ __forceinline__ void line_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* row, uint32_t set) {
+__device__ __forceinline__ void line_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* row, uint32_t set, bool through = false) {
     using S = LineShape<DIM>;
     using piece_t = float __attribute__((ext_vector_type(S::kPiece)));
     const int lane = threadIdx.x & 63, sub = lane & 3, gb = lane & ~3;
@@ -226,9 +230,11 @@ __device__ __forceinline__ void line_store(float* __restrict__ y, uint32_t node,
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const uint32_t wt = group_bcast<4>(word, t);
-        if ((wt & 0x80000000u) && sub >= lo && sub <= hi)
-            *reinterpret_cast<piece_t*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * S::kFloats + (uint32_t)sub * (uint32_t)S::kPiece) =
-                *reinterpret_cast<const piece_t*>(stage + (gb + t) * S::kStageRow + sub * S::kPiece);
+        if ((wt & 0x80000000u) && sub >= lo && sub <= hi) {
+            piece_t* dst = reinterpret_cast<piece_t*>(base + (uint64_t)(wt & 0x7FFFFFFFu) * S::kFloats + (uint32_t)sub * (uint32_t)S::kPiece);
+            const piece_t v = *reinterpret_cast<const piece_t*>(stage + (gb + t) * S::kStageRow + sub * S::kPiece);
+            if (through) store_through(dst, v); else *dst = v;
+        }
     }
     wave_lds_sync();
 }
@@ -263,6 +269,36 @@ struct RowFetch {  // a coordinate row on its way to its lane
         }
     }
 };
+// rows handed from one workgroup of a launch to another: past the caches (agent scope)
+template <int DIM>
+__device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t node, const float* in, uint32_t stride) {
+    float* p = y + (uint64_t)node * stride;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int DIM>
+__device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint32_t node, float* out, uint32_t stride) {
+    const float* p = y + (uint64_t)node * stride;
+    if constexpr (DIM % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < DIM / 2; q++) {
+            const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[2 * q] = __uint_as_float((uint32_t)bits);
+            out[2 * q + 1] = __uint_as_float((uint32_t)(bits >> 32));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DIM; t++) out[t] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+}
 template <int DIM>
 __device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, bool want, float* stage, const float* in, uint32_t stride, int nt = 0) {
     if constexpr (kCoopRow<DIM>) {
@@ -274,7 +310,10 @@ __device__ __forceinline__ void row_store(float* __restrict__ y, uint32_t node, 
         }
         coop_store<DIM>(y, node, want, stage, stride, nt);
     } else {
-        if (want) store_row<DIM>(y + (uint64_t)node * stride, 0u, in);
+        if (want) {
+            if (nt == 2) store_row_agent<DIM>(y, node, in, stride);   // (rows of <= 4 columns: one 8- / 16-byte piece or two)
+            else store_row<DIM>(y + (uint64_t)node * stride, 0u, in);
+        }
     }
 }
 // the source's static record: embedded scale, the neighbour ids (rejection test of the negatives), the sampled edge's probability
@@ -375,7 +414,9 @@ struct TileFetch {
     f4 pc[T::kPieces];
     uint32_t node[T::kPieces];
     // rows: the tile's first `rows` rows are distinct draws, the others repeat them (the step kernel's hub tile: 128 draws for 256 samples)
-    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n, uint32_t rows = (uint32_t)TileShape<DIM>::kRows) {
+    // coherent: the rows are read past the caches (agent scope: what the other workgroups of this launch have written through)
+    __device__ __forceinline__ void issue(const CeDev& c, uint32_t wkey, bool hub, const uint32_t* __restrict__ hub_pool, uint32_t hub_pool_n, uint32_t rows = (uint32_t)TileShape<DIM>::kRows,
+                                          bool coherent = false) {
         const uint32_t pool_at = hub ? __umulhi(pcg_hash(wkey), hub_pool_n - (uint32_t)T::kRows) : 0u;
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
@@ -391,8 +432,20 @@ struct TileFetch {
 #pragma unroll
         for (int z = 0; z < T::kPieces; z++) {
             const uint32_t x = (uint32_t)z * 256u + threadIdx.x, q = x % Q;
-            if constexpr (DIM % 4 == 0) pc[z] = *reinterpret_cast<const f4*>(yb + (uint64_t)node[z] * c.ystride + 4u * q);
-            else pc[z].x = yb[(uint64_t)node[z] * c.ystride + q];
+            if constexpr (DIM % 4 == 0) {
+                const float* src = yb + (uint64_t)node[z] * c.ystride + 4u * q;
+                if (coherent) {
+                    const uint64_t lo = __hip_atomic_load(reinterpret_cast<const uint64_t*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t hi = __hip_atomic_load(reinterpret_cast<const uint64_t*>(src) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pc[z].x = __uint_as_float((uint32_t)lo); pc[z].y = __uint_as_float((uint32_t)(lo >> 32));
+                    pc[z].z = __uint_as_float((uint32_t)hi); pc[z].w = __uint_as_float((uint32_t)(hi >> 32));
+                } else {
+                    pc[z] = *reinterpret_cast<const f4*>(src);
+                }
+            } else {
+                const float* src = yb + (uint64_t)node[z] * c.ystride + q;
+                pc[z].x = coherent ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *src;
+            }
         }
     }
     __device__ __forceinline__ void land(float* s_tile, uint32_t* s_tnode) {
@@ -521,7 +574,7 @@ struct SplitSample {
     static constexpr bool kAhead = DIM <= 16 && !TILE;
     float grad[DIM];
     float nrow[kAhead ? 5 : 1][DIM];
-    __device__ __forceinline__ static void fetch_row(const CeDev& c, const float* s_tile, uint32_t x, float* row) {
+    __device__ __forceinline__ static void fetch_row(const CeDev& c, const float* s_tile, uint32_t x, float* row, bool coherent = false) {
         if constexpr (TILE) {
             if constexpr (DIM % 4 == 0) {
 #pragma unroll
@@ -534,13 +587,14 @@ struct SplitSample {
                 for (int t2 = 0; t2 < DIM; t2++) row[t2] = s_tile[x * DIM + t2];
             }
         } else {
-            load_row<DIM>((c.yneg ? c.yneg : c.y) + (uint64_t)x * c.ystride, 0u, row);
+            if (coherent) load_row_agent<DIM>(c.y, x, row, c.ystride);
+            else load_row<DIM>((c.yneg ? c.yneg : c.y) + (uint64_t)x * c.ystride, 0u, row);
         }
     }
-    __device__ __forceinline__ void fetch(const CeDev& c, const float* s_tile, const uint32_t (&neg)[5]) {
+    __device__ __forceinline__ void fetch(const CeDev& c, const float* s_tile, const uint32_t (&neg)[5], bool coherent = false) {
         if constexpr (kAhead) {
 #pragma unroll
-            for (int g = 0; g < 5; g++) fetch_row(c, s_tile, neg[g], nrow[g]);
+            for (int g = 0; g < 5; g++) fetch_row(c, s_tile, neg[g], nrow[g], coherent);
         }
     }
     // (1 / s^2 in f64, once per call site: the compiler keeps it in registers across a sample's interactions)
@@ -553,7 +607,7 @@ struct SplitSample {
         if constexpr (F64) repulse_f64<DIM>(yi, yk, grad, inv_s2_f64(scale_f), c.b, step);  // :1267-1297
         else repulse_f32<DIM>(yi, yk, grad, rcp(scale_f * scale_f), (float)c.b, (float)step);
     }
-    __device__ __forceinline__ void repulse(const CeDev& c, const float* s_tile, float* yi, float scale_f, double step, const uint32_t (&neg)[5], uint32_t got) {
+    __device__ __forceinline__ void repulse(const CeDev& c, const float* s_tile, float* yi, float scale_f, double step, const uint32_t (&neg)[5], uint32_t got, bool coherent = false) {
         if constexpr (kAhead) {
 #pragma unroll
             for (int g = 0; g < 5; g++)
@@ -563,7 +617,7 @@ struct SplitSample {
                 uint32_t x = neg[0];
 #pragma unroll
                 for (int q = 1; q < 5; q++) x = g == (uint32_t)q ? neg[q] : x;
-                fetch_row(c, s_tile, x, nrow[0]);
+                fetch_row(c, s_tile, x, nrow[0], coherent);
                 repulse_one(c, yi, nrow[0], scale_f, step);
             }
         }
@@ -571,11 +625,11 @@ struct SplitSample {
 };
 template <int DIM, bool F64, bool TILE>
 __device__ __forceinline__ void run_sample(const CeDev& c, const float* s_tile, float* yi, float* yj, float w, float scale_f,
-                                           double step, const uint32_t (&neg)[5], uint32_t got) {
+                                           double step, const uint32_t (&neg)[5], uint32_t got, bool coherent = false) {
     SplitSample<DIM, F64, TILE> sm;
-    sm.fetch(c, s_tile, neg);
+    sm.fetch(c, s_tile, neg, coherent);
     sm.attract(c, yi, yj, w, scale_f, step);
-    sm.repulse(c, s_tile, yi, scale_f, step, neg, got);
+    sm.repulse(c, s_tile, yi, scale_f, step, neg, got, coherent);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -604,36 +658,6 @@ struct StepShared {
     __attribute__((aligned(16))) float stage[4 * kStageFloats<DIM, SREC>];
     uint32_t tnode[TILE ? T::kRows : 1];
 };
-
-template <int DIM>
-__device__ __forceinline__ void store_row_agent(float* __restrict__ y, uint32_t node, const float* in, uint32_t stride) {
-    float* p = y + (uint64_t)node * stride;
-    if constexpr (DIM % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 2; q++) {
-            const uint64_t bits = ((uint64_t)__float_as_uint(in[2 * q + 1]) << 32) | __float_as_uint(in[2 * q]);
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) __hip_atomic_store(reinterpret_cast<uint32_t*>(p) + t, __float_as_uint(in[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-template <int DIM>
-__device__ __forceinline__ void load_row_agent(const float* __restrict__ y, uint32_t node, float* out, uint32_t stride) {
-    const float* p = y + (uint64_t)node * stride;
-    if constexpr (DIM % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < DIM / 2; q++) {
-            const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out[2 * q] = __uint_as_float((uint32_t)bits);
-            out[2 * q + 1] = __uint_as_float((uint32_t)(bits >> 32));
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < DIM; t++) out[t] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-}
 
 // the events [a.begin, a.end) of one step, workgroup `block` of the step's grid (256 x a.ept events per workgroup)
 // LINE > 0: the source's row, embedded scale and neighbour ids come as ONE line of LINE floats (NodeLine above; SREC == LINE then: it only
@@ -824,7 +848,14 @@ struct SliceRunArgs {
     uint32_t lines;                // the words sit in the node's line around its row (LineShape: rows of 8 / 2 columns)
     uint32_t dep_stride;           // 64-bit words from one node's word to the next: 1 (an array of its own), or the coordinate rows' stride / 2 where the words
                                    // sit behind the node's row (rows of <= 8 columns: the word comes with the row's line and is wiped with its store)
+    // THE CLASS WINDOW (round 6): a workgroup of class position q starts -- stages its tile, reads its rows, draws its negatives -- only once the
+    // classes at positions <= q - window are through, every row is stored through the caches, and the negatives are read past them: the
+    // negatives' rows are `window` steps old at most, where a merged launch without it reads them as the slice found them (the form's
+    // published bias: DESIGN 4.3b).  0: no window.
+    uint32_t window;
+    uint32_t* class_done;          // [classes]: workgroups of every class position that are through (zeroed per batch)
 };
+constexpr uint32_t kErrWindowPoll = 32u;                // done_counter[1024] flag: a workgroup waited for the classes before its window beyond the poll budget
 // an event of a slice enters its class in the words of its two nodes (fire-and-forget atomics on the words' low halves)
 __device__ __forceinline__ void dep_mark_event(unsigned long long* dep, uint32_t dep_stride, const Event e, uint32_t q) {
     uint32_t* words = reinterpret_cast<uint32_t*>(dep);   // (little endian: the low word of a node's 64 bits holds the classes)
@@ -858,6 +889,24 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     const uint32_t wkey = pcg_hash(nkey + s_seq * 0x85EBCA6Bu) + block * 64u;
     const uint32_t p = s_begin + block * 256u + threadIdx.x;
     uint32_t done = 0;
+    const bool through = ra.window != 0u;   // (uniform) every row store leaves the caches as it is written
+    // the class window: before anything of this workgroup reads a negative's row, the class `window` positions before its own is through
+    // (dispatched before this workgroup: it runs or is through; ONE counter is polled -- the classes before that one were held to
+    // the same rule, and what the window bounds is the age of the negatives' rows, a statistical matter: the node-by-node order is the
+    // dependency words' business)
+    auto window_wait = [&]() {
+        if (ra.window && q >= ra.window) {
+            if (threadIdx.x == 0) {
+                const uint32_t qq = q - ra.window, want = (ra.sptr[qq + 1u] - ra.sptr[qq] + 255u) >> 8;
+                uint32_t polls = 0;
+                while (__hip_atomic_load(&ra.class_done[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1u << 22)) { atomicOr(reinterpret_cast<unsigned int*>(a.done_counter + 1024), kErrWindowPoll); break; }
+                }
+            }
+            __syncthreads();
+        }
+    };
     // hop 1: the event and its two neighbours in the array, the tile
     const bool act0 = p < s_end;
     Event e{0u, kNoNode}, pv{0u, kNoNode}, nx{0u, kNoNode};
@@ -867,7 +916,7 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
         if (p + 1 < s_end) nx = a.ev[p + 1];
     }
     TileFetch<DIM> ft;
-    if constexpr (TILE) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
+    if constexpr (TILE) if (!through) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n);
     const uint32_t i = e.im >> 5, j = act0 ? ev_node(e.j) : 0u;
     const bool half = act0 && ev_half(e.j);
     const bool inrun = act0 && p > s_begin && ev_node(pv.j) == j;
@@ -895,6 +944,10 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
             fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
             li.issue(c.y, i, cmp);
             lj.issue(c.y, j, act0);   // (a chain's followers want the word: the last of them announces the chain)
+            if (through) {   // (the event's own requests are on their way while the workgroup waits for its window)
+                window_wait();
+                if constexpr (TILE) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n, (uint32_t)TileShape<DIM>::kRows, true);
+            }
             if constexpr (TILE) ft.land(sh.tile, sh.tnode);
             fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
             li.land(stage, yi, wi, ra.set);
@@ -907,6 +960,10 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
         fr.issue(a.srec, i, e.im & 31u, cmp, scale_f, w, nbr_reg);
         fi.issue(c.y, i, cmp, yi, c.ystride);
         fj.issue(c.y, j, cmp && !inrun, yj, c.ystride);
+        if (through) {
+            window_wait();
+            if constexpr (TILE) ft.issue(c, wkey, hub, a.hub_pool, a.hub_pool_n, (uint32_t)TileShape<DIM>::kRows, true);
+        }
         if constexpr (TILE) ft.land(sh.tile, sh.tnode);
         fr.land(stage, e.im & 31u, cmp, scale_f, w, nbr_reg);
         fi.land(stage, yi);
@@ -924,7 +981,7 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
     uint32_t neg[5], got = 0;
     if (cmp && !half) {   // (the negatives do not wait for anybody: drawn and requested before the first poll)
         got = draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + rep - 1u)), i, nbr_reg, neg);
-        sm.fetch(c, sh.tile, neg);
+        sm.fetch(c, sh.tile, neg, through);
     }
     // LANE BY LANE: a lane runs as soon as ITS OWN predecessors are through -- the classes before it on its two nodes, the lane
     // before it in a chain -- and announces its rows at once.  (The first form waited for all 64 lanes' predecessors before any
@@ -964,7 +1021,7 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
                 for (uint32_t z = 0; z + 1u < rep; z++) {   // earlier repetitions of the edge: whole samples, one after the other
                     uint32_t ng[5] = {0u, 0u, 0u, 0u, 0u};
                     const uint32_t gt = half ? 0u : draw_negatives<DIM, KREG, TILE>(c, hub, sh.tnode, pcg_hash(nkey + (p + z)), i, nbr_reg, ng);
-                    run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt);
+                    run_sample<DIM, F64, TILE>(c, sh.tile, yi, yj, w, scale_f, a.step, ng, gt, through);
                 }
                 sm.attract(c, yi, yj, w, scale_f, a.step);
             }
@@ -993,19 +1050,19 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
                         for (int g = 0; g < 5; g++) load_row_agent<DIM>(c.y, neg[g], sm.nrow[g], c.ystride);
                     }
                 }
-                sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got);
+                sm.repulse(c, sh.tile, yi, scale_f, a.step, neg, got, through);
                 done += rep;
             }
             // stores: as sl_step_body for the rows no later class of the slice will ask for; the node's last event of the slice wipes its
             // word (everybody who had to read it has: they are earlier classes, or this chain)
             if (lines) {   // (the row's store takes the wiped word along: one request)
                 if constexpr (kHasLines<DIM>) {
-                    line_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, ra.set);   // :1239
-                    line_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, ra.set);   // :1301
+                    line_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, ra.set, through);   // :1239
+                    line_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, ra.set, through);   // :1301
                 }
             } else {
-                row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride);   // :1239
-                row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, c.ystride);   // :1301
+                row_store<DIM>(c.y, j, fin && store_j && !succ_j, stage, yj, c.ystride, through ? 2 : 0);   // :1239
+                row_store<DIM>(c.y, i, fin && store_i && !succ_i, stage, yi, c.ystride, through ? 2 : 0);   // :1301
                 if (fin && store_i && !succ_i && !(a.dbg & 16)) *dep_i = 0ull;
                 if (fin && store_j && !succ_j && !(a.dbg & 16)) *dep_j = 0ull;
             }
@@ -1024,6 +1081,11 @@ __global__ void __launch_bounds__(256) sl_slice_kernel(SliceRunArgs ra) {
                 break;
             }
         } else idle = 0;
+    }
+    if (ra.window) {   // this workgroup's rows are out (the stores waited for): its class counts it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&ra.class_done[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // The NEXT slice's events enter their words now: two fire-and-forget atomics per event (~24 G/s: 29 us for a slice of 344 k events
     // as a launch of its own) that nothing in this slice waits for -- issued when a wave is through, they run beside the other waves' work.

@@ -141,13 +141,15 @@ enum {
        40 batches; ratios to AE_CE_SEQUENTIAL's means, 2 SE = 0.7 % on the final cross entropy, 1.2 % on the median edge length;
        profiles/r06/r6_blobs_forms.txt): AE_CE_ORDERED 1.002 / 0.994, AE_CE_EVENT 1.003 / 0.995, AE_CE_SLICED with one launch per class
        0.997-1.002 / 0.992-1.006 whatever its palette -- all inside the standard error.  AE_CE_SLICED where its slices run MERGED (what
-       AE_CE_AUTO runs from 2^25 samples per batch up to a few 10^8, and on the ranks of a sharded run from 4 ranks on) or through the
-       optimistic passes: cross entropy +0.9 ... +1.1 %, median edge -1.6 ... -2.2 % -- a RESOLVED bias of these forms on stiff 2-D graphs
-       (not visible at 8 columns).  Its cause, isolated in round 6: the AGE of the negatives' rows.  A merged launch reads a slice's negatives
-       as the slice found them (half an event per node stale on average); with one launch per class they are a step old.  One launch per
-       class with its negatives read from a copy of the coordinates refreshed every 1 / 4 / 16 slices reproduces sign and size: cross
-       entropy 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820.  Thinner slices shrink it in proportion
-       (lambda 1/4: half), at twice the launches.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
+       AE_CE_AUTO runs from 2^25 samples per batch up to a few 10^8, and on the ranks of a sharded run from 4 ranks on): with the CLASS
+       WINDOW of round 6 (a workgroup reads its negatives only once the class half a palette before its own is through; rows written
+       through the caches) cross entropy +0.12 +- 0.22 %, median edge -0.18 +- 0.43 % against one launch per class at 256 seeds a side --
+       inside the standard error too (profiles/r06/r6_blobs_window256.txt).  Without the window (rounds 4-5, and the optimistic passes
+       still): cross entropy +0.34 +- 0.23 % ... +1 %, median edge -0.7 +- 0.4 % ... -2 % -- a RESOLVED bias on stiff 2-D graphs (not
+       visible at 8 columns).  Its cause, isolated in round 6: the AGE of the negatives' rows.  A merged launch without the window reads
+       a slice's negatives as the slice found them (half an event per node stale on average); with one launch per class they are a step
+       old.  One launch per class with its negatives read from a copy of the coordinates refreshed every 1 / 4 / 16 slices reproduces
+       sign and size: cross entropy 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820.  Every asked_dim in [1, 64]: coordinate rows are stored zero-padded to 2, 3, 4, 8, 16, 32 or 64 columns (a zero
        column adds +0 to every distance and never moves).  A sharded node range (several GPUs) runs AE_CE_SLICED whatever the
        batch size (see there; refused with AE_ERR_INVALID_ARG when more than 10 % of the range's edge mass crosses shards: the
        approximate AE_CE_HOGWILD still shards, by name).  ae_entropy_optim_get_ce_mode reports the choice. */
@@ -166,9 +168,9 @@ enum {
        communicator is attached).
        Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
        parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
-       standard error on graphs of 8 columns; on stiff 2-column graphs the merged-slice and optimistic forms sit at CE +1 %, median
-       edge -2 % against the exact mode at 32 seeds -- their negatives are a slice old --, one launch per class inside the standard
-       error: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
+       standard error on graphs of 8 columns; on stiff 2-column graphs one launch per class and the merged slices with their class
+       window are inside the standard error, the optimistic form sits at CE +1 %, median edge -2 % against the exact mode at 32
+       seeds -- its negatives are a slice old: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
        sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
        the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
        exchange. */
@@ -455,9 +457,12 @@ int32_t ae_entropy_optim_slice_hub_info(const ae_entropy_optim *o, uint32_t *max
 /* AE_CE_SLICED: the launch form of the handle's LAST batch (0 before the first) -- it decides how old the negatives' rows are, i.e. which
    of the fidelity figures under AE_CE_AUTO applies: AE_SLICE_PER_CLASS (one launch per class and slice: negatives a step old; inside the
    exact mode's standard error), AE_SLICE_PER_CLASS_LINES (the same on node lines: a source's row, scale and neighbour ids as one request),
-   AE_SLICE_MERGED (every class of a slice in one launch: negatives a slice old -- the resolved bias on stiff 2-D graphs),
-   AE_SLICE_OPTIMISTIC (no classes: every event through the optimistic passes; the same bias).  AE_ERR_STATE for another mode. */
-enum { AE_SLICE_NONE = 0, AE_SLICE_PER_CLASS = 1, AE_SLICE_PER_CLASS_LINES = 2, AE_SLICE_MERGED = 3, AE_SLICE_OPTIMISTIC = 4 };
+   AE_SLICE_MERGED_WINDOW (every class of a slice in one launch, a workgroup's negatives read once the class half a palette before its
+   own is through: negatives half a slice old at most; inside the standard error at 256 seeds -- what merged slices run as),
+   AE_SLICE_MERGED (the same without the window, the form of rounds 4-5, debug builds only: negatives a slice old -- the resolved
+   bias on stiff 2-D graphs), AE_SLICE_OPTIMISTIC (no classes: every event through the optimistic passes; the same bias).
+   AE_ERR_STATE for another mode. */
+enum { AE_SLICE_NONE = 0, AE_SLICE_PER_CLASS = 1, AE_SLICE_PER_CLASS_LINES = 2, AE_SLICE_MERGED = 3, AE_SLICE_OPTIMISTIC = 4, AE_SLICE_MERGED_WINDOW = 5 };
 int32_t ae_entropy_optim_slice_form(const ae_entropy_optim *o, uint32_t *form);
 /* ce_compute_threaded (embedder.rs:1127-1163) over this handle's edges */
 int32_t ae_entropy_optim_ce(ae_entropy_optim *o, double *ce);

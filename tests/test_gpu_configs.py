@@ -97,6 +97,10 @@ def test_k6_blobs_without_hubness_40_batches(A):
     median edge 0.978-0.981) -- floors 1.5 % / 3.5 % / 3 % / 3 % = what is claimed, and the same against one launch per class.  Its cause is
     the AGE of the negatives' rows: a merged launch reads them as the slice found them; one launch per class with the negatives read from a
     snapshot taken every 1 / 4 / 16 slices reproduces the sign and a dose-response (CE 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820).
+    And CLOSED in round 6 by the class window (a workgroup of a merged launch reads its negatives once the class half a palette before
+    its own is through; rows written through): 256 seeds a side against one launch per class, CE +0.12 +- 0.22 %, median edge -0.18 +- 0.43 %
+    (without: +0.34 +- 0.23 % / -0.69 +- 0.43 %; profiles/r06/r6_blobs_window256.txt) -- merged slices run with it, and take the floors of
+    one launch per class here.
     A four-seed mean of the median edge scatters by ~2 % on this graph (the runs of these modes are not repeatable seed by seed: the overflow
     class is scheduled by races): EIGHT seeds for the class path."""
     n = 60000
@@ -149,19 +153,20 @@ def test_k6_blobs_without_hubness_40_batches(A):
                     os.environ.pop(k2, None)
                 else:
                     os.environ[k2] = v2
-    floors = {"one launch per class": (0.01, 0.03, 0.01, 0.03), "merged slices": (0.015, 0.035, 0.03, 0.03)}   # (the claims of the docstring)
+    floors = {"one launch per class": (0.01, 0.03, 0.01, 0.03), "merged slices": (0.01, 0.03, 0.01, 0.03)}   # (the claims of the docstring)
     for form, got in forced.items():
         assert_means_close(got, exact, METRIC_NAMES, floors[form], "k6 blobs, time-sliced, class path forced, " + form)
     # same events in the same order on every node: the two forms differ only in WHEN a finished row becomes visible to the negatives -- and
-    # that is what the merged form's bias is made of (the snapshot experiment of the docstring)
+    # that is what the merged form's bias was made of (the snapshot experiment of the docstring; the class window bounds it)
     assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, floors["merged slices"], "k6 blobs, merged slices against one launch per class")
 
 
-@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 3)])
+@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 5),
+                                         ({"AE_SL_MERGE": "1", "AE_SL_WINDOW": "0"}, 3), ({"AE_SL_MERGE": "1", "AE_SL_WINDOW": "2"}, 5)])
 def test_class_path_runs_every_event_once_in_every_layout(A, knobs, form):
     """One launch per class in its round-6 layouts -- node lines, the events sorted by their slice bits alone (the edges come in class order: the
     overflow class FIRST, key 0) -- and in the layouts they replaced (composite (slice, class position) keys, dense rows + static records),
-    and merged slices: on a graph with hubs and a real overflow class (200 k Higgs-shaped points, 8 columns, k = 6, the class path forced)
+    and merged slices (with the class window of round 6 at its default half palette, without it, and two classes wide): on a graph with hubs and a real overflow class (200 k Higgs-shaped points, 8 columns, k = 6, the class path forced)
     every event of the batch's Poisson totals runs exactly once (the executed count within 6 sigma of nb_sample: a step pointer one class off
     would drop or double 1/15 of a slice), `ae_entropy_optim_slice_form` names the form, and the layouts end at the same cross entropy (5 %:
     one run against one run, three batches from a random start, the slices' class orders drawn differently: measured 2.1 % apart)."""

@@ -6,7 +6,9 @@ slices:
   * workgroups dispatched in index order onto a bounded number of slots never deadlock: an event only waits for a workgroup that was
     dispatched before its own;
   * the words clean themselves: after the slice every word is zero again (the node's last event wipes it);
-  * a chain through a shared target stands in the node's order as ONE event (its head waits, its last member announces it).
+  * a chain through a shared target stands in the node's order as ONE event (its head waits, its last member announces it);
+  * the CLASS WINDOW (round 6: a workgroup of class position q begins once every workgroup of position q - window is through -- what
+    bounds the age of the negatives' rows) adds no deadlock under the same in-order dispatch, whatever the slots, and holds what it says.
 No GPU, no library: pure Python."""
 import numpy as np
 import pytest
@@ -32,8 +34,9 @@ def random_slice(rng, n_nodes, n_events, classes):
     return ev
 
 
-def run_merged(ev, n_nodes, classes, slots, wg, rng):
-    """Executes the slice as the kernel does.  Returns the per-node execution log [(class, event index)]."""
+def run_merged(ev, n_nodes, classes, slots, wg, rng, window=0):
+    """Executes the slice as the kernel does.  Returns the per-node execution log [(class, event index)].
+    window > 0: a workgroup of class q begins only when the workgroups of class q - window are all through (one counter per class)."""
     cls_word = np.zeros(n_nodes, np.int64)     # low half of the word: classes with an event on the node
     done_word = np.zeros(n_nodes, np.int64)    # high half: classes through with the node
     for i, j, q in ev:                         # the marks (the slice before, or sl_dep_mark_kernel)
@@ -52,6 +55,10 @@ def run_merged(ev, n_nodes, classes, slots, wg, rng):
         if x == n or ev[x][2] != ev[start][2] or x - start == wg:
             groups.append(list(range(start, x)))
             start = x
+    group_class = [ev[g[0]][2] for g in groups]
+    groups_of_class = np.bincount(group_class, minlength=classes)
+    class_done = np.zeros(classes, np.int64)       # SliceRunArgs::class_done
+    begun = [False] * len(groups)
     log = [[] for _ in range(n_nodes)]
     attracted = [False] * n
     finished = [False] * n
@@ -64,6 +71,13 @@ def run_merged(ev, n_nodes, classes, slots, wg, rng):
         order = list(resident)
         rng.shuffle(order)                                           # any interleaving of the resident workgroups
         for g in order:
+            if not begun[g]:
+                qg = group_class[g]
+                if window and qg >= window and class_done[qg - window] < groups_of_class[qg - window]:
+                    continue                                         # polls its window's counter (holds its slot meanwhile)
+                if window and qg >= window:                          # what the window says: that class is through, every event of it
+                    assert all(finished[x] for x in range(n) if ev[x][2] == qg - window)
+                begun[g] = True
             lanes = list(groups[g])
             rng.shuffle(lanes)                                       # lane by lane: any order inside a wave
             for x in lanes:
@@ -90,6 +104,9 @@ def run_merged(ev, n_nodes, classes, slots, wg, rng):
                         cls_word[i] = 0; done_word[i] = 0
                     finished[x] = True
                     progress = True
+        for g in resident:
+            if all(finished[x] for x in groups[g]):
+                class_done[group_class[g]] += 1
         resident = [g for g in resident if not all(finished[x] for x in groups[g])]
         steps += 1
         assert progress, "no resident lane could run: deadlock (step %d, %d groups resident, next %d of %d)" % (steps, len(resident), next_group, len(groups))
@@ -114,6 +131,20 @@ def test_node_order_is_the_class_order_and_nothing_hangs(seed, slots):
                 assert log[v][a][1] > log[v][a - 1][1], (v, log[v])
         seen += len(qs)
     assert seen == 2 * len(ev)                         # every event ran once, on both its rows
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("slots,window", [(1, 1), (2, 1), (3, 2), (64, 3), (5, 8)])
+def test_class_window_neither_hangs_nor_reorders(seed, slots, window):
+    rng = np.random.default_rng(100 + seed)
+    classes = int(rng.integers(3, 16))
+    n_nodes = int(rng.integers(20, 200))
+    ev = random_slice(rng, n_nodes, int(rng.integers(50, 400)), classes)
+    log = run_merged(ev, n_nodes, classes, slots=slots, wg=int(rng.choice([2, 4, 8])), rng=rng, window=window)
+    for v in range(n_nodes):
+        qs = [q for q, _ in log[v]]
+        assert qs == sorted(qs), (v, log[v])
+    assert sum(len(l) for l in log) == 2 * len(ev)
 
 
 def test_a_hub_chain_counts_as_one_event_of_its_node():

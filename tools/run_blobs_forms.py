@@ -8,6 +8,7 @@ variants that look for the merged form's bias (+0.7 % CE, -1.5 % median edge at 
 usage: python tools/run_blobs_forms.py [n_seeds] [variants: comma list of exact,per_class,merged,optimistic,late,ov_every,base11,pc15]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -44,6 +45,14 @@ VARIANTS = {
     "pc_snap1": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="1")),
     "pc_snap4": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="4")),
     "pc_snap16": (A.AE_CE_SLICED, dict(K, AE_SL_NO_MERGE="1", AE_SL_NEG_SNAPSHOT="16")),
+    # the class window of the merged launches: a workgroup starts once the classes `window` positions before it are through, rows written through
+    "win1": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="1")),
+    "win2": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="2")),
+    "win3": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="3")),
+    "win4": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="4")),
+    "win8": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="8")),
+    "win6": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="6")),
+    "win32": (A.AE_CE_SLICED, dict(K, AE_SL_MERGE="1", AE_SL_WINDOW="32")),   # (beyond the palette: nobody waits -- what the written-through rows and the loads past the caches do alone)
     "ordered": (A.AE_CE_ORDERED, {}),
     "event": (A.AE_CE_EVENT, {}),
 }
@@ -53,9 +62,11 @@ def rows(mode, knobs):
     os.environ.update(knobs)
     try:
         out = []
+        t0 = time.perf_counter()
         for sd in seeds:
             y, ce, _ = T._run_ce(A, g, npar, y0, 40, mode, seed=sd)
             out.append(T._metrics(indptr, nbr, y, ce))
+        print("  (%.2f s per seed: 40 batches, handle and metrics included)" % ((time.perf_counter() - t0) / len(seeds)), flush=True)
         return np.array(out)
     finally:
         for k in knobs:
