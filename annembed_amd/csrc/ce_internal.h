@@ -129,9 +129,6 @@ struct ae_entropy_optim {
     DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
     DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
-    DevBuf<uint32_t> sl_vb_start, sl_cls_vb;    // events bucketed at generation: the virtual blocks' first edges (cut at the class boundaries; nvb + 1), the first block of every class key
-    DevBuf<uint32_t> sl_bhist, sl_bscan;        // ... a segment's events per [slice][block], and their exclusive scan (+ 1: the total)
-    uint32_t sl_nvb = 0;                        // virtual blocks (0: the handle's generation order is not bucketed)
     DevBuf<unsigned long long> sl_dep;          // merged slices: per node, classes through with the node << 32 | classes with an event on it; all zero between slices
     DevBuf<uint32_t> sl_chunk_flag;             // hand-over flags of the hub chains, one per 64-event chunk of the sorted events
     DevBuf<uint32_t> sl_hub_pool;               // (hubness weighting) the batch's pool of NodeSampler draws for the tiles of negatives

@@ -271,8 +271,12 @@ __global__ void __launch_bounds__(256) sl_backlog_kernel(uint64_t n, const float
 // ------------------------------------------------------------------------------------------------------------------
 // events of a batch segment
 // ------------------------------------------------------------------------------------------------------------------
-// the number of events of generation-order edge e in a batch segment: Poisson(mu), capped at 255
-__device__ __forceinline__ uint32_t edge_event_count(uint64_t e, uint32_t ck, float mu) {
+// (e: position in the event-generation order of the edges, slice_color_edges)
+__global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, const EdgeRec* __restrict__ erec, float unit, uint32_t key, uint32_t* __restrict__ cnt) {
+    const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
+    if (e >= n_gen) return;
+    const uint32_t ck = round_hash_key(key, c.seed) ^ kTagSlCount;
+    const float mu = unit * erec[e].w;
     const float u = edge_uniform(e, ck);
     float p = __expf(-mu), cdf = p;
     uint32_t k = 0;
@@ -281,13 +285,7 @@ __device__ __forceinline__ uint32_t edge_event_count(uint64_t e, uint32_t ck, fl
         p *= mu * (1.0f / (float)k);
         cdf += p;
     }
-    return k;
-}
-// (e: position in the event-generation order of the edges, slice_color_edges)
-__global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, const EdgeRec* __restrict__ erec, float unit, uint32_t key, uint32_t* __restrict__ cnt) {
-    const uint64_t e = blockIdx.x * 256ull + threadIdx.x;
-    if (e >= n_gen) return;
-    cnt[e] = edge_event_count(e, round_hash_key(key, c.seed) ^ kTagSlCount, unit * erec[e].w);
+    cnt[e] = k;
 }
 // (step key, event) of every event, at the edge's offset.  step key = slice * (classes + 1) + position of the edge's class in the
 // slice's class order (class_pos[slice][class]; overflow last).  The slices of an edge's events are i.i.d. uniform.  REPEATS of an
@@ -301,50 +299,14 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 // (Round 6: the same kernel with its writes through a wave-private LDS stage -- every thread drops its keys at its run's place, the wave
 // then stores the stretch 64 places at a time, the records fetched from their lanes by shuffles: fully coalesced stores -- was built and
 // measured: 134.2 against 134.2 ms per configs[3] batch.  The kernel is not bound by how its stores coalesce; commit d82df92 holds the code.)
-constexpr uint32_t kSortMax = 24;
-// The slices of the k events of generation-order edge e (the rule above).  prepare(): k in [2, kSortMax] -- the k slices in ascending
-// order into the thread's scratch column sl[r * 256] (LDS: dynamic indexing), the repeats inside a slice dealt with; slice(r): the
-// r-th event's slice (scratch, or drawn on the fly for a single event / more than kSortMax of them), the overflow class's cadence applied.
-template <typename T>
-struct EdgeSlices {
-    T* sl;
-    uint32_t e32, tk, n_slices;
-    bool sorted;
-    __device__ __forceinline__ uint32_t draw(uint32_t r) const { return __umulhi(pcg_hash((pcg_hash(e32) + r * 0x9E3779B9u) ^ tk), n_slices); }
-    __device__ __forceinline__ void prepare(uint64_t e, uint32_t k, uint32_t tk_, uint32_t n_slices_, int spread, uint32_t flags, float ev_per_mass) {
-        e32 = (uint32_t)e; tk = tk_; n_slices = n_slices_;
-        sorted = spread && k > 1 && k <= kSortMax && k <= n_slices;
-        if (!sorted) return;
-#define SL(r) sl[(r) * 256u]
-        for (uint32_t r = 0; r < k; r++) {   // (insertion sort)
-            const uint32_t s = draw(r);
-            uint32_t q = r;
-            while (q > 0 && (uint32_t)SL(q - 1) > s) { SL(q) = SL(q - 1); q--; }
-            SL(q) = (T)s;
-        }
-        // p_stay: the probability that NO other event of the edge's end points falls between two events of the edge that share a slice,
-        // in the i.i.d. sequence the slices stand for: the two at uniform places of the slice (distance x: density 2 (1 - x)), the
-        // others a Poisson stream of rate rho per slice: 2 (rho - 1 + exp(-rho)) / rho^2
-        const float rho = (float)(flags & kEndMassMask) * (1.0f / 256.0f) * ev_per_mass;
-        const float p_stay = spread == 1 ? 0.f : (rho < 0.05f ? 1.f - rho * (1.0f / 3.0f) : 2.f * (rho - 1.f + __expf(-rho)) / (rho * rho));
-        for (uint32_t r = 1; r < k; r++) {
-            if ((uint32_t)SL(r) > (uint32_t)SL(r - 1)) continue;
-            const float u = (float)(pcg_hash((pcg_hash(e32) ^ 0x5851F42Du) + r * 0x9E3779B9u + tk) >> 8) * (1.0f / 16777216.0f);
-            SL(r) = (T)((uint32_t)SL(r - 1) + (u < p_stay ? 0u : 1u));
-        }
-        // what ran past the end of the segment is pulled back from the top
-        if ((uint32_t)SL(k - 1) >= n_slices) {
-            SL(k - 1) = (T)(n_slices - 1u);
-            for (uint32_t r = k - 1; r > 0 && (uint32_t)SL(r - 1) > (uint32_t)SL(r); r--) SL(r - 1) = SL(r);
-        }
-    }
-    __device__ __forceinline__ uint32_t slice(uint32_t r, bool overflow_class, uint32_t ov_every) const {
-        uint32_t s = sorted ? (uint32_t)SL(r) : draw(r);
-        if (overflow_class && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
-        return s;
-#undef SL
-    }
-};
+// (Round 6, too: the events BUCKETED AT GENERATION -- the edges come in class order, so a virtual block of 512 edges of one class counts its
+// events per slice, a scan over [slice][block] gives every block's place in every slice and the step pointers, and a second pass draws the
+// events again, ranks them by slice inside the block (stably, in LDS: eight ballots per 64 events) and stores each slice's run in one
+// piece: no keys, no radix pass, 12 bytes an event written once.  Word for word the events and step pointers of this path (checked on the
+// device), and SLOWER: count pass 3.7 ms + fill pass 14.3 ms against 16.5 ms for count + scan + fill + the radix pass; 135.9 against 133.3 ms
+// per configs[3] batch.  Drawing an edge's slices (the sort and the repeat rule below) is a third of this kernel's time and is paid twice
+// there, and the ranking runs at two workgroups per CU under 75 KB of LDS.  Commit f2c9fab holds the code; profiles/r06/r6_c4_buckets_ab.jsonl,
+// r6_evgen_buckets_kernel_stats_top.txt.)
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
@@ -357,12 +319,37 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     const uint8_t cl = color[e];
     const EdgeRec er = erec[e];
     const Event evv{er.im, er.j | (er.flags & kHalfEvent), er.w};
-    __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge
-    EdgeSlices<uint32_t> es;
-    es.sl = s_sl + threadIdx.x;
-    es.prepare(e, k, tk, n_slices, spread, er.flags, ev_per_mass);
+    constexpr uint32_t kSortMax = 24;
+    __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge (dynamic indexing: LDS, not scratch)
+    uint32_t* sl = s_sl + threadIdx.x;
+#define SL(r) sl[(r) * 256u]
+    const bool sorted = spread && k > 1 && k <= kSortMax && k <= n_slices;
+    if (sorted) {  // the k slices in ascending order (insertion sort); then the repeats inside a slice are dealt with
+        for (uint32_t r = 0; r < k; r++) {
+            const uint32_t s = __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
+            uint32_t q = r;
+            while (q > 0 && SL(q - 1) > s) { SL(q) = SL(q - 1); q--; }
+            SL(q) = s;
+        }
+        // p_stay: the probability that NO other event of the edge's end points falls between two events of the edge that share a slice,
+        // in the i.i.d. sequence the slices stand for: the two at uniform places of the slice (distance x: density 2 (1 - x)), the
+        // others a Poisson stream of rate rho per slice: 2 (rho - 1 + exp(-rho)) / rho^2
+        const float rho = (float)(er.flags & kEndMassMask) * (1.0f / 256.0f) * ev_per_mass;
+        const float p_stay = spread == 1 ? 0.f : (rho < 0.05f ? 1.f - rho * (1.0f / 3.0f) : 2.f * (rho - 1.f + __expf(-rho)) / (rho * rho));
+        for (uint32_t r = 1; r < k; r++) {
+            if (SL(r) > SL(r - 1)) continue;
+            const float u = (float)(pcg_hash((pcg_hash((uint32_t)e) ^ 0x5851F42Du) + r * 0x9E3779B9u + tk) >> 8) * (1.0f / 16777216.0f);
+            SL(r) = SL(r - 1) + (u < p_stay ? 0u : 1u);
+        }
+        // what ran past the end of the segment is pulled back from the top
+        if (SL(k - 1) >= n_slices) {
+            SL(k - 1) = n_slices - 1u;
+            for (uint32_t r = k - 1; r > 0 && SL(r - 1) > SL(r); r--) SL(r - 1) = SL(r);
+        }
+    }
     for (uint32_t r = 0; r < k; r++) {
-        const uint32_t s = es.slice(r, cl >= classes, ov_every);
+        uint32_t s = sorted ? SL(r) : __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
+        if (cl >= classes && ov_every > 1u) s = min(n_slices - 1u, s - s % ov_every + ov_every / 2u);   // (a thin overflow class runs in every ov_every-th slice: ce_slice_gradient_iteration)
         // class_pos null: one launch per class -- the key is (slice << kClsBits) | class, sorted on its slice bits alone (the edges come in
         // class order); else merged slices: slice * (classes + 1) + the class's POSITION in the slice's order
         // (the overflow class is 0 there, class c is 1 + c: the ORDER the edges are generated in -- the sort on the slice bits is stable, the
@@ -371,186 +358,7 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
         keys[o + r] = class_pos ? s * (classes + 1u) + (cl < classes ? (uint32_t)class_pos[s * classes + cl] : classes) : (s << kClsBits) | cls;
         vals[o + r] = evv;
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// EVENTS BUCKETED AT GENERATION (round 6; one launch per class, <= 256 slices).  The edges are generated in class order, so the events
-// of a segment sorted by (slice, class, edge) are the events sorted by slice, STABLY: a virtual block of kVbEdges consecutive edges of
-// one class (sl_vb_start: cut at the class boundaries) counts its events per slice (pass 1), an exclusive scan over [slice][block]
-// turns the counts into every block's place in every slice -- and into the step pointers: a class starts where its first block does --,
-// and pass 2 draws the same events again, ranks them by slice inside the block (in LDS, stably: edge order, then event order -- the
-// members of a chain through a shared target stay side by side) and stores each slice's run in one piece.  Against count + scan + fill
-// (key and event, 16 bytes an event) + the radix pass over both (16 in, 16 out) + the binary searches: 12 bytes an event written once.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kVbEdges = 512;      // edges of a virtual block: two per thread
-constexpr uint32_t kVbCap = 8192;       // events ranked at a time (a block with more takes them in ranges of its event list)
-constexpr uint32_t kVbListBytes = 6u * kVbCap;   // the list and the sorted list: a slice (1 byte) and an edge of the block (2) per event, twice
-__global__ void __launch_bounds__(256) sl_bucket_count_kernel(CeDev c, const uint32_t* __restrict__ vb_start, uint32_t nvb, uint32_t key, float unit, uint32_t n_slices,
-                                                              const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color, uint32_t classes, int spread,
-                                                              float ev_per_mass, uint32_t ov_every, uint32_t* __restrict__ bhist) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint16_t s_sl[kSortMax * 256];
-    const uint32_t b = blockIdx.x, e0 = vb_start[b], e1 = vb_start[b + 1];
-    hist[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t rk = round_hash_key(key, c.seed), ck = rk ^ kTagSlCount, tk = pcg_hash(rk ^ kTagSlTime);
-    EdgeSlices<uint16_t> es;
-    es.sl = s_sl + threadIdx.x;
-    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256u) {
-        const EdgeRec er = erec[e];
-        const uint32_t k = edge_event_count(e, ck, unit * er.w);
-        if (!k) continue;
-        const bool ovc = color[e] >= classes;
-        es.prepare(e, k, tk, n_slices, spread, er.flags, ev_per_mass);
-        for (uint32_t r = 0; r < k; r++) atomicAdd(&hist[es.slice(r, ovc, ov_every)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < n_slices) bhist[(uint64_t)threadIdx.x * nvb + b] = hist[threadIdx.x];
-}
-// exclusive scan of one value per thread over the 256 threads of the block (part: 4 words of LDS); total: the block's sum
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* part, uint32_t& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) part[w] = inc;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int q = 0; q < 4; q++) before += q < w ? part[q] : 0u;
-    total = part[0] + part[1] + part[2] + part[3];
-    __syncthreads();
-    return before + inc - v;
-}
-__global__ void __launch_bounds__(256) sl_bucket_fill_kernel(CeDev c, const uint32_t* __restrict__ vb_start, uint32_t nvb, uint32_t key, float unit, uint32_t n_slices,
-                                                             const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color, uint32_t classes, int spread,
-                                                             float ev_per_mass, uint32_t ov_every, const uint32_t* __restrict__ bscan, Event* __restrict__ out) {
-    __shared__ uint16_t s_sl[kSortMax * 256];
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_lists[];   // (kVbListBytes: with the static arrays beyond the 64 KB a launch gets by default)
-    uint16_t* const list_edge = reinterpret_cast<uint16_t*>(s_lists);
-    uint16_t* const sorted_edge = list_edge + kVbCap;
-    uint8_t* const list_slice = s_lists + 4u * kVbCap;
-    uint8_t* const sorted_slice = list_slice + kVbCap;
-    __shared__ Event edata[kVbEdges];
-    __shared__ uint32_t whist[4][256], lbase[256], tot[256], goff[256], part[4];
-    const uint32_t b = blockIdx.x, e0 = vb_start[b], e1 = vb_start[b + 1];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t rk = round_hash_key(key, c.seed), ck = rk ^ kTagSlCount, tk = pcg_hash(rk ^ kTagSlTime);
-    if (tid < n_slices) goff[tid] = bscan[(uint64_t)tid * nvb + b];
-    // this thread's two edges (consecutive: the block's event list is in edge order), their counts, their place in the list
-    EdgeRec er[2];
-    uint32_t k[2] = {0u, 0u};
-    bool ovc[2] = {false, false};
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const uint32_t e = e0 + 2u * tid + (uint32_t)q;
-        if (e < e1) {
-            er[q] = erec[e];
-            k[q] = edge_event_count(e, ck, unit * er[q].w);
-            ovc[q] = color[e] >= classes;
-            edata[2u * tid + (uint32_t)q] = Event{er[q].im, er[q].j | (er[q].flags & kHalfEvent), er[q].w};
-        }
-    }
-    uint32_t total = 0;
-    const uint32_t off0 = block_scan_256(k[0] + k[1], part, total);
-    EdgeSlices<uint16_t> es;
-    es.sl = s_sl + tid;
-    for (uint32_t r0 = 0; r0 < total; r0 += kVbCap) {   // (one range unless the block holds more than kVbCap events)
-        const uint32_t tr = min(kVbCap, total - r0);
-        for (int q = 0; q < 4; q++) whist[q][tid] = 0u;
-        // a. the range's events into the list: (slice, edge)
-        uint32_t at = off0;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (k[q] && at < r0 + tr && at + k[q] > r0) {
-                es.prepare(e0 + 2u * tid + (uint32_t)q, k[q], tk, n_slices, spread, er[q].flags, ev_per_mass);
-                for (uint32_t r = 0; r < k[q]; r++) {
-                    const uint32_t idx = at + r;
-                    if (idx >= r0 && idx < r0 + tr) {
-                        list_slice[idx - r0] = (uint8_t)es.slice(r, ovc[q], ov_every);
-                        list_edge[idx - r0] = (uint16_t)(2u * tid + (uint32_t)q);
-                    }
-                }
-            }
-            at += k[q];
-        }
-        __syncthreads();
-        // b. every wave counts its quarter of the list
-        const uint32_t chunk = ((tr + 255u) >> 8) << 6, w_begin = min(tr, w * chunk), w_end = min(tr, w_begin + chunk);
-        for (uint32_t idx = w_begin + lane; idx < w_end; idx += 64u) atomicAdd(&whist[w][list_slice[idx]], 1u);
-        __syncthreads();
-        // c. a slice's run inside the block's sorted list, and where each wave's share of it starts
-        {
-            const uint32_t h0 = whist[0][tid], h1 = whist[1][tid], h2 = whist[2][tid], h3 = whist[3][tid];
-            uint32_t dummy;
-            const uint32_t base = block_scan_256(h0 + h1 + h2 + h3, part, dummy);
-            lbase[tid] = base;
-            tot[tid] = h0 + h1 + h2 + h3;
-            whist[0][tid] = base; whist[1][tid] = base + h0; whist[2][tid] = base + h0 + h1; whist[3][tid] = base + h0 + h1 + h2;
-        }
-        __syncthreads();
-        // d. stable ranks: a wave walks its quarter 64 events at a time; the lanes that hold the same slice find one another (eight ballots)
-        //    and take consecutive places behind the wave's running count of that slice
-        volatile uint32_t* run = whist[w];
-        for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64u) {
-            const uint32_t idx = i0 + lane;
-            const bool valid = idx < w_end;
-            const uint32_t sv = valid ? (uint32_t)list_slice[idx] : 0u;
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int bit = 0; bit < 8; bit++) {
-                const unsigned long long bb = __ballot(valid && ((sv >> bit) & 1u));
-                peers &= ((sv >> bit) & 1u) ? bb : ~bb;
-            }
-            const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-            uint32_t place = 0;
-            if (valid) place = run[sv] + rank;
-            __builtin_amdgcn_wave_barrier();
-            if (valid && rank == 0u) run[sv] = place + (uint32_t)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                sorted_slice[place] = (uint8_t)sv;
-                sorted_edge[place] = list_edge[idx];
-            }
-        }
-        __syncthreads();
-        // e. the sorted list out: a slice's run is one piece of the slice's events
-        for (uint32_t ks = tid; ks < tr; ks += 256u) {
-            const uint32_t sv = sorted_slice[ks];
-            out[goff[sv] + (ks - lbase[sv])] = edata[sorted_edge[ks]];
-        }
-        __syncthreads();
-        goff[tid] += tot[tid];
-        __syncthreads();
-    }
-}
-// step pointers of the bucketed events: (slice, class key) starts where the first virtual block of the class does (cls_vb[key]; nvb for
-// the keys beyond the palette: the next slice's start); sptr[n_keys] = the segment's events
-__global__ void sl_bucket_sptr_kernel(const uint32_t* __restrict__ bscan, uint32_t nvb, const uint32_t* __restrict__ cls_vb, uint32_t n_slices, uint32_t n_keys,
-                                      uint32_t* __restrict__ sptr) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x > n_keys) return;
-    const uint32_t sidx = x >> kClsBits, cidx = x & ((1u << kClsBits) - 1u);
-    sptr[x] = x == n_keys ? bscan[(uint64_t)n_slices * nvb] : bscan[(uint64_t)sidx * nvb + cls_vb[cidx]];
-}
-// (AE_SL_CHECK_BUCKETS) words that differ between two arrays
-__global__ void __launch_bounds__(256) sl_diff_words_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ y, uint64_t words, unsigned long long* __restrict__ out) {
-    unsigned long long c = 0;
-    for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < words; q += (uint64_t)gridDim.x * 256ull) c += x[q] != y[q] ? 1ull : 0ull;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
-}
-// the first generation-order edge of every class key (the keys ascend: lower bounds)
-__global__ void sl_class_starts_kernel(const uint32_t* __restrict__ sorted_class_keys, uint64_t n_gen, uint32_t n_out, unsigned long long* __restrict__ out) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n_out) return;
-    uint64_t lo = 0, hi = n_gen;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (sorted_class_keys[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    out[x] = lo;
+#undef SL
 }
 // (hubness weighting) the batch's pool of i.i.d. draws of the NodeSampler (embedder.rs:927-930), ce_slice_kernels.h: TileFetch
 __global__ void __launch_bounds__(256) sl_hub_pool_kernel(CeDev c, uint32_t key, uint32_t count, uint32_t* __restrict__ pool) {
@@ -796,7 +604,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
     o->sl_cross_frac = 0.;
     o->sl_erec_gen.release();
     o->sl_color_gen.release();
-    o->sl_nvb = 0;
     const unsigned grid = blocks_for(nnz, 256), ngrid = blocks_for(n, 256);
     DevBuf<uint32_t> group_key, ident;
     group_key.alloc_pooled(nnz); ident.alloc_pooled(nnz);
@@ -866,29 +673,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
                                (const EdgeRec*)erec, (const uint8_t*)o->sl_color.p, (const uint32_t*)(o->sl_perm.n ? o->sl_perm.p : nullptr),
                                reinterpret_cast<EdgeRec*>(o->sl_erec_gen.p), o->sl_color_gen.p);
         check_launch("sl_permute_edges");
-        // events bucketed at generation (sl_bucket_*): the virtual blocks of the generation order, cut where a class ends
-        if (n_gen && n_gen < (1ull << 32) && o->sl_classes) {
-            const uint32_t n_cls_keys = (uint32_t)o->sl_classes + 2u;   // key 0: the overflow class, 1 + c: class c; one beyond: the end
-            DevBuf<unsigned long long> d_starts;
-            d_starts.alloc_pooled(n_cls_keys);
-            hipLaunchKernelGGL(sl_class_starts_kernel, dim3(1), dim3(256), 0, stream(), (const uint32_t*)key_out.p, (uint64_t)n_gen, n_cls_keys, d_starts.p);
-            const std::vector<unsigned long long> starts = d_starts.to_host();
-            std::vector<uint32_t> vb, cls_vb(1u << kClsBits, 0u);
-            for (uint32_t ck = 0; ck + 1u < n_cls_keys; ck++) {
-                cls_vb[ck] = (uint32_t)vb.size();   // (an empty class: the next one's first block)
-                for (unsigned long long e = starts[ck]; e < starts[ck + 1u]; e += kVbEdges) vb.push_back((uint32_t)e);
-            }
-            const uint32_t nvb = (uint32_t)vb.size();
-            for (uint32_t ck = n_cls_keys - 1u; ck < (1u << kClsBits); ck++) cls_vb[ck] = nvb;   // (keys beyond the palette: the next slice's start)
-            vb.push_back((uint32_t)n_gen);
-            if (starts[n_cls_keys - 1u] == n_gen && nvb) {
-                o->sl_vb_start.alloc(vb.size());
-                o->sl_vb_start.upload(vb.data(), vb.size());
-                o->sl_cls_vb.alloc(cls_vb.size());
-                o->sl_cls_vb.upload(cls_vb.data(), cls_vb.size());
-                o->sl_nvb = nvb;
-            }
-        }
         sync();
         o->sl_erec.release();   // (the generation order is what the batches read)
         o->sl_color.release();
@@ -1264,22 +1048,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_backlog.download(&backlog, 1);
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list
-    // EVENTS BUCKETED AT GENERATION (sl_bucket_*: one launch per class, the edges in class order, <= 256 slices): the events leave the
-    // generator in (slice, class, edge) order -- no keys, no sort, no second buffer
-    const bool bucketed = slice_keys && classes && o->sl_nvb && n_slices <= 256u && !debug_knob("AE_SL_NO_BUCKETS");
-    const uint32_t nvb = o->sl_nvb;
-    const bool check_buckets = bucketed && debug_knob("AE_SL_CHECK_BUCKETS");   // (test: the sorting path runs beside it, events and step pointers compared word for word)
-    if (bucketed) {
-        const uint64_t nb = (uint64_t)n_slices * nvb + 1u;
-        if (o->sl_bhist.n < nb) { o->sl_bhist.alloc(nb); o->sl_bscan.alloc(nb); }
-        if (o->sl_vals0.n < 3 * ev_cap) o->sl_vals0.alloc(3 * ev_cap);   // (Event: three words)
-    }
-    if (!bucketed || check_buckets) {
-        if (o->sl_cnt.n < n_gen + 1) { o->sl_cnt.alloc(n_gen + 1); o->sl_offs.alloc(n_gen + 1); }
-        if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); }
-        if (o->sl_vals0.n < 3 * ev_cap) o->sl_vals0.alloc(3 * ev_cap);
-        if (o->sl_vals1.n < 3 * ev_cap) o->sl_vals1.alloc(3 * ev_cap);
-    }
+    if (o->sl_cnt.n < n_gen + 1) { o->sl_cnt.alloc(n_gen + 1); o->sl_offs.alloc(n_gen + 1); }
+    if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(3 * ev_cap); o->sl_vals1.alloc(3 * ev_cap); }   // (Event: three words)
     if (o->sl_sptr.n < n_keys + 2) o->sl_sptr.alloc(n_keys + 2);
     if (has_overflow && o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4);
     if ((uint64_t)kSub * cap >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: pending lists beyond 2^32 entries");
@@ -1491,102 +1261,36 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
             }
             if (classes) o->sl_class_pos.upload(class_pos.data(), class_pos.size());
         }
-        uint32_t total = 0;
-        Event* sorted_ev = ev0;
-        double t_cnt = 0., t_fill = 0., t_sort = 0.;
-        if (bucketed) {
-            static bool attr_set = false;
-            if (!attr_set) {   // (static + dynamic LDS beyond the 64 KB a launch may ask for by default)
-                AE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sl_bucket_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVbListBytes));
-                attr_set = true;
-            }
-            const uint64_t nb = (uint64_t)n_slices * nvb + 1u;
-            const float unit = (float)(seg_samples / (double)n), ev_per_mass = (float)(seg_samples / (double)n / (double)n_slices);
-            AE_HIP(hipMemsetAsync(o->sl_bhist.p + (nb - 1u), 0, sizeof(uint32_t), stream()));
-            hipLaunchKernelGGL(sl_bucket_count_kernel, dim3(nvb), dim3(256), 0, stream(), o->dev, (const uint32_t*)o->sl_vb_start.p, nvb, key, unit, n_slices, gen_erec, gen_color,
-                               classes, spread, ev_per_mass, ov_every, o->sl_bhist.p);
-            {
-                size_t tmp_bytes = 0;
-                if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_bhist.p, o->sl_bscan.p, 0u, nb, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
-                    fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan (size query) failed");
-                DevBuf<char> tmp;
-                tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-                if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_bhist.p, o->sl_bscan.p, 0u, nb, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
-                    fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan failed");
-            }
-            AE_HIP(hipMemcpyAsync(&total, o->sl_bscan.p + (nb - 1u), 4, hipMemcpyDeviceToHost, stream()));
-            sync();
-            t_cnt = wall();
-            if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
-            hipLaunchKernelGGL(sl_bucket_fill_kernel, dim3(nvb), dim3(256), kVbListBytes, stream(), o->dev, (const uint32_t*)o->sl_vb_start.p, nvb, key, unit, n_slices, gen_erec,
-                               gen_color, classes, spread, ev_per_mass, ov_every, (const uint32_t*)o->sl_bscan.p, ev0);
-            if (prof) sync();
-            t_fill = t_sort = wall();
-            hipLaunchKernelGGL(sl_bucket_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)o->sl_bscan.p, nvb,
-                               (const uint32_t*)o->sl_cls_vb.p, n_slices, (uint32_t)n_keys, o->sl_sptr.p);
-            if (check_buckets) {   // the sorting path into the second buffers, then word for word
-                DevBuf<uint32_t> ref_sptr;
-                ref_sptr.alloc_pooled(n_keys + 2);
-                Event* const alt = reinterpret_cast<Event*>(o->sl_vals1.p);
-                DevBuf<uint32_t> alt2;
-                alt2.alloc_pooled(3 * ev_cap);
-                hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, unit, key, o->sl_cnt.p);
-                size_t tmp_bytes = 0;
-                (void)rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream());
-                DevBuf<char> tmp;
-                tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-                (void)rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream());
-                hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
-                                   (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color, (const uint8_t*)nullptr, classes, spread, ev_per_mass, ov_every, o->sl_keys0.p, alt);
-                Event* const alt_second = reinterpret_cast<Event*>(alt2.p);
-                const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, alt, alt_second, total, kbegin, kbits);
-                hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), (const uint32_t*)(in_second ? o->sl_keys1.p : o->sl_keys0.p), total,
-                                   (uint32_t)n_keys, ref_sptr.p);
-                DevBuf<unsigned long long> bad;
-                bad.alloc_pooled(2);
-                bad.zero();
-                hipLaunchKernelGGL(sl_diff_words_kernel, dim3(1024), dim3(256), 0, stream(), reinterpret_cast<const uint32_t*>(ev0),
-                                   reinterpret_cast<const uint32_t*>(in_second ? alt_second : alt), 3ull * total, bad.p);
-                hipLaunchKernelGGL(sl_diff_words_kernel, dim3(64), dim3(256), 0, stream(), (const uint32_t*)o->sl_sptr.p, (const uint32_t*)ref_sptr.p, n_keys + 1, bad.p + 1);
-                const std::vector<unsigned long long> hb = bad.to_host();
-                if (hb[0] || hb[1]) {
-                    char msg[200];
-                    snprintf(msg, sizeof msg, "AE_SL_CHECK_BUCKETS: %llu event words and %llu step pointers differ from the sorting path (%u events)", hb[0], hb[1], total);
-                    fail(AE_ERR_STATE, msg);
-                }
-            }
-        } else {
-            hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, (float)(seg_samples / (double)n), key, o->sl_cnt.p);
-            {
-                size_t tmp_bytes = 0;
-                if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
-                    fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan (size query) failed");
-                DevBuf<char> tmp;
-                tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-                if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
-                    fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan failed");
-            }
-            uint32_t last[2];
-            AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
-            AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
-            sync();
-            t_cnt = wall();
-            total = last[0] + last[1];
-            if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
-            hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
-                               (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
-                               slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
-                               ov_every, o->sl_keys0.p, ev0);
-            if (prof) sync();
-            t_fill = wall();
-            const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
-            const uint32_t* sorted_keys = in_second ? o->sl_keys1.p : o->sl_keys0.p;
-            sorted_ev = in_second ? ev1 : ev0;
-            if (prof) sync();
-            t_sort = wall();
-            hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), sorted_keys, total, (uint32_t)n_keys,
-                               o->sl_sptr.p);
+        hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, (float)(seg_samples / (double)n), key, o->sl_cnt.p);
+        {
+            size_t tmp_bytes = 0;
+            if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+                fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan (size query) failed");
+            DevBuf<char> tmp;
+            tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
+            if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+                fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan failed");
         }
+        uint32_t last[2];
+        AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
+        sync();
+        const double t_cnt = wall();
+        const uint32_t total = last[0] + last[1];
+        if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
+        hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
+                           (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
+                           slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
+                           ov_every, o->sl_keys0.p, ev0);
+        if (prof) sync();
+        const double t_fill = wall();
+        const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
+        const uint32_t* sorted_keys = in_second ? o->sl_keys1.p : o->sl_keys0.p;
+        Event* sorted_ev = in_second ? ev1 : ev0;
+        if (prof) sync();
+        const double t_sort = wall();
+        hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), sorted_keys, total, (uint32_t)n_keys,
+                           o->sl_sptr.p);
         check_launch("sl_events");
         o->sl_sptr.download(hptr.data(), n_keys + 1);
         const double t_ev = wall();
