@@ -323,7 +323,23 @@ __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, u
     __shared__ uint32_t s_sl[kSortMax * 256];  // [r][thread]: the slices of this thread's edge (dynamic indexing: LDS, not scratch)
     uint32_t* sl = s_sl + threadIdx.x;
 #define SL(r) sl[(r) * 256u]
-    const bool sorted = spread && k > 1 && k <= kSortMax && k <= n_slices;
+    bool sorted = (spread & 3) && k > 1 && k <= kSortMax && k <= n_slices;
+    if (sorted && n_slices <= 256u && !(spread & 4)) {
+        // Only an edge with two events in ONE slice needs its slices in order (the repeat rule): a 256-bit set of the slices drawn says
+        // whether there is one (k = 10 events in 240 slices: one edge in five).  Without a repeat the slices go out as drawn -- the events
+        // of an edge are equal and the sort by slice is stable: the sorted array is the same.  (spread bit 4: always in order, for the A/B)
+        unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull;
+        bool dup = false;
+        for (uint32_t r = 0; r < k; r++) {
+            const uint32_t sd = __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices), ws = sd >> 6;
+            const unsigned long long bit = 1ull << (sd & 63u);
+            const unsigned long long cur = ws == 0u ? m0 : (ws == 1u ? m1 : (ws == 2u ? m2 : m3));
+            dup = dup || (cur & bit) != 0ull;
+            m0 |= ws == 0u ? bit : 0ull; m1 |= ws == 1u ? bit : 0ull; m2 |= ws == 2u ? bit : 0ull; m3 |= ws == 3u ? bit : 0ull;
+        }
+        sorted = dup;
+    }
+    spread &= 3;
     if (sorted) {  // the k slices in ascending order (insertion sort); then the repeats inside a slice are dealt with
         for (uint32_t r = 0; r < k; r++) {
             const uint32_t s = __umulhi(pcg_hash((pcg_hash((uint32_t)e) + r * 0x9E3779B9u) ^ tk), n_slices);
@@ -369,6 +385,13 @@ __global__ void __launch_bounds__(256) sl_hub_pool_kernel(CeDev c, uint32_t key,
     const float uu = (float)(pcg_hash(w0 ^ 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
     const uint2 he = c.hub_tab[xs];
     pool[x] = (uu < __uint_as_float(he.x)) ? xs : he.y;
+}
+// (AE_SL_CHECK_FILL) words that differ between two arrays
+__global__ void __launch_bounds__(256) sl_diff_words_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ y, uint64_t words, unsigned long long* __restrict__ out) {
+    unsigned long long c = 0;
+    for (uint64_t q = blockIdx.x * 256ull + threadIdx.x; q < words; q += (uint64_t)gridDim.x * 256ull) c += x[q] != y[q] ? 1ull : 0ull;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 __global__ void sl_sptr_kernel(const uint32_t* __restrict__ keys, uint32_t total, uint32_t n_keys, uint32_t* __restrict__ sptr) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1282,6 +1305,31 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                            (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
                            slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
                            ov_every, o->sl_keys0.p, ev0);
+        if (debug_knob("AE_SL_CHECK_FILL")) {   // (test) the same fill with every edge's slices in order, both sorted: word for word the same events and keys
+            DevBuf<uint32_t> k2, k3, v2, v3;
+            k2.alloc_pooled(total + 1); k3.alloc_pooled(total + 1); v2.alloc_pooled(3ull * total + 3); v3.alloc_pooled(3ull * total + 3);
+            hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
+                               (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
+                               slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread | 4, (float)(seg_samples / (double)n / (double)n_slices),
+                               ov_every, k2.p, reinterpret_cast<Event*>(v2.p));
+            const bool ref_second = sort_events(o, k2.p, k3.p, reinterpret_cast<Event*>(v2.p), reinterpret_cast<Event*>(v3.p), total, kbegin, kbits);
+            DevBuf<uint32_t> k0c, v0c, k1c, v1c;   // (copies: the batch's own sort follows on the originals)
+            k0c.alloc_pooled(total + 1); k1c.alloc_pooled(total + 1); v0c.alloc_pooled(3ull * total + 3); v1c.alloc_pooled(3ull * total + 3);
+            AE_HIP(hipMemcpyAsync(k0c.p, o->sl_keys0.p, 4ull * total, hipMemcpyDeviceToDevice, stream()));
+            AE_HIP(hipMemcpyAsync(v0c.p, ev0, 12ull * total, hipMemcpyDeviceToDevice, stream()));
+            const bool got_second = sort_events(o, k0c.p, k1c.p, reinterpret_cast<Event*>(v0c.p), reinterpret_cast<Event*>(v1c.p), total, kbegin, kbits);
+            DevBuf<unsigned long long> bad;
+            bad.alloc_pooled(2);
+            bad.zero();
+            hipLaunchKernelGGL(sl_diff_words_kernel, dim3(1024), dim3(256), 0, stream(), (const uint32_t*)(got_second ? v1c.p : v0c.p), (const uint32_t*)(ref_second ? v3.p : v2.p), 3ull * total, bad.p);
+            hipLaunchKernelGGL(sl_diff_words_kernel, dim3(1024), dim3(256), 0, stream(), (const uint32_t*)(got_second ? k1c.p : k0c.p), (const uint32_t*)(ref_second ? k3.p : k2.p), (uint64_t)total, bad.p + 1);
+            const std::vector<unsigned long long> hb = bad.to_host();
+            if (hb[0] || hb[1]) {
+                char msg[200];
+                snprintf(msg, sizeof msg, "AE_SL_CHECK_FILL: %llu event words and %llu keys differ from the fill with every edge's slices in order (%u events)", hb[0], hb[1], total);
+                fail(AE_ERR_STATE, msg);
+            }
+        }
         if (prof) sync();
         const double t_fill = wall();
         const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);

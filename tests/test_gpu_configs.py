@@ -161,11 +161,13 @@ def test_k6_blobs_without_hubness_40_batches(A):
     assert_means_close(forced["merged slices"], forced["one launch per class"], METRIC_NAMES, floors["merged slices"], "k6 blobs, merged slices against one launch per class")
 
 
-@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 5),
+@pytest.mark.parametrize("knobs,form", [({}, 2), ({"AE_SL_CHECK_FILL": "1"}, 2), ({"AE_SL_COMPOSITE_KEYS": "1"}, 2), ({"AE_SL_NO_LINES": "1"}, 1), ({"AE_SL_MERGE": "1"}, 5),
                                          ({"AE_SL_MERGE": "1", "AE_SL_WINDOW": "0"}, 3), ({"AE_SL_MERGE": "1", "AE_SL_WINDOW": "2"}, 5)])
 def test_class_path_runs_every_event_once_in_every_layout(A, knobs, form):
     """One launch per class in its round-6 layouts -- node lines, the events sorted by their slice bits alone (the edges come in class order: the
     overflow class FIRST, key 0) -- and in the layouts they replaced (composite (slice, class position) keys, dense rows + static records),
+    `AE_SL_CHECK_FILL`: the event fill's short cut (an edge without two events in one slice sends its slices out as drawn) against the fill
+    with every edge's slices in order, both sorted, compared word for word on the device -- a difference fails the batch;
     and merged slices (with the class window of round 6 at its default half palette, without it, and two classes wide): on a graph with hubs and a real overflow class (200 k Higgs-shaped points, 8 columns, k = 6, the class path forced)
     every event of the batch's Poisson totals runs exactly once (the executed count within 6 sigma of nb_sample: a step pointer one class off
     would drop or double 1/15 of a slice), `ae_entropy_optim_slice_form` names the form, and the layouts end at the same cross entropy (5 %:
