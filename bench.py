@@ -568,7 +568,7 @@ def compact_line(full):
             form = ((dm.get("roofline") or {}).get("sliced") or {}).get("launch_form")
             brief[name] = {"ms": round(dm["ms_per_step"], 2), "points_per_s": round(dm["points_per_s"]), "frac": round(dm["roofline"]["frac"], 4),
                            "frac_whole_batch": round(dm["roofline"]["frac_whole_batch"], 4)}
-            if form:   # (merged / optimistic: the published bias on stiff 2-D graphs applies)
+            if form:   # (optimistic passes, merged slices without their window: the published bias on stiff 2-D graphs applies)
                 brief[name]["form"] = {"one launch per class": "per_class", "one launch per class, node lines": "lines", "merged slices": "merged*", "merged slices, class window": "merged+window",
                                        "optimistic passes": "optimistic*"}.get(form, form)
     if brief:
