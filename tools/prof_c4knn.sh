@@ -4,7 +4,7 @@
 set -u
 TAG=$1; SHAPE=${2:-c4_knn}
 export NEEDLE="sl_direct_kernel<8, 16, true, true, 16>"   # (round 6: the node-line instantiation; <8, 16, true, true, 0> under AE_SL_NO_LINES)
-case $SHAPE in c5*) export NEEDLE="sl_direct_kernel<16, 32, true, true, 32>";; esac
+case $SHAPE in c5*) export NEEDLE="sl_direct_kernel<16, 32, true, true, 32>";; c3*) export NEEDLE="sl_slice_kernel<2, 16, true, true>";; esac   # (c3_knn: merged slices)
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1,4 +1,4 @@
-"""ONE scale shape in the time-sliced mode only (profiling: tools/prof_c4knn.sh): python tools/run_step_shape.py c4_knn|c5_knn [batches]"""
+"""ONE scale shape in the time-sliced mode only (profiling: tools/prof_c4knn.sh): python tools/run_step_shape.py c4_knn|c5_knn|c3_knn [batches]"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ from annembed_amd import _lib as L  # noqa: E402
 
 if which == "c4_knn":
     gr, d, hubw = bench.config_graphs(A, "c4"), 8, True
+elif which == "c3_knn":   # configs[2]'s large graph: merged slices with the class window
+    gr, d, hubw = bench.exact_knn_graph(A, bench.higgs_shaped_points(1_650_000), 6, "Higgs-shaped points"), 2, True
+    gr.setdefault("n", 1_650_000); gr.setdefault("k", 6)
 else:
     gr, d, hubw = bench.config_graphs(A, "c5"), 16, False
 n, k = gr["n"], gr["k"]
