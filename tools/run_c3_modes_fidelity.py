@@ -36,12 +36,19 @@ def run(mode, seed):
 
 
 rows = {}
-for name, mode in (("sequential", A.AE_CE_SEQUENTIAL), ("ordered", A.AE_CE_ORDERED), ("time-sliced", A.AE_CE_SLICED)):
-    out = [run(mode, sd) for sd in seeds]
+for name, mode, knobs in (("sequential", A.AE_CE_SEQUENTIAL, {}), ("ordered", A.AE_CE_ORDERED, {}), ("time-sliced", A.AE_CE_SLICED, {}),
+                          # round 6: the merged slices without their class window (the form of rounds 4-5)
+                          ("time-sliced, no class window", A.AE_CE_SLICED, {"AE_DEBUG_KNOBS": "1", "AE_SL_WINDOW": "0"})):
+    os.environ.update(knobs)
+    try:
+        out = [run(mode, sd) for sd in seeds]
+    finally:
+        for kk in knobs:
+            os.environ.pop(kk, None)
     rows[name] = np.array([o[0] for o in out])
     print(name, "mean", np.round(rows[name].mean(0), 5), out[0][1], flush=True)
 b = rows["sequential"]
-for name in ("ordered", "time-sliced"):
+for name in ("ordered", "time-sliced", "time-sliced, no class window"):
     a = rows[name]
     se = np.sqrt(a.var(0, ddof=1) / len(a) + b.var(0, ddof=1) / len(b)) / b.mean(0)
     print("%s / sequential (n = %d, %d seeds a side): ce, q05, q25, q50, q75 = %s  2 SE %s" % (name, n, len(seeds), np.round(a.mean(0) / b.mean(0), 4), np.round(2 * se, 4)))
