@@ -120,34 +120,13 @@ struct ae_entropy_optim {
     uint64_t ev_resident_blocks = 0;
     DevBuf<float> ev_slots;
     // time-sliced optimistic mode (ce_slice.hip)
-    DevBuf<uint32_t> sl_erec, sl_owner, sl_counts, sl_lists;
-    // The events of a batch segment, as the generator leaves them (ce_slice.hip): counts and offsets per edge, keys and events twice (the
-    // radix sort's double buffer), the step pointers (device + host), the slices' class orders.  TWO sets: a segment runs on one while the
-    // next segment's -- or, speculatively, the next batch's first -- is generated into the other on a side stream (`ahead`).
-    struct SlEventSet {
-        DevBuf<uint32_t> cnt, offs, keys0, keys1, vals0, vals1, sptr;
-        DevBuf<uint8_t> class_pos;
-        DevBuf<char> sort_tmp;                  // rocPRIM's temporary storage of the event sort (histograms), kept with the handle
-        std::vector<uint32_t> hptr;             // the step pointers on the host
-        std::vector<uint8_t> class_pos_h;       // the class order of every slice on the host
-        uint32_t total = 0;                     // events
-        bool in_second = false;                 // the sorted events are in vals1 / keys1
-        // what the set was generated FOR (valid: it holds a finished generation nobody has used yet)
-        bool valid = false;
-        uint32_t iter = 0, sg = 0, n_slices = 0, classes = 0, ov_every = 0, kstride = 0;
-        int spread = 0;
-        bool slice_keys = false;
-        double seg_samples = 0.;
-        uint64_t n_gen = 0, epoch = 0;
-    };
-    SlEventSet sl_ev, sl_ev_ahead;
-    uint64_t sl_ev_epoch = 0;                   // bumped by every preparation / colouring: a set generated before it is stale
-    hipStream_t sl_side_stream = nullptr;       // the generator's side stream (created with the first batch)
+    DevBuf<uint32_t> sl_erec, sl_owner, sl_counts, sl_cnt, sl_offs, sl_keys0, sl_keys1, sl_vals0, sl_vals1, sl_sptr, sl_lists;
     DevBuf<unsigned long long> sl_done;
     DevBuf<uint32_t> sl_chain_head, sl_chain_next;  // chain rounds: per node the head of its pending in-events' list (kept all-NIL between rounds), per list position the next link
+    DevBuf<char> sl_sort_tmp;                   // rocPRIM's temporary storage of the event sort (histograms), kept with the handle
     float sl_pmax = 0.f;
     bool sl_prepared = false;                   // ce_slice_prepare has run (a sharded handle defers it to the communicator's attach or its first batch)
-    DevBuf<uint8_t> sl_color;                   // per edge: its colour class (a matching) or the overflow mark
+    DevBuf<uint8_t> sl_color, sl_class_pos;     // per edge: its colour class (a matching) or the overflow mark; per batch: the class order of every slice
     DevBuf<uint32_t> sl_erec_gen;               // coloured graphs: the edge records in event-generation order (the edges of a class sorted by target) ...
     DevBuf<uint8_t> sl_color_gen;               // ... and their classes (then sl_erec / sl_color are released)
     DevBuf<unsigned long long> sl_dep;          // merged slices: per node, classes through with the node << 32 | classes with an event on it; all zero between slices
@@ -181,7 +160,6 @@ struct ae_entropy_optim {
     uint32_t comm_exchanges = 1;
     uint64_t comm_bytes = 0;                    // bytes of coordinate rows received through exchanges since the handle was created (the other ranks' rows x stride x 4 per exchange; every mode)
     ~ae_entropy_optim() {
-        if (sl_side_stream) { (void)hipStreamSynchronize(sl_side_stream); (void)hipStreamDestroy(sl_side_stream); }
         if (df_ahead.prep) { (void)hipStreamSynchronize(df_ahead.prep); (void)hipStreamDestroy(df_ahead.prep); }
         if (df_ahead.run) { (void)hipStreamSynchronize(df_ahead.run); (void)hipStreamDestroy(df_ahead.run); }
         for (hipEvent_t e : {df_ahead.start, df_ahead.ran, df_ahead.prepared}) if (e) (void)hipEventDestroy(e);

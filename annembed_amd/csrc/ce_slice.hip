@@ -307,6 +307,11 @@ __global__ void __launch_bounds__(256) sl_count_kernel(CeDev c, uint64_t n_gen, 
 // per configs[3] batch.  Drawing an edge's slices (the sort and the repeat rule below) is a third of this kernel's time and is paid twice
 // there, and the ranking runs at two workgroups per CU under 75 KB of LDS.  Commit f2c9fab holds the code; profiles/r06/r6_c4_buckets_ab.jsonl,
 // r6_evgen_buckets_kernel_stats_top.txt.)
+// (And GENERATION AHEAD: a second set of event buffers, the next segment's events -- after a batch's last segment the next batch's first,
+// speculatively: the same call with iter + 1 -- counted, filled and sorted on a side stream while the current segment's steps run.  The
+// generator then takes 20 ms beside the steps instead of 17 alone, and the steps take that much longer: 128.7 -> 127.2 ms per configs[3]
+// batch, 32.6 -> 31.9 on configs[2]'s large graph, at any stream priority -- for twice the event buffers (21 GB more at configs[3]).  Not
+// kept; commit d266210 holds the code, profiles/r06/r6_c4_ahead_ab.jsonl the measurement.)
 __global__ void __launch_bounds__(256) sl_fill_kernel(CeDev c, uint64_t n_gen, uint32_t key, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ offs,
                                                       uint32_t n_slices, const EdgeRec* __restrict__ erec, const uint8_t* __restrict__ color,
                                                       const uint8_t* __restrict__ class_pos, uint32_t classes, int spread, float ev_per_mass,
@@ -578,15 +583,15 @@ __global__ void __launch_bounds__(256) sl_chain_unlink_kernel(SliceArgs a, uint3
 // in/out form asks for a full copy of keys and values as temporary storage -- 7.6 GB at the C4 shape -- and its size follows the
 // batch's event count: whenever a batch set a new record the stream-ordered pool had to get a fresh block from the driver, 1.5-2 s,
 // a few times per run.  Found in round 3 as C4-shape batches of 300-900 ms among batches of 121 ms.)
-bool sort_events(DevBuf<char>& sort_tmp, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned begin_bit, unsigned end_bit) {
+bool sort_events(ae_entropy_optim* o, uint32_t* keys_a, uint32_t* keys_b, Event* vals_a, Event* vals_b, uint64_t count, unsigned begin_bit, unsigned end_bit) {
     static_assert(sizeof(Event) == 12, "events are sorted as 12-byte values");
     rocprim::double_buffer<uint32_t> dk(keys_a, keys_b);
     rocprim::double_buffer<Event> dv(vals_a, vals_b);
     size_t tmp_bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, begin_bit, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs (size query) failed");
-    if (sort_tmp.n < tmp_bytes + 1) sort_tmp.alloc(2 * tmp_bytes + 4096);  // (kept with the handle: no allocation in the batch)
-    if (rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, dk, dv, count, begin_bit, end_bit, stream()) != hipSuccess)
+    if (o->sl_sort_tmp.n < tmp_bytes + 1) o->sl_sort_tmp.alloc(2 * tmp_bytes + 4096);  // (kept with the handle: no allocation in the batch)
+    if (rocprim::radix_sort_pairs(o->sl_sort_tmp.p, tmp_bytes, dk, dv, count, begin_bit, end_bit, stream()) != hipSuccess)
         fail(AE_ERR_NO_DEVICE, "rocprim radix_sort_pairs failed");
     return dk.current() == keys_b;
 }
@@ -627,7 +632,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
     o->sl_cross_frac = 0.;
     o->sl_erec_gen.release();
     o->sl_color_gen.release();
-    o->sl_ev_epoch++;   // (events generated ahead for the old colouring are stale)
     const unsigned grid = blocks_for(nnz, 256), ngrid = blocks_for(n, 256);
     DevBuf<uint32_t> group_key, ident;
     group_key.alloc_pooled(nnz); ident.alloc_pooled(nnz);
@@ -821,7 +825,6 @@ static void slice_color_edges(ae_entropy_optim* o) {
 void ce_slice_prepare(ae_entropy_optim* o) {
     const ae_kgraph* g = o->g;
     if (ce_slice_unsupported(o)) return;  // reported by the first batch
-    o->sl_ev_epoch++;
     o->sl_erec.alloc(g->nnz * 4);  // EdgeRec as four words
     hipLaunchKernelGGL(sl_edge_rec_kernel, dim3(blocks_for(g->n, 256)), dim3(256), 0, stream(), o->dev, reinterpret_cast<EdgeRec*>(o->sl_erec.p));
     // static records: 16 floats serve rows of <= 7 neighbours, 32: <= 15, 64: <= 31, 128: 32
@@ -1073,15 +1076,9 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         d_backlog.download(&backlog, 1);
     }
     const uint64_t cap = (uint64_t)((4.0 * per_slice_ov + 16.0 * std::sqrt(per_slice_ov) + 2.0 * backlog) / kSub + 8192.0);  // per sub-list
-    using EventSet = ae_entropy_optim::SlEventSet;
-    auto size_event_set = [&](EventSet& B) {
-        if (B.cnt.n < n_gen + 1) { B.cnt.alloc(n_gen + 1); B.offs.alloc(n_gen + 1); }
-        if (B.keys0.n < ev_cap) { B.keys0.alloc(ev_cap); B.keys1.alloc(ev_cap); B.vals0.alloc(3 * ev_cap); B.vals1.alloc(3 * ev_cap); }   // (Event: three words)
-        if (B.sptr.n < n_keys + 2) B.sptr.alloc(n_keys + 2);
-        if (B.class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) B.class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
-        B.hptr.resize(n_keys + 2);
-        B.class_pos_h.resize((size_t)n_slices * std::max(1u, classes));
-    };
+    if (o->sl_cnt.n < n_gen + 1) { o->sl_cnt.alloc(n_gen + 1); o->sl_offs.alloc(n_gen + 1); }
+    if (o->sl_keys0.n < ev_cap) { o->sl_keys0.alloc(ev_cap); o->sl_keys1.alloc(ev_cap); o->sl_vals0.alloc(3 * ev_cap); o->sl_vals1.alloc(3 * ev_cap); }   // (Event: three words)
+    if (o->sl_sptr.n < n_keys + 2) o->sl_sptr.alloc(n_keys + 2);
     if (has_overflow && o->sl_lists.n < 3 * (uint64_t)kSub * cap * 4) o->sl_lists.alloc(3 * (uint64_t)kSub * cap * 4);
     if ((uint64_t)kSub * cap >= 0xFFFFFFFFull) fail(AE_ERR_INVALID_ARG, "AE_CE_SLICED: pending lists beyond 2^32 entries");
     if (has_overflow && o->sl_chain_next.n < (uint64_t)kSub * cap) o->sl_chain_next.alloc((uint64_t)kSub * cap);
@@ -1089,6 +1086,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         o->sl_chain_head.alloc(n);
         AE_HIP(hipMemsetAsync(o->sl_chain_head.p, 0xFF, sizeof(uint32_t) * n, stream()));
     }
+    if (o->sl_class_pos.n < (uint64_t)n_slices * std::max(1u, classes)) o->sl_class_pos.alloc((uint64_t)n_slices * std::max(1u, classes));
     unsigned kbits = 1;
     while (kbits < 32 && (n_keys >> kbits)) kbits++;
     const unsigned kbegin = slice_keys ? kClsBits : 0u;   // (the class bits are in order already)
@@ -1189,6 +1187,10 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     int drain_iterations = 0;
     const double t_begin = wall();
     o->sl_counts.zero();
+    std::vector<uint8_t> class_pos((size_t)n_slices * std::max(1u, classes));
+    std::vector<uint32_t> hptr(n_keys + 2);
+    Event* ev0 = reinterpret_cast<Event*>(o->sl_vals0.p);
+    Event* ev1 = reinterpret_cast<Event*>(o->sl_vals1.p);
     // one chain round over the pending list `cur` (see sl_chain_run_kernel); the f64-scalar debug variant keeps the passes
     const bool use_chains = !debug_knob("AE_SL_NO_CHAIN");
     auto chain_round = [&](unsigned grid) {
@@ -1256,7 +1258,7 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         ra.class_done = window ? o->sl_class_done.p + (size_t)s * classes : nullptr;
         ra.d = da;
         ra.d.ept = 1;
-        ra.sptr = o->sl_ev.sptr.p + (size_t)s * (classes + 1u);
+        ra.sptr = o->sl_sptr.p + (size_t)s * (classes + 1u);
         ra.classes = classes;
         ra.step_seq0 = step_seq_base + s * classes;
         ra.next_sptr = nullptr;
@@ -1273,59 +1275,54 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         }
         return ra;
     };
-    // THE EVENTS OF A SEGMENT into an event set (on the stream that is current: the library's, or the side stream of a generation ahead)
-    auto generate_events = [&](EventSet& B, uint32_t g_iter, uint32_t g_sg) {
-        const uint32_t gkey = (g_iter << 12) | g_sg;
+    for (uint32_t sg = 0; sg < segments; sg++) {
+        const uint32_t key = (iter << 12) | sg;
         const double t_seg = wall();
-        size_event_set(B);
-        Event* const ev0 = reinterpret_cast<Event*>(B.vals0.p);
-        Event* const ev1 = reinterpret_cast<Event*>(B.vals1.p);
         // the order of the classes inside every slice: a fresh uniform permutation (so the order of two events that share a node is
         // uniform, as in an i.i.d. sequence)
         {
-            std::mt19937_64 rng(o->dev.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)gkey << 20) + 0x5851F42D4C957F2Dull);
+            std::mt19937_64 rng(o->dev.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)key << 20) + 0x5851F42D4C957F2Dull);
             for (uint32_t s = 0; s < n_slices && classes; s++) {
-                uint8_t* row = B.class_pos_h.data() + (size_t)s * classes;
+                uint8_t* row = class_pos.data() + (size_t)s * classes;
                 for (uint32_t q = 0; q < classes; q++) row[q] = (uint8_t)q;
                 for (uint32_t q = classes - 1; q > 0; q--) std::swap(row[q], row[rng() % (q + 1)]);
             }
-            if (classes) B.class_pos.upload(B.class_pos_h.data(), B.class_pos_h.size());
+            if (classes) o->sl_class_pos.upload(class_pos.data(), class_pos.size());
         }
-        hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, (float)(seg_samples / (double)n), gkey, B.cnt.p);
+        hipLaunchKernelGGL(sl_count_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gen_erec, (float)(seg_samples / (double)n), key, o->sl_cnt.p);
         {
             size_t tmp_bytes = 0;
-            if (rocprim::exclusive_scan(nullptr, tmp_bytes, B.cnt.p, B.offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+            if (rocprim::exclusive_scan(nullptr, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
                 fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan (size query) failed");
             DevBuf<char> tmp;
             tmp.alloc_pooled(tmp_bytes ? tmp_bytes : 1);
-            if (rocprim::exclusive_scan(tmp.p, tmp_bytes, B.cnt.p, B.offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
+            if (rocprim::exclusive_scan(tmp.p, tmp_bytes, o->sl_cnt.p, o->sl_offs.p, 0u, n_gen, rocprim::plus<uint32_t>(), stream()) != hipSuccess)
                 fail(AE_ERR_NO_DEVICE, "rocprim exclusive_scan failed");
         }
         uint32_t last[2];
-        AE_HIP(hipMemcpyAsync(&last[0], B.offs.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
-        AE_HIP(hipMemcpyAsync(&last[1], B.cnt.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipMemcpyAsync(&last[0], o->sl_offs.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
+        AE_HIP(hipMemcpyAsync(&last[1], o->sl_cnt.p + (n_gen - 1), 4, hipMemcpyDeviceToHost, stream()));
         sync();
         const double t_cnt = wall();
         const uint32_t total = last[0] + last[1];
-        B.total = total;
         if (total > ev_cap) fail(AE_ERR_STATE, "AE_CE_SLICED: more events than the 8-sigma capacity");
-        hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gkey, (const uint32_t*)B.cnt.p,
-                           (const uint32_t*)B.offs.p, n_slices, gen_erec, gen_color,
-                           slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)B.class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
-                           ov_every, B.keys0.p, ev0);
+        hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
+                           (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
+                           slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread, (float)(seg_samples / (double)n / (double)n_slices),
+                           ov_every, o->sl_keys0.p, ev0);
         if (debug_knob("AE_SL_CHECK_FILL")) {   // (test) the same fill with every edge's slices in order, both sorted: word for word the same events and keys
             DevBuf<uint32_t> k2, k3, v2, v3;
             k2.alloc_pooled(total + 1); k3.alloc_pooled(total + 1); v2.alloc_pooled(3ull * total + 3); v3.alloc_pooled(3ull * total + 3);
-            hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, gkey, (const uint32_t*)B.cnt.p,
-                               (const uint32_t*)B.offs.p, n_slices, gen_erec, gen_color,
-                               slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)B.class_pos.p, classes, spread | 4, (float)(seg_samples / (double)n / (double)n_slices),
+            hipLaunchKernelGGL(sl_fill_kernel, dim3(blocks_for(n_gen, 256)), dim3(256), 0, stream(), o->dev, n_gen, key, (const uint32_t*)o->sl_cnt.p,
+                               (const uint32_t*)o->sl_offs.p, n_slices, gen_erec, gen_color,
+                               slice_keys ? (const uint8_t*)nullptr : (const uint8_t*)o->sl_class_pos.p, classes, spread | 4, (float)(seg_samples / (double)n / (double)n_slices),
                                ov_every, k2.p, reinterpret_cast<Event*>(v2.p));
-            const bool ref_second = sort_events(B.sort_tmp, k2.p, k3.p, reinterpret_cast<Event*>(v2.p), reinterpret_cast<Event*>(v3.p), total, kbegin, kbits);
+            const bool ref_second = sort_events(o, k2.p, k3.p, reinterpret_cast<Event*>(v2.p), reinterpret_cast<Event*>(v3.p), total, kbegin, kbits);
             DevBuf<uint32_t> k0c, v0c, k1c, v1c;   // (copies: the batch's own sort follows on the originals)
             k0c.alloc_pooled(total + 1); k1c.alloc_pooled(total + 1); v0c.alloc_pooled(3ull * total + 3); v1c.alloc_pooled(3ull * total + 3);
-            AE_HIP(hipMemcpyAsync(k0c.p, B.keys0.p, 4ull * total, hipMemcpyDeviceToDevice, stream()));
+            AE_HIP(hipMemcpyAsync(k0c.p, o->sl_keys0.p, 4ull * total, hipMemcpyDeviceToDevice, stream()));
             AE_HIP(hipMemcpyAsync(v0c.p, ev0, 12ull * total, hipMemcpyDeviceToDevice, stream()));
-            const bool got_second = sort_events(B.sort_tmp, k0c.p, k1c.p, reinterpret_cast<Event*>(v0c.p), reinterpret_cast<Event*>(v1c.p), total, kbegin, kbits);
+            const bool got_second = sort_events(o, k0c.p, k1c.p, reinterpret_cast<Event*>(v0c.p), reinterpret_cast<Event*>(v1c.p), total, kbegin, kbits);
             DevBuf<unsigned long long> bad;
             bad.alloc_pooled(2);
             bad.zero();
@@ -1340,52 +1337,20 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
         }
         if (prof) sync();
         const double t_fill = wall();
-        const bool in_second = sort_events(B.sort_tmp, B.keys0.p, B.keys1.p, ev0, ev1, total, kbegin, kbits);
-        B.in_second = in_second;
-        const uint32_t* sorted_keys = in_second ? B.keys1.p : B.keys0.p;
+        const bool in_second = sort_events(o, o->sl_keys0.p, o->sl_keys1.p, ev0, ev1, total, kbegin, kbits);
+        const uint32_t* sorted_keys = in_second ? o->sl_keys1.p : o->sl_keys0.p;
+        Event* sorted_ev = in_second ? ev1 : ev0;
         if (prof) sync();
         const double t_sort = wall();
         hipLaunchKernelGGL(sl_sptr_kernel, dim3(blocks_for(n_keys + 1, 256)), dim3(256), 0, stream(), sorted_keys, total, (uint32_t)n_keys,
-                           B.sptr.p);
+                           o->sl_sptr.p);
         check_launch("sl_events");
-        B.sptr.download(B.hptr.data(), n_keys + 1);
+        o->sl_sptr.download(hptr.data(), n_keys + 1);
         const double t_ev = wall();
+        t_evgen += t_ev - t_seg;
         if (prof && t_ev - t_seg > 0.1)
             fprintf(stderr, "CESLICE slow event generation: permutation + count + scan %.1f ms, fill %.1f ms, sort %.1f ms, slice pointers + download %.1f ms\n",
                     (t_cnt - t_seg) * 1e3, (t_fill - t_cnt) * 1e3, (t_sort - t_fill) * 1e3, (t_ev - t_sort) * 1e3);
-        B.valid = true;
-        B.iter = g_iter; B.sg = g_sg; B.n_slices = n_slices; B.classes = classes; B.ov_every = ov_every; B.kstride = kstride; B.spread = spread;
-        B.slice_keys = slice_keys; B.seg_samples = seg_samples; B.n_gen = n_gen; B.epoch = o->sl_ev_epoch;
-    };
-    auto generated_for = [&](const EventSet& B, uint32_t g_iter, uint32_t g_sg) {
-        return B.valid && B.iter == g_iter && B.sg == g_sg && B.n_slices == n_slices && B.classes == classes && B.ov_every == ov_every && B.kstride == kstride &&
-               B.spread == spread && B.slice_keys == slice_keys && B.seg_samples == seg_samples && B.n_gen == n_gen && B.epoch == o->sl_ev_epoch &&
-               B.hptr.size() == n_keys + 2;
-    };
-    // GENERATION AHEAD (round 6): while a segment's steps run -- they are enqueued long before they finish -- the NEXT segment's events (the
-    // next batch's first segment after a batch's last: the same call with iter + 1, what Embedder::embed makes; any other next call generates
-    // afresh) are drawn, filled and sorted on a side stream into the other event set.  AE_SL_NO_AHEAD: off.
-    const bool ahead = !debug_knob("AE_SL_NO_AHEAD") && !debug_knob("AE_SL_CHECK_FILL");
-    int ahead_hits = 0;
-    double t_ahead = 0.;
-    if (ahead && !o->sl_side_stream) AE_HIP(hipStreamCreateWithFlags(&o->sl_side_stream, hipStreamNonBlocking));
-    for (uint32_t sg = 0; sg < segments; sg++) {
-        const uint32_t key = (iter << 12) | sg;
-        const double t_seg = wall();
-        if (generated_for(o->sl_ev_ahead, iter, sg)) {
-            std::swap(o->sl_ev, o->sl_ev_ahead);
-            ahead_hits++;
-        } else {
-            generate_events(o->sl_ev, iter, sg);
-        }
-        o->sl_ev.valid = false;   // (in use: not a generation ahead any more)
-        o->sl_ev_ahead.valid = false;
-        const EventSet& E = o->sl_ev;
-        const std::vector<uint32_t>& hptr = E.hptr;
-        const std::vector<uint8_t>& class_pos = E.class_pos_h;
-        Event* const sorted_ev = reinterpret_cast<Event*>(E.in_second ? E.vals1.p : E.vals0.p);
-        const double t_ev = wall();
-        t_evgen += t_ev - t_seg;
         a.ev = sorted_ev;
         da.ev = sorted_ev;
         a.key = key;
@@ -1529,22 +1494,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
                 AE_HIP(hipStreamWaitEvent(stream(), dbg_ev, 0));
             }
         }
-        double t_enq = wall();
+        const double t_enq = wall();
         t_enqueue += t_enq - t_ev;
-        if (ahead && (sg + 1u < segments || iter + 1u < (1u << 20))) {   // the next segment's events, beside this segment's steps
-            const bool last = sg + 1u == segments;
-            StreamScope side(o->sl_side_stream);
-            try {
-                generate_events(o->sl_ev_ahead, last ? iter + 1u : iter, last ? 0u : sg + 1u);
-                sync();   // (the side stream: the set is complete before anybody asks for it)
-            } catch (...) {   // (a speculative generation must not fail THIS batch: whoever needs those events generates them again, and reports)
-                o->sl_ev_ahead.valid = false;
-                (void)hipStreamSynchronize(o->sl_side_stream);
-            }
-            const double t_done = wall();
-            t_ahead += t_done - t_enq;
-            t_enq = t_done;
-        }
         // drain: passes until nothing is pending (a look at the counters every 8 passes)
         uint64_t drain_prev_left = 0;
         int drain_prev_pass = 0;
@@ -1597,8 +1548,8 @@ void ce_slice_gradient_iteration(ae_entropy_optim* o, uint64_t nb_sample, double
     }
     owe.armed = false;
     if (own_copy) move_rows(0, n, 0, 0, (const float*)(o->sl_y.p + row_at), o->dev.y, 0);   // back to the caller's labels and row stride
-    if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms (%d of %u segments generated ahead), slices enqueued in %.1f ms, generation ahead (host) %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
-                      t_evgen * 1e3, ahead_hits, segments, t_enqueue * 1e3, t_ahead * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
+    if (prof) fprintf(stderr, "CESLICE batch %u: event generation %.1f ms, slices enqueued in %.1f ms, first look + drain %.1f ms (%d looks), total %.1f ms\n", iter,
+                      t_evgen * 1e3, t_enqueue * 1e3, t_drain * 1e3, drain_iterations, (wall() - t_begin) * 1e3);
     check_launch("ce_slice");
     std::vector<unsigned long long> h = o->sl_done.to_host();
     o->sl_done.zero();
