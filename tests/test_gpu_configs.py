@@ -93,8 +93,8 @@ def test_k6_blobs_without_hubness_40_batches(A):
     -2.5 ... -3 % over four seeds, +0.4 ... +0.8 % / -1 ... -2 % over sixteen (both launch forms; optimistic path +1.1 % / -1.4 ... -2.8 %;
     r5_fidelity_means.txt).  Round 6 resolved the forms with 32 seeds a side (profiles/r06/r6_blobs_forms.txt): ONE LAUNCH PER CLASS is the
     exact mode's within a standard error whatever the palette (11 / 13 / 15 / 19 classes: CE 0.997-1.002, median edge 0.992-1.006; 2 SE 0.7 % /
-    1.2 %) -- floors 1 % / 3 % / 1 % / 3 %; MERGED SLICES carry a bias of CE +1.1 %, quartiles -2 ... -2.5 % (three 32-seed runs: CE 1.009-1.011,
-    median edge 0.978-0.981) -- floors 1.5 % / 3.5 % / 3 % / 3 % = what is claimed, and the same against one launch per class.  Its cause is
+    1.2 %) -- floors 1 % / 3 % / 1 % / 3 %; MERGED SLICES as rounds 4-5 ran them carried a bias of CE +1.1 %, quartiles -2 ... -2.5 % (three 32-seed
+    runs: CE 1.009-1.011, median edge 0.978-0.981; floors 1.5 % / 3.5 % / 3 % / 3 % then).  Its cause is
     the AGE of the negatives' rows: a merged launch reads them as the slice found them; one launch per class with the negatives read from a
     snapshot taken every 1 / 4 / 16 slices reproduces the sign and a dose-response (CE 1.004 / 1.028 / 1.110, median edge 0.991 / 0.946 / 0.820).
     And CLOSED in round 6 by the class window (a workgroup of a merged launch reads its negatives once the class half a palette before
