@@ -173,7 +173,10 @@ enum {
        seeds -- its negatives are a slice old: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
        sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
        the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
-       exchange. */
+       exchange.  Where the slices run merged (AE_SLICE_MERGED_WINDOW) the launches rely on the device starting a grid's workgroups in
+       index order -- a workgroup only ever waits for one started before it -- with every wait under a poll budget: a violation (seen only
+       under CU masks that strand workgroups) ends the batch with AE_ERR_STATE instead of a hang.  Do not run this mode on a CU-masked
+       stream. */
     AE_CE_SLICED = 5,
     /* The samples of AE_CE_SEQUENTIAL (same Philox plan, same order, same f64 arithmetic) with only their two END POINTS as
        dependencies: every attraction is applied to the rows the previous writers of i and j produced, exactly as the sequential
