@@ -231,7 +231,7 @@ SLICE_FORMS = {0: "none", 1: "one launch per class", 2: "one launch per class, n
 FAITHFUL_FRESH = "statistically (one launch per class: negatives a step old; inside the exact mode's standard error at 32 seeds)"
 FAITHFUL_WINDOW = ("statistically (merged slices with the class window: negatives half a slice old at most; CE +0.12 +- 0.22 %, median edge -0.18 +- 0.43 % "
                    "against one launch per class at 256 seeds a side on the stiff 2-D graph: inside the standard error)")
-FAITHFUL_STALE = ("statistically, with a RESOLVED BIAS on stiff 2-D graphs: final cross entropy +1 %, median edge -2 % at 32 seeds (optimistic passes / merged "
+FAITHFUL_STALE = ("statistically, with a RESOLVED BIAS on stiff 2-D graphs: final cross entropy +0.4 %, median edge -0.7 % at 256 seeds (optimistic passes / merged "
                   "slices without their class window read a slice's negatives as the slice found them; not visible at 8 columns; DESIGN.md 4.3b)")
 
 
@@ -574,7 +574,7 @@ def compact_line(full):
     if brief:
         out["scale_shapes"] = brief
         if any(str(v.get("form", "")).endswith("*") for v in brief.values()):
-            out["form_note"] = "*: negatives a slice old: CE +1 %, median edge -2 % on stiff 2-D graphs (DESIGN 4.3b)"
+            out["form_note"] = "*: optimistic passes: CE +0.4 %, median edge -0.7 % on stiff 2-D graphs at 256 seeds (DESIGN 4.3b)"
 
     if full.get("end_to_end"):
         out["end_to_end"] = {k: v for k, v in full["end_to_end"].items() if k != "note"}

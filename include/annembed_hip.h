@@ -145,7 +145,8 @@ enum {
        WINDOW of round 6 (a workgroup reads its negatives only once the class half a palette before its own is through; rows written
        through the caches) cross entropy +0.12 +- 0.22 %, median edge -0.18 +- 0.43 % against one launch per class at 256 seeds a side --
        inside the standard error too (profiles/r06/r6_blobs_window256.txt).  Without the window (rounds 4-5, and the optimistic passes
-       still): cross entropy +0.34 +- 0.23 % ... +1 %, median edge -0.7 +- 0.4 % ... -2 % -- a RESOLVED bias on stiff 2-D graphs (not
+       still: +0.38 +- 0.22 % / -0.69 +- 0.41 % against the exact mode at 256 seeds, profiles/r06/r6_blobs_optwindow256.txt; the 32-seed runs
+       of earlier rounds read +1 % / -2 %): cross entropy +0.34 +- 0.23 %, median edge -0.7 +- 0.4 % -- a RESOLVED bias on stiff 2-D graphs (not
        visible at 8 columns).  Its cause, isolated in round 6: the AGE of the negatives' rows.  A merged launch without the window reads
        a slice's negatives as the slice found them (half an event per node stale on average); with one launch per class they are a step
        old.  One launch per class with its negatives read from a copy of the coordinates refreshed every 1 / 4 / 16 slices reproduces
@@ -169,7 +170,7 @@ enum {
        Two events of an edge inside a slice stay together with the probability an i.i.d. sequence gives them.  Statistical
        parity like AE_CE_EVENT (over ten seeds the means of CE and of the edge-length quantiles are the exact mode's within a
        standard error on graphs of 8 columns; on stiff 2-column graphs one launch per class and the merged slices with their class
-       window are inside the standard error, the optimistic form sits at CE +1 %, median edge -2 % against the exact mode at 32
+       window are inside the standard error, the optimistic form sits at CE +0.4 %, median edge -0.7 % against the exact mode at 256
        seeds -- its negatives are a slice old: see AE_CE_AUTO), throughput-bound, any asked_dim in [1, 64], rows of <= 32 neighbours, <= 2^27 nodes; one device, or a
        sharded node range with a communicator (ae_entropy_optim_set_comm / ae_embedder_set_comm): a shard generates the events of
        the edges whose source it owns, cross-shard edges fire as two half events, other shards' rows are read as of the last
